@@ -1,0 +1,171 @@
+"""ctypes binding of libpp_hip.so (the C ABI declared in include/pp_hip.h).
+
+The library is the product: if it is missing this module raises -- there is no
+Python or CPU fallback for any compute entry point.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libpp_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", f)
+           for f in ("pp_runtime.hip", "pp_voxelize.hip", "pp_iou.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "pp_common.h"), os.path.join(_ROOT, "include", "pp_hip.h")]
+
+PP_OK, PP_ERR_INDEX, PP_ERR_VALUE, PP_ERR_WINDING = 0, -2, -3, -4
+PP_ERR_NOMEM, PP_ERR_HIP, PP_ERR_INTERNAL = -5, -6, -7
+ORDER_ROW_MAJOR, ORDER_SCRAMBLED = 0, 1
+NUM_FEATURES = 9
+MAX_BATCH = 32
+
+EXPORTS = [
+    "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
+    "pp_voxelize_reserve", "pp_voxelize_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
+    "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_ctx_set_timing",
+    "pp_ctx_read_emit_ms",
+]
+
+
+class VoxelParams(ctypes.Structure):
+    """pp_voxel_params_t: the scalar arguments of create_pillars
+    (/root/reference data/pillars.cpp:239-249)."""
+    _fields_ = [
+        ("max_points_per_pillar", ctypes.c_int32), ("max_pillars", ctypes.c_int32),
+        ("x_step", ctypes.c_double), ("y_step", ctypes.c_double),
+        ("x_min", ctypes.c_double), ("y_min", ctypes.c_double), ("z_min", ctypes.c_double),
+        ("x_max", ctypes.c_double), ("y_max", ctypes.c_double), ("z_max", ctypes.c_double),
+        ("canvas_height", ctypes.c_double),
+        ("order", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+class TargetParams(ctypes.Structure):
+    _fields_ = [("pos_thresh", ctypes.c_double), ("canvas_height", ctypes.c_double),
+                ("num_classes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into libpp_hip.so (in-tree)."""
+    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off",            # every f64 product/sum rounds separately
+           "--offload-arch=gfx950",
+           "-I" + os.path.join(_ROOT, "include"),
+           "-Wl,-rpath,/opt/rocm/lib",
+           *SOURCES, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libpp_hip.so once per process; never initialises HIP by itself."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback.")
+        try:  # share torch's HIP runtime (same SONAME) when torch is in the process
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the host drop-in
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        c_int, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+        pi64 = ctypes.POINTER(ctypes.c_int64)
+        L.pp_last_error.restype = ctypes.c_char_p
+        L.pp_version.restype = ctypes.c_char_p
+        L.pp_device_count.restype = c_int
+        L.pp_ctx_create.argtypes = [c_int, ctypes.POINTER(vp)]
+        L.pp_ctx_destroy.argtypes = [vp]
+        L.pp_ctx_destroy.restype = None
+        L.pp_voxelize_reserve.argtypes = [vp, c_int, i64, ctypes.POINTER(VoxelParams)]
+        L.pp_voxelize_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                      ctypes.POINTER(VoxelParams), vp, vp, vp]
+        L.pp_create_pillars_f64.argtypes = [vp, vp, i64, i64, i64, vp, pi64, pi64, vp, pi64, pi64,
+                                            ctypes.POINTER(VoxelParams), pi64]
+        L.pp_make_ious_f64.argtypes = [vp, vp, i64, pi64, vp, i64, pi64, vp, pi64, vp, pi64, vp, pi64]
+        L.pp_iou_check.argtypes = [vp, vp]
+        L.pp_make_ious_dev.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i64, vp]
+        L.pp_assign_targets_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
+                                            vp, ctypes.POINTER(TargetParams), vp, vp]
+        L.pp_ctx_set_timing.argtypes = [vp, c_int]
+        L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
+                                          ctypes.POINTER(c_int)]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name not in ("pp_last_error", "pp_version", "pp_ctx_destroy"):
+                fn.restype = c_int
+        _lib = L
+    return _lib
+
+
+class PPError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    """Map a PP_ERR_* code to the exception the reference's pybind11 module
+    raises for the same condition (IndexError) or to a loud failure."""
+    if rc == PP_OK:
+        return
+    msg = lib().pp_last_error().decode("utf-8", "replace")
+    msg = f"{what}: {msg}" if what else msg
+    if rc == PP_ERR_INDEX:
+        raise IndexError(msg)          # pybind11 index_error
+    if rc == PP_ERR_VALUE:
+        raise ValueError(msg)
+    if rc == PP_ERR_WINDING:
+        raise ValueError(msg)          # reference: std::exit(1), pillars.cpp:166-169
+    if rc == PP_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise PPError(f"{msg} (rc={rc})")
+
+
+class Context:
+    """Owner of one pp_ctx_t (scratch buffers for one device / one stream)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib().pp_ctx_create(int(device), ctypes.byref(self._h)), "pp_ctx_create")
+        self.device = int(device)
+        self._pid = os.getpid()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and self._pid == os.getpid():
+            lib().pp_ctx_destroy(self._h)
+        self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_voxel_params(max_points_per_pillar, max_pillars, x_step, y_step, x_min, y_min, z_min,
+                      x_max, y_max, z_max, canvas_height, order=ORDER_ROW_MAJOR):
+    return VoxelParams(int(max_points_per_pillar), int(max_pillars), float(x_step), float(y_step),
+                       float(x_min), float(y_min), float(z_min), float(x_max), float(y_max),
+                       float(z_max), float(canvas_height), int(order), 0)

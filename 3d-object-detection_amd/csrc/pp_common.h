@@ -1,0 +1,74 @@
+// pp_common.h -- shared host-side plumbing of libpp_hip.so (context, errors,
+// workspace).  gfx950 / ROCm only; there is deliberately no CPU path here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "pp_hip.h"
+
+namespace pp {
+
+void set_error(const char *fmt, ...);
+
+#define PP_HIP_TRY(expr)                                                        \
+  do {                                                                          \
+    hipError_t e__ = (expr);                                                    \
+    if (e__ != hipSuccess) {                                                    \
+      pp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                    __FILE__, __LINE__);                                        \
+      return PP_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+// A grow-only device buffer.
+struct DevBuf {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need, bool *grew = nullptr);
+  void release();
+};
+
+// A grow-only pinned host buffer (staging for the host drop-in entry points).
+struct PinBuf {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need);
+  void release();
+};
+
+// Geometry of the implied cell grid, derived from the create_pillars scalars.
+struct GridGeom {
+  double x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max, canvas_height;
+  int nx, ny;         // columns / rows of the cell grid
+  int ncells;         // nx * ny
+  int ncells_pad;     // rounded up to the scan tile
+  int order;          // PP_ORDER_*
+  unsigned long long mult, mult_inv;  // scrambled order: slot = cell*mult % ncells
+};
+
+int make_grid(const pp_voxel_params_t *prm, GridGeom *g);
+
+}  // namespace pp
+
+struct pp_ctx {
+  int device = 0;
+  // voxelizer scratch, laid out by VoxWorkspace (pp_voxelize.hip)
+  pp::DevBuf vox_ws;
+  unsigned long long vox_layout_key[6] = {0, 0, 0, 0, 0, 0};
+  // host drop-in staging
+  pp::DevBuf stage_in, stage_out, stage_out2;
+  pp::PinBuf pin_in, pin_out, pin_meta;
+  // IoU / target scratch
+  pp::DevBuf iou_ws;
+  // emit-kernel timing ring (bench.py)
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  int ev_slots = 0;
+  int ev_next = 0;
+  int ev_count = 0;
+};

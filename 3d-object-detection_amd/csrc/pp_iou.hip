@@ -1,0 +1,482 @@
+// pp_iou.hip -- rotated-box anchor/ground-truth IoU and the fused anchor-target
+// assignment as hand-written HIP for gfx950.
+//
+// Replaces make_ious + iou (/root/reference data/pillars.cpp:400-427, 132-172)
+// and, fused on the device-resident path, create_target + make_target
+// (utils/box_utils.py:162-232, 70-109) so that the [A,G] IoU matrix is never
+// materialised.
+//
+// Boost.Geometry (bg::intersection / bg::area, pillars.cpp:160,164,165) is an
+// absent, unpinned third-party dependency of the reference; its published
+// behaviour for convex quads is restated as Sutherland-Hodgman clipping plus a
+// shoelace area, executed in f64 with contraction disabled in exactly the
+// operation order of oracle/pp_oracle.c, so HIP-vs-oracle parity is bit-exact.
+
+#include "pp_common.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+namespace pp {
+
+constexpr int kIouThreads = 256;
+using u64 = unsigned long long;
+
+__device__ __forceinline__ double shoelace_dev(const double *q, int n) {
+  double s = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const int j = (k + 1 == n) ? 0 : k + 1;
+    s = s + (q[2 * k] * q[2 * j + 1] - q[2 * j] * q[2 * k + 1]);
+  }
+  return 0.5 * s;
+}
+
+// pillars.cpp:132-172 for one pair.  a: anchor corners, declared counter-
+// clockwise; g: ground-truth corners, declared clockwise.  *bad is set when a
+// declared-orientation area is negative (the reference's "IOU < 0" exit).
+__device__ double iou_pair_dev(const double a[8], const double g[8], bool *bad) {
+  const double area_a = shoelace_dev(a, 4);
+  const double area_g = -shoelace_dev(g, 4);
+  if (area_a < 0.0 || area_g < 0.0) {
+    *bad = true;
+    return -1.0;
+  }
+  double poly[2][16];
+  int n = 4, cur = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) poly[0][k] = a[k];
+  for (int e = 0; e < 4 && n > 0; ++e) {
+    const int ia = (4 - e) & 3, ib = (3 - e) & 3;
+    const double ax = g[2 * ia], ay = g[2 * ia + 1];
+    const double ex = g[2 * ib] - ax, ey = g[2 * ib + 1] - ay;
+    const double *in = poly[cur];
+    double *out = poly[cur ^ 1];
+    int m = 0;
+    double px = in[2 * (n - 1)], py = in[2 * (n - 1) + 1];
+    double dp = ex * (py - ay) - ey * (px - ax);
+    for (int i = 0; i < n; ++i) {
+      const double cx = in[2 * i], cy = in[2 * i + 1];
+      const double dc = ex * (cy - ay) - ey * (cx - ax);
+      if ((dc >= 0.0) != (dp >= 0.0)) {
+        const double t = dp / (dp - dc);
+        out[2 * m] = px + t * (cx - px);
+        out[2 * m + 1] = py + t * (cy - py);
+        ++m;
+      }
+      if (dc >= 0.0) {
+        out[2 * m] = cx;
+        out[2 * m + 1] = cy;
+        ++m;
+      }
+      px = cx;
+      py = cy;
+      dp = dc;
+    }
+    n = m;
+    cur ^= 1;
+  }
+  if (n < 3) return 0.0;
+  const double inter = shoelace_dev(poly[cur], n);
+  if (!(inter > 0.0)) return 0.0;
+  return inter / (area_a + area_g - inter);
+}
+
+// the +-10 cell centre gate of pillars.cpp:418-419
+__device__ __forceinline__ bool gate_far(double acx, double acy, double gcx, double gcy) {
+  return (fabs(acx - gcx) > 10.0) || (fabs(acy - gcy) > 10.0);
+}
+
+// ------------------------------------------------------------------------- //
+// make_ious: one lane per (anchor, gt) entry, coalesced f64 stores           //
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(kIouThreads) void k_make_ious(
+    const double *__restrict__ a_corners, const double *__restrict__ a_centers, int acols,
+    int64_t A, const double *__restrict__ g_corners, const double *__restrict__ g_centers,
+    int gcols, int G, double *__restrict__ ious, int *errflag) {
+  const int64_t total = A * G;
+  for (int64_t e = (int64_t)blockIdx.x * kIouThreads + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kIouThreads) {
+    const int64_t i = e / G;
+    const int j = (int)(e - i * G);
+    const double acx = a_centers[i * acols], acy = a_centers[i * acols + 1];
+    const double gcx = g_centers[(int64_t)j * gcols], gcy = g_centers[(int64_t)j * gcols + 1];
+    double v = 0.0;
+    if (!gate_far(acx, acy, gcx, gcy)) {
+      double a[8], g[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a[k] = a_corners[i * 8 + k];
+        g[k] = g_corners[(int64_t)j * 8 + k];
+      }
+      bool bad = false;
+      v = iou_pair_dev(a, g, &bad);
+      if (bad) atomicExch(errflag, 1);
+    }
+    ious[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// fused target assignment                                                    //
+// ------------------------------------------------------------------------- //
+struct TargetArgs {
+  int64_t A;
+  int G;
+  const double *a_corners, *a_centers, *a_wlh, *a_yaw;
+  const double *g_corners, *g_centers_img, *g_centers, *g_wlh, *g_yaw;
+  const int *g_class;
+  double pos_thresh, canvas_height;
+  int num_classes;
+  // scratch
+  u64 *col_max;  // [G] bit pattern of the column maximum IoU (0 = all zero)
+  int *col_arg;  // [G] first anchor reaching the column maximum
+  int *errflag;
+  // outputs
+  float *cls_targets;  // [A][num_classes]
+  float *reg_targets;  // [A][9]
+};
+
+// utils/box_utils.py:70-109
+__device__ void make_target_dev(const TargetArgs &t, int64_t i, int j, float out[9]) {
+  const double ax = t.a_centers[i * 3], ay = t.a_centers[i * 3 + 1], az = t.a_centers[i * 3 + 2];
+  const double gx = t.g_centers[j * 3];
+  double gy = t.g_centers[j * 3 + 1];
+  const double gz = t.g_centers[j * 3 + 2];
+  const double aw = t.a_wlh[i * 3], al = t.a_wlh[i * 3 + 1], ah = t.a_wlh[i * 3 + 2];
+  const double gw = t.g_wlh[j * 3], gl = t.g_wlh[j * 3 + 1], gh = t.g_wlh[j * 3 + 2];
+  const double ad = sqrt(aw * aw + al * al);
+  const double at = t.a_yaw[i];
+  double gt = t.g_yaw[j];
+  const double pi = 3.141592653589793;  // np.pi
+  gy = (t.canvas_height - 1) - gy;       // box_utils.py:83
+  const double dx = (gx - ax) / ad;
+  const double dy = (gy - ay) / ad;
+  const double dz = (gz - az) / ah;
+  const double dw = log(gw / aw);
+  const double dl = log(gl / al);
+  const double dh = log(gh / ah);
+  if (gt <= pi && gt >= pi / 2)  // box_utils.py:92-95
+    gt -= pi;
+  else if (gt >= -pi && gt <= -pi / 2)
+    gt += pi;
+  const double dt = sin(gt - at);
+  const double df = gt - at;
+  const double ort =
+      ((df <= pi && df >= pi / 2) || (df >= -pi && df <= -pi / 2)) ? 1.0 : 0.0;  // :99-102
+  out[0] = 1.0f;
+  out[1] = (float)dx;
+  out[2] = (float)dy;
+  out[3] = (float)dz;
+  out[4] = (float)dw;
+  out[5] = (float)dl;
+  out[6] = (float)dh;
+  out[7] = (float)dt;
+  out[8] = (float)ort;
+}
+
+__device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad) {
+  double a[8], g[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = t.a_corners[i * 8 + k];
+    g[k] = t.g_corners[(int64_t)j * 8 + k];
+  }
+  return iou_pair_dev(a, g, bad);
+}
+
+// T1: one lane per anchor.  Row maximum / first argmax over the ground truths
+// (box_utils.py:193-196), positive rows of both targets (:211, :219-221),
+// zero rows otherwise, and the column maxima via 64-bit atomicMax on the f64
+// bit pattern (IoU >= 0, so the patterns order like the values).
+__global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
+  const int64_t i = (int64_t)blockIdx.x * kIouThreads + threadIdx.x;
+  if (i >= t.A) return;
+  const double acx = t.a_centers[i * 3], acy = t.a_centers[i * 3 + 1];
+  double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
+  int best_j = 0;
+  bool bad = false;
+  for (int j = 0; j < t.G; ++j) {
+    const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
+    if (gate_far(acx, acy, gcx, gcy)) continue;
+    const double v = pair_iou(t, i, j, &bad);
+    if (v > best) {  // strict: first maximum wins, like np.argmax
+      best = v;
+      best_j = j;
+    }
+    if (v > 0.0) atomicMax(&t.col_max[j], (u64)__double_as_longlong(v));
+  }
+  if (bad) atomicExch(t.errflag, 1);
+  float *cls = t.cls_targets + i * t.num_classes;
+  float *reg = t.reg_targets + i * 9;
+  const bool pos = best > t.pos_thresh;  // box_utils.py:195 (strict >)
+  const int cj = pos ? t.g_class[best_j] : -1;
+  for (int c = 0; c < t.num_classes; ++c) cls[c] = (c == cj) ? 1.0f : 0.0f;
+  float r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (pos) make_target_dev(t, i, best_j, r);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) reg[d] = r[d];
+}
+
+// T2: first anchor index that reaches each column maximum (np.argmax over the
+// transposed matrix, box_utils.py:199-200).  Recomputes the (deterministic)
+// IoU of the gated pairs instead of storing candidates.
+__global__ __launch_bounds__(kIouThreads) void k_targets_cols(TargetArgs t) {
+  const int64_t i = (int64_t)blockIdx.x * kIouThreads + threadIdx.x;
+  if (i >= t.A) return;
+  const double acx = t.a_centers[i * 3], acy = t.a_centers[i * 3 + 1];
+  bool bad = false;
+  for (int j = 0; j < t.G; ++j) {
+    const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
+    if (gate_far(acx, acy, gcx, gcy)) continue;
+    const double v = pair_iou(t, i, j, &bad);
+    if (v > 0.0 && (u64)__double_as_longlong(v) == t.col_max[j]) atomicMin(&t.col_arg[j], (int)i);
+  }
+}
+
+// T3 (one workgroup): the highest-IoU anchor of every ground truth overrides
+// the row written by T1 (box_utils.py:204-205, 212-213, 223-228).  A column
+// whose argmax is anchor 0 -- all-zero columns included -- is dropped, exactly
+// like the reference's np.nonzero filter.
+__global__ __launch_bounds__(kIouThreads) void k_targets_forced(TargetArgs t) {
+  const int G = t.G;
+  // phase A: clear the class rows of all forced anchors
+  for (int j = threadIdx.x; j < G; j += kIouThreads) {
+    const int i = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
+    if (i != 0) {
+      float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+      for (int c = 0; c < t.num_classes; ++c) cls[c] = 0.0f;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // phase B: set the classes (duplicates of one anchor set several ones, as
+  // numpy's fancy assignment does); regression row: the last ground truth wins
+  for (int j = threadIdx.x; j < G; j += kIouThreads) {
+    const int i = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
+    if (i == 0) continue;
+    t.cls_targets[(int64_t)i * t.num_classes + t.g_class[j]] = 1.0f;
+    bool later = false;
+    for (int j2 = j + 1; j2 < G; ++j2) {
+      const int i2 = (t.col_max[j2] != 0ull) ? t.col_arg[j2] : 0;
+      later = later || (i2 == i);
+    }
+    if (!later) {
+      float r[9];
+      make_target_dev(t, i, j, r);
+      float *reg = t.reg_targets + (int64_t)i * 9;
+      for (int d = 0; d < 9; ++d) reg[d] = r[d];
+    }
+  }
+}
+
+__global__ void k_targets_init(u64 *col_max, int *col_arg, int G, int *errflag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < G) {
+    col_max[j] = 0ull;
+    col_arg[j] = INT_MAX;
+  }
+  if (j == 0) *errflag = 0;
+}
+
+namespace {
+struct DeviceGuard2 {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard2(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess) {
+      ok = true;
+      if (prev != dev) (void)hipSetDevice(dev);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  ~DeviceGuard2() {
+    if (ok) (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_corners_dev,
+                                const double *a_centers_dev, int64_t a_center_cols, int64_t A,
+                                const double *g_corners_dev, const double *g_centers_dev,
+                                int64_t g_center_cols, int64_t G, double *ious_dev) {
+  if (!ctx) {
+    set_error("ctx is NULL");
+    return PP_ERR_VALUE;
+  }
+  if (A < 0 || G < 0 || G > INT_MAX / 16 || A > (1ll << 40) || a_center_cols < 2 ||
+      g_center_cols < 2) {
+    set_error("pp_make_ious_dev: bad sizes (A=%lld G=%lld)", (long long)A, (long long)G);
+    return PP_ERR_VALUE;
+  }
+  if (A == 0 || G == 0) return PP_OK;
+  if (!a_corners_dev || !a_centers_dev || !g_corners_dev || !g_centers_dev || !ious_dev) {
+    set_error("pp_make_ious_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard2 guard(ctx->device);
+  int rc = ctx->iou_ws.ensure(4096);
+  if (rc) return rc;
+  int *errflag = static_cast<int *>(ctx->iou_ws.ptr);
+  PP_HIP_TRY(hipMemsetAsync(errflag, 0, 4, stream));
+  const int64_t total = A * G;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + kIouThreads - 1) / kIouThreads, 1 << 20);
+  hipLaunchKernelGGL(k_make_ious, dim3(blocks), dim3(kIouThreads), 0, stream, a_corners_dev,
+                     a_centers_dev, (int)a_center_cols, A, g_corners_dev, g_centers_dev,
+                     (int)g_center_cols, (int)G, ious_dev, errflag);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+// error flag of the last IoU / target launch on this context (synchronises)
+extern "C" int pp_iou_check(pp_ctx_t *ctx, void *stream_) {
+  if (!ctx || !ctx->iou_ws.ptr) return PP_OK;
+  DeviceGuard2 guard(ctx->device);
+  int flag = 0;
+  PP_HIP_TRY(hipMemcpyAsync(&flag, ctx->iou_ws.ptr, 4, hipMemcpyDeviceToHost,
+                            static_cast<hipStream_t>(stream_)));
+  PP_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
+  if (flag) {
+    set_error("IOU < 0: a box has the wrong corner winding (pillars.cpp:166-169)");
+    return PP_ERR_WINDING;
+  }
+  return PP_OK;
+}
+
+extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
+                                const int64_t ac[3], const void *g_corners, int64_t G,
+                                const int64_t gc[3], const void *a_centers, const int64_t an[2],
+                                const void *g_centers, const int64_t gn[2], void *ious,
+                                const int64_t io[2]) {
+  if (!ctx || !ac || !gc || !an || !gn || !io) {
+    set_error("pp_make_ious_f64: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (A < 0 || G < 0) {
+    set_error("negative size");
+    return PP_ERR_VALUE;
+  }
+  if (A == 0 || G == 0) return PP_OK;
+  if (!a_corners || !g_corners || !a_centers || !g_centers || !ious) {
+    set_error("pp_make_ious_f64: NULL array");
+    return PP_ERR_VALUE;
+  }
+  DeviceGuard2 guard(ctx->device);
+  hipStream_t stream = nullptr;
+  // pinned staging: anchors [A][8] + [A][2], gts [G][8] + [G][2]
+  const size_t in_bytes = ((size_t)A * 10 + (size_t)G * 10) * 8;
+  int rc = ctx->pin_in.ensure(in_bytes);
+  if (rc) return rc;
+  rc = ctx->stage_in.ensure(in_bytes);
+  if (rc) return rc;
+  rc = ctx->stage_out2.ensure((size_t)A * G * 8);
+  if (rc) return rc;
+  rc = ctx->pin_out.ensure((size_t)A * G * 8);
+  if (rc) return rc;
+  double *h = static_cast<double *>(ctx->pin_in.ptr);
+  double *h_ac = h, *h_an = h_ac + A * 8, *h_gc = h_an + A * 2, *h_gn = h_gc + G * 8;
+  auto rd = [](const void *base, int64_t off) {
+    double v;
+    std::memcpy(&v, static_cast<const char *>(base) + off, 8);
+    return v;
+  };
+  for (int64_t i = 0; i < A; ++i) {
+    for (int k = 0; k < 4; ++k)
+      for (int c = 0; c < 2; ++c) h_ac[i * 8 + k * 2 + c] = rd(a_corners, i * ac[0] + k * ac[1] + c * ac[2]);
+    h_an[i * 2] = rd(a_centers, i * an[0]);
+    h_an[i * 2 + 1] = rd(a_centers, i * an[0] + an[1]);
+  }
+  for (int64_t j = 0; j < G; ++j) {
+    for (int k = 0; k < 4; ++k)
+      for (int c = 0; c < 2; ++c) h_gc[j * 8 + k * 2 + c] = rd(g_corners, j * gc[0] + k * gc[1] + c * gc[2]);
+    h_gn[j * 2] = rd(g_centers, j * gn[0]);
+    h_gn[j * 2 + 1] = rd(g_centers, j * gn[0] + gn[1]);
+  }
+  double *d = static_cast<double *>(ctx->stage_in.ptr);
+  PP_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, stream));
+  rc = pp_make_ious_dev(ctx, stream, d, d + A * 8, 2, A, d + A * 10, d + A * 10 + G * 8, 2, G,
+                        static_cast<double *>(ctx->stage_out2.ptr));
+  if (rc) return rc;
+  PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, ctx->stage_out2.ptr, (size_t)A * G * 8,
+                            hipMemcpyDeviceToHost, stream));
+  PP_HIP_TRY(hipStreamSynchronize(stream));
+  // every entry is written (pillars.cpp:421,424)
+  const double *src = static_cast<const double *>(ctx->pin_out.ptr);
+  char *dst = static_cast<char *>(ious);
+  if (io[1] == 8 && io[0] == G * 8) {
+    std::memcpy(dst, src, (size_t)A * G * 8);
+  } else {
+    for (int64_t i = 0; i < A; ++i)
+      for (int64_t j = 0; j < G; ++j) std::memcpy(dst + i * io[0] + j * io[1], &src[i * G + j], 8);
+  }
+  return pp_iou_check(ctx, stream);
+}
+
+extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
+                                     const double *a_corners, const double *a_centers,
+                                     const double *a_wlh, const double *a_yaw, int64_t G,
+                                     const double *g_corners, const double *g_centers_img,
+                                     const double *g_centers, const double *g_wlh,
+                                     const double *g_yaw, const int32_t *g_class,
+                                     const pp_target_params_t *prm, float *cls_targets,
+                                     float *reg_targets) {
+  if (!ctx || !prm) {
+    set_error("pp_assign_targets_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (A < 1 || A > INT_MAX / 2 || G < 0 || G > 65536 || prm->num_classes < 1 ||
+      prm->num_classes > 1024) {
+    set_error("pp_assign_targets_dev: bad sizes (A=%lld G=%lld classes=%d)", (long long)A,
+              (long long)G, prm->num_classes);
+    return PP_ERR_VALUE;
+  }
+  if (!a_corners || !a_centers || !a_wlh || !a_yaw || !cls_targets || !reg_targets ||
+      (G > 0 && (!g_corners || !g_centers_img || !g_centers || !g_wlh || !g_yaw || !g_class))) {
+    set_error("pp_assign_targets_dev: NULL array");
+    return PP_ERR_VALUE;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard2 guard(ctx->device);
+  const size_t need = 4096 + (size_t)std::max<int64_t>(G, 1) * 16;
+  int rc = ctx->iou_ws.ensure(need);
+  if (rc) return rc;
+  char *ws = static_cast<char *>(ctx->iou_ws.ptr);
+  TargetArgs t;
+  t.A = A;
+  t.G = (int)G;
+  t.a_corners = a_corners;
+  t.a_centers = a_centers;
+  t.a_wlh = a_wlh;
+  t.a_yaw = a_yaw;
+  t.g_corners = g_corners;
+  t.g_centers_img = g_centers_img;
+  t.g_centers = g_centers;
+  t.g_wlh = g_wlh;
+  t.g_yaw = g_yaw;
+  t.g_class = g_class;
+  t.pos_thresh = prm->pos_thresh;
+  t.canvas_height = prm->canvas_height;
+  t.num_classes = prm->num_classes;
+  t.errflag = reinterpret_cast<int *>(ws);
+  t.col_max = reinterpret_cast<u64 *>(ws + 4096);
+  t.col_arg = reinterpret_cast<int *>(ws + 4096 + (size_t)std::max<int64_t>(G, 1) * 8);
+  t.cls_targets = cls_targets;
+  t.reg_targets = reg_targets;
+  const unsigned gb = (unsigned)((std::max<int64_t>(G, 1) + 255) / 256);
+  hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_arg,
+                     (int)G, t.errflag);
+  const unsigned ab = (unsigned)((A + kIouThreads - 1) / kIouThreads);
+  hipLaunchKernelGGL(k_targets_rows, dim3(ab), dim3(kIouThreads), 0, stream, t);
+  if (G > 0) {
+    hipLaunchKernelGGL(k_targets_cols, dim3(ab), dim3(kIouThreads), 0, stream, t);
+    hipLaunchKernelGGL(k_targets_forced, dim3(1), dim3(kIouThreads), 0, stream, t);
+  }
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}

@@ -1,0 +1,185 @@
+// pp_runtime.hip -- context, error string, buffers and timing ring of
+// libpp_hip.so (host code only).
+
+#include "pp_common.h"
+
+#include <cstring>
+
+namespace pp {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int DevBuf::ensure(size_t need, bool *grew) {
+  if (grew) *grew = false;
+  if (need <= bytes && ptr) return PP_OK;
+  if (ptr) {
+    // the previous buffer may still be in use by queued kernels
+    PP_HIP_TRY(hipDeviceSynchronize());
+    PP_HIP_TRY(hipFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+  }
+  if (need == 0) need = 256;
+  hipError_t e = hipMalloc(&ptr, need);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? PP_ERR_NOMEM : PP_ERR_HIP;
+  }
+  bytes = need;
+  if (grew) *grew = true;
+  return PP_OK;
+}
+
+void DevBuf::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+int PinBuf::ensure(size_t need) {
+  if (need <= bytes && ptr) return PP_OK;
+  if (ptr) {
+    PP_HIP_TRY(hipDeviceSynchronize());
+    PP_HIP_TRY(hipHostFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+  }
+  if (need == 0) need = 256;
+  need = (need + 4095) / 4096 * 4096;
+  hipError_t e = hipHostMalloc(&ptr, need, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    set_error("hipHostMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    return PP_ERR_NOMEM;
+  }
+  bytes = need;
+  return PP_OK;
+}
+
+void PinBuf::release() {
+  if (ptr) (void)hipHostFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" const char *pp_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *pp_version(void) { return "pp_hip 0.1 (gfx950)"; }
+
+extern "C" int pp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int pp_ctx_create(int device, pp_ctx_t **out) {
+  if (!out) {
+    set_error("pp_ctx_create: out is NULL");
+    return PP_ERR_VALUE;
+  }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (%s): libpp_hip has no CPU fallback",
+              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return PP_ERR_HIP;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range [0,%d)", device, n);
+    return PP_ERR_VALUE;
+  }
+  pp_ctx *c = new (std::nothrow) pp_ctx();
+  if (!c) return PP_ERR_NOMEM;
+  c->device = device;
+  *out = c;
+  return PP_OK;
+}
+
+extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
+  if (!ctx) return;
+  int prev = -1;
+  if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  ctx->vox_ws.release();
+  ctx->stage_in.release();
+  ctx->stage_out.release();
+  ctx->stage_out2.release();
+  ctx->iou_ws.release();
+  ctx->pin_in.release();
+  ctx->pin_out.release();
+  ctx->pin_meta.release();
+  for (auto &e : ctx->ev_start) (void)hipEventDestroy(e);
+  for (auto &e : ctx->ev_stop) (void)hipEventDestroy(e);
+  if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+  delete ctx;
+}
+
+extern "C" int pp_ctx_set_timing(pp_ctx_t *ctx, int slots) {
+  if (!ctx || slots < 0 || slots > 4096) {
+    set_error("pp_ctx_set_timing: bad argument");
+    return PP_ERR_VALUE;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+  for (auto &e : ctx->ev_start) (void)hipEventDestroy(e);
+  for (auto &e : ctx->ev_stop) (void)hipEventDestroy(e);
+  ctx->ev_start.clear();
+  ctx->ev_stop.clear();
+  ctx->ev_slots = 0;
+  ctx->ev_next = 0;
+  ctx->ev_count = 0;
+  int rc = PP_OK;
+  for (int i = 0; i < slots && rc == PP_OK; ++i) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      set_error("hipEventCreate failed");
+      rc = PP_ERR_HIP;
+      break;
+    }
+    ctx->ev_start.push_back(a);
+    ctx->ev_stop.push_back(b);
+  }
+  if (rc == PP_OK) ctx->ev_slots = slots;
+  if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+extern "C" int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count) {
+  if (!ctx || !ms || !count) {
+    set_error("pp_ctx_read_emit_ms: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  const int n = ctx->ev_count < cap ? ctx->ev_count : cap;
+  // oldest first
+  int idx = (ctx->ev_next - ctx->ev_count + 2 * (ctx->ev_slots > 0 ? ctx->ev_slots : 1)) %
+            (ctx->ev_slots > 0 ? ctx->ev_slots : 1);
+  for (int i = 0; i < n; ++i) {
+    PP_HIP_TRY(hipEventSynchronize(ctx->ev_stop[idx]));
+    PP_HIP_TRY(hipEventElapsedTime(&ms[i], ctx->ev_start[idx], ctx->ev_stop[idx]));
+    idx = (idx + 1) % ctx->ev_slots;
+  }
+  *count = n;
+  ctx->ev_count = 0;
+  ctx->ev_next = 0;
+  return PP_OK;
+}

@@ -1,0 +1,1099 @@
+// pp_voxelize.hip -- the pillar voxelizer as hand-written HIP for gfx950 (CDNA4).
+//
+// Replaces create_pillars (/root/reference data/pillars.cpp:236-398) and, on the
+// device-resident path, the caller glue around it (data/dataset.py:88-106):
+// np.zeros + create_pillars + transpose to [9,P,N] + f64->f32 + indices->int64.
+//
+// Pipeline (one launch each, grid.y = sweep of the batch):
+//   k_bin_count  point -> cell slot (f64 true division + floor, half-open range
+//                test: pillars.cpp:271-280), per-cell population count
+//   k_scan       single-pass decoupled-look-back scan over the cell grid:
+//                pillar index of every non-empty cell (P-index compaction) and
+//                CSR offset of its bucket; the count array becomes the cursor
+//   k_fill       CSR bucket fill (point index lists per cell)
+//   k_emit       one wave per 4 consecutive pillars: LDS-staged buckets, input
+//                order restored, sequential running mean (pillars.cpp:311-328),
+//                N-cap, 9 features (pillars.cpp:30-31,48-56,381-383), dense
+//                [9,P,N] f32 store incl. the zero padding, [P,3] int64 indices
+//
+// The path is HBM-bound: 97% of the bytes are the dense store of
+// k_emit, issued as 16-byte stores that each touch a byte exactly once.
+// All arithmetic that decides a value is f64 with contraction disabled
+// (-ffp-contract=off), matching the reference's x86-64 build.
+
+#include "pp_common.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace pp {
+
+// ------------------------------------------------------------------------- //
+// constants                                                                  //
+// ------------------------------------------------------------------------- //
+constexpr int kWave = 64;
+constexpr int kBinThreads = 256;
+constexpr int kScanThreads = 256;
+constexpr int kScanTile = kScanThreads * 4;  // cells per scan workgroup
+constexpr int kEmitWaves = 4;                // waves per emit workgroup
+constexpr int kEmitThreads = kEmitWaves * kWave;
+constexpr int KW = 4;      // pillars per emit wave
+constexpr int CAPW = 128;  // pooled bucket capacity (points) per emit wave
+constexpr unsigned kSpinLimit = 1u << 26;
+
+using u64 = unsigned long long;
+
+struct NPoints {
+  int n[PP_MAX_BATCH];
+};
+
+// status word of the look-back scan: [63:62] flag, [61:31] points, [30:0] pillars
+constexpr u64 kFlagAgg = 1ull << 62;
+constexpr u64 kFlagPre = 2ull << 62;
+__device__ __forceinline__ u64 st_pack(u64 flag, u64 v) {
+  // v = points << 32 | pillars
+  return flag | ((v >> 32) << 31) | (v & 0x7FFFFFFFull);
+}
+__device__ __forceinline__ u64 st_payload(u64 s) {
+  return (((s >> 31) & 0x7FFFFFFFull) << 32) | (s & 0x7FFFFFFFull);
+}
+
+__device__ __forceinline__ void wave_sync() {
+  // LDS operations of one wave execute in program order; this only stops the
+  // compiler from moving LDS accesses across a cross-lane hand-off.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int cell_to_slot(int cell, const GridGeom &g) {
+  if (g.order == PP_ORDER_ROW_MAJOR) return cell;
+  return (int)(((u64)cell * g.mult) % (u64)g.ncells);
+}
+__device__ __forceinline__ int slot_to_cell(int slot, const GridGeom &g) {
+  if (g.order == PP_ORDER_ROW_MAJOR) return slot;
+  return (int)(((u64)slot * g.mult_inv) % (u64)g.ncells);
+}
+
+// ------------------------------------------------------------------------- //
+// k_bin_count                                                                 //
+// ------------------------------------------------------------------------- //
+template <typename T>
+__device__ __forceinline__ void load_point(const T *pts, int64_t row, int64_t s0,
+                                           int64_t s1, bool contig, T &x, T &y,
+                                           T &z, T &r);
+
+template <>
+__device__ __forceinline__ void load_point<float>(const float *pts, int64_t row,
+                                                  int64_t s0, int64_t s1,
+                                                  bool contig, float &x, float &y,
+                                                  float &z, float &r) {
+  if (contig) {
+    float4 v = reinterpret_cast<const float4 *>(pts)[row];  // 16 B/lane, coalesced
+    x = v.x; y = v.y; z = v.z; r = v.w;
+  } else {
+    const float *p = pts + row * s0;
+    x = p[0]; y = p[s1]; z = p[2 * s1]; r = p[3 * s1];
+  }
+}
+template <>
+__device__ __forceinline__ void load_point<double>(const double *pts, int64_t row,
+                                                   int64_t s0, int64_t s1,
+                                                   bool contig, double &x, double &y,
+                                                   double &z, double &r) {
+  if (contig) {
+    const double4 v = reinterpret_cast<const double4 *>(pts)[row];
+    x = v.x; y = v.y; z = v.z; r = v.w;
+  } else {
+    const double *p = pts + row * s0;
+    x = p[0]; y = p[s1]; z = p[2 * s1]; r = p[3 * s1];
+  }
+}
+
+// pillars.cpp:271-280.  Returns the cell id (row-major over ascending
+// (canvas_y, canvas_x)) or -1 when the point is outside the half-open box.
+// NaN coordinates fail the positive comparisons and are dropped.
+__device__ __forceinline__ int point_cell(double x, double y, double z,
+                                          const GridGeom &g) {
+  if (!(x >= g.x_min && x < g.x_max && y >= g.y_min && y < g.y_max &&
+        z >= g.z_min && z < g.z_max))
+    return -1;
+  const double fx = floor((x - g.x_min) / g.x_step);
+  const double fy = floor((y - g.y_min) / g.y_step);
+  const int ix = (int)fx, iy = (int)fy;
+  return ((g.ny - 1) - iy) * g.nx + ix;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(
+    const T *__restrict__ pts, int64_t sweep_stride, int64_t s0, int64_t s1,
+    int contig, NPoints np, GridGeom g, int *__restrict__ cell_of, int ncap,
+    int *__restrict__ cursor) {
+  const int b = blockIdx.y;
+  const int n = np.n[b];
+  const int i = blockIdx.x * kBinThreads + threadIdx.x;
+  if (i >= n) return;
+  T x, y, z, r;
+  load_point<T>(pts + (int64_t)b * sweep_stride * 4, i, s0, s1, contig != 0, x, y, z, r);
+  const int cell = point_cell((double)x, (double)y, (double)z, g);
+  int slot = -1;
+  if (cell >= 0) {
+    slot = cell_to_slot(cell, g);
+    atomicAdd(&cursor[(int64_t)b * g.ncells_pad + slot], 1);  // no return value used
+  }
+  cell_of[(int64_t)b * ncap + i] = slot;
+}
+
+// ------------------------------------------------------------------------- //
+// k_scan: decoupled look-back over the cell grid                             //
+// ------------------------------------------------------------------------- //
+__device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
+  int lo = __shfl_up((int)(v & 0xFFFFFFFFull), d, kWave);
+  int hi = __shfl_up((int)(v >> 32), d, kWave);
+  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+  int lo = __shfl((int)(v & 0xFFFFFFFFull), src, kWave);
+  int hi = __shfl((int)(v >> 32), src, kWave);
+  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    int lo = __shfl_xor((int)(v & 0xFFFFFFFFull), d, kWave);
+    int hi = __shfl_xor((int)(v >> 32), d, kWave);
+    v += ((u64)(unsigned)hi << 32) | (unsigned)lo;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan(
+    int *__restrict__ cursor, int ncells_pad, int P, int4 *__restrict__ pillar_meta,
+    u64 *status, unsigned *ticket, int2 *__restrict__ totals, int *errflag) {
+  __shared__ unsigned s_ticket;
+  __shared__ u64 s_wave[kScanThreads / kWave];
+  __shared__ u64 s_excl;
+  const int b = blockIdx.y;
+  const int nwg = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // Dynamic tile id: a workgroup that holds ticket t knows tickets < t have
+  // started, so the look-back below never waits on an unscheduled workgroup.
+  if (tid == 0) s_ticket = atomicAdd(&ticket[b], 1u);
+  __syncthreads();
+  const int t = (int)s_ticket;
+  u64 *st = status + (int64_t)b * nwg;
+
+  int4 *cur = reinterpret_cast<int4 *>(cursor + (int64_t)b * ncells_pad) +
+              (int64_t)t * kScanThreads + tid;
+  const int4 c = *cur;
+  const u64 mine = ((u64)((unsigned)c.x + (unsigned)c.y + (unsigned)c.z + (unsigned)c.w) << 32) |
+                   (u64)((c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0));
+  // inclusive scan inside the wave
+  u64 inc = mine;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    u64 o = shfl_up64(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == kWave - 1) s_wave[wv] = inc;
+  __syncthreads();
+  u64 wave_off = 0, agg = 0;
+#pragma unroll
+  for (int k = 0; k < kScanThreads / kWave; ++k) {
+    if (k < wv) wave_off += s_wave[k];
+    agg += s_wave[k];
+  }
+  // publish + look back (wave 0)
+  if (wv == 0) {
+    u64 excl = 0;
+    if (t == 0) {
+      if (lane == 0)
+        __hip_atomic_store(&st[0], st_pack(kFlagPre, agg), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0)
+        __hip_atomic_store(&st[t], st_pack(kFlagAgg, agg), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      int base = t - 1;
+      bool failed = false;
+      while (true) {
+        const int j = base - lane;
+        u64 s = kFlagPre;  // virtual predecessor of tile 0: prefix 0
+        if (j >= 0) {
+          unsigned spins = 0;
+          do {
+            s = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((s >> 62) == 0 && ++spins < kSpinLimit);
+          if ((s >> 62) == 0) failed = true;
+        }
+        const u64 maskP = __ballot((s >> 62) == 2);
+        const int firstP = maskP ? (__ffsll((long long)maskP) - 1) : kWave;
+        const u64 val = (lane <= firstP) ? st_payload(s) : 0ull;
+        excl += wave_sum64(val);
+        if (maskP || __any(failed)) break;
+        base -= kWave;
+      }
+      if (__any(failed) && lane == 0) atomicExch(errflag, 1);
+      if (lane == 0)
+        __hip_atomic_store(&st[t], st_pack(kFlagPre, excl + agg), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_excl = excl;
+  }
+  __syncthreads();
+  const u64 base = s_excl + wave_off + (inc - mine);
+  int p = (int)(base & 0xFFFFFFFFull);
+  int s = (int)(base >> 32);
+  const int slot0 = (t * kScanThreads + tid) * 4;
+  const int vals[4] = {c.x, c.y, c.z, c.w};
+  int outv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    outv[e] = s;
+    if (vals[e] > 0) {
+      if (p < P) pillar_meta[(int64_t)b * P + p] = make_int4(slot0 + e, s, vals[e], 0);
+      ++p;
+      s += vals[e];
+    }
+  }
+  *cur = make_int4(outv[0], outv[1], outv[2], outv[3]);  // cursor = bucket start
+  if (t == nwg - 1 && tid == 0) {
+    const u64 tot = s_excl + agg;
+    totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// k_fill: CSR bucket fill; also re-arms the scan's ticket/status words        //
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(kBinThreads) void k_fill(
+    const int *__restrict__ cell_of, int ncap, NPoints np, int *__restrict__ cursor,
+    int ncells_pad, int *__restrict__ bucket, u64 *status, int nwg_scan,
+    unsigned *ticket) {
+  const int b = blockIdx.y;
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < nwg_scan; i += kBinThreads)
+      status[(int64_t)b * nwg_scan + i] = 0ull;
+    if (threadIdx.x == 0) ticket[b] = 0u;
+  }
+  const int i = blockIdx.x * kBinThreads + threadIdx.x;
+  if (i >= np.n[b]) return;
+  const int slot = cell_of[(int64_t)b * ncap + i];
+  if (slot < 0) return;
+  const int pos = atomicAdd(&cursor[(int64_t)b * ncells_pad + slot], 1);
+  bucket[(int64_t)b * ncap + pos] = i;
+}
+
+// ------------------------------------------------------------------------- //
+// k_emit                                                                      //
+// ------------------------------------------------------------------------- //
+template <typename TIn>
+struct WaveLds {
+  int idx[CAPW];                        // bucket entries as fetched (unordered)
+  TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar
+  union {
+    struct {
+      double q[3][CAPW];   // v / (n+1)
+      double ratio[CAPW];  // n / (n+1)
+    } c;
+    float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense mode), aliases c
+  } u;
+  double mean[KW][3];
+  int cnt[KW], live[KW], segbeg[KW], slot[KW], start[KW];
+};
+
+struct EmitArgs {
+  GridGeom g;
+  NPoints np;
+  int P, N, ncap;
+  const int4 *pillar_meta;  // [B][P] {slot, start, count, -}
+  const int2 *totals;       // [B]    {cells, points}
+  const int *bucket;        // [B][ncap]
+  const int *cell_of;       // [B][ncap]
+  int *cursor;              // [B][ncells_pad], zeroed here for the next call
+  const void *pts;          // [B][sweep_stride][4] (contiguous rows)
+  int64_t sweep_stride;
+  // dense mode
+  float *out;        // [B][9][P][N]
+  long long *idx_out;  // [B][P][3]
+  // compact mode
+  double *feat_out;  // [B][ncap][9]
+};
+
+enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2 };
+
+__device__ __forceinline__ void pillar_canvas(int slot, const GridGeom &g,
+                                              double &canvas_x, double &canvas_y) {
+  const int cell = slot_to_cell(slot, g);
+  const int ix = cell % g.nx;
+  const int ry = cell / g.nx;
+  canvas_x = (double)ix;
+  const double fy = (double)((g.ny - 1) - ry);
+  canvas_y = (g.canvas_height - 1) - fy;  // pillars.cpp:280
+}
+
+// nine features of one point, pillars.cpp:48-56 (order), :30-31 (xp,yp), :381-383
+__device__ __forceinline__ void point_features(double x, double y, double z, double r,
+                                               double canvas_x, double canvas_y,
+                                               const double *mean, double f[9]) {
+  f[0] = x;
+  f[1] = y;
+  f[2] = z;
+  f[3] = r;
+  f[4] = canvas_x - x;
+  f[5] = canvas_y - y;
+  f[6] = mean[0] - x;
+  f[7] = mean[1] - y;
+  f[8] = mean[2] - z;
+}
+
+// A pillar whose bucket does not fit the wave's LDS pool: re-scan the sweep's
+// cell ids in input order and compact the matches with ballot + popcount, so
+// the order is restored without sorting.  O(n_points/64) per such pillar.
+template <typename TIn, int MODE>
+__device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k, int p,
+                                int lane) {
+  const int slot = L.slot[k];
+  const int nb = a.np.n[b];
+  const TIn *pts = reinterpret_cast<const TIn *>(a.pts) + (int64_t)b * a.sweep_stride * 4;
+  const int *cell_of = a.cell_of + (int64_t)b * a.ncap;
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  double m0 = 0, m1 = 0, m2 = 0;
+  int seen = 0;
+  for (int base = 0; base < nb; base += kWave) {
+    const int i = base + lane;
+    const bool match = (i < nb) && (cell_of[i] == slot);
+    const u64 mask = __ballot(match);
+    if (!mask) continue;
+    const int rank = __popcll(mask & lt_mask);
+    if (match) {
+      const TIn x = pts[(int64_t)i * 4 + 0], y = pts[(int64_t)i * 4 + 1],
+                z = pts[(int64_t)i * 4 + 2];
+      const double n = (double)(seen + rank), den = n + 1;
+      L.px[rank] = x;
+      L.py[rank] = y;
+      L.pz[rank] = z;
+      L.u.c.ratio[rank] = n / den;
+      L.u.c.q[0][rank] = (double)x / den;
+      L.u.c.q[1][rank] = (double)y / den;
+      L.u.c.q[2][rank] = (double)z / den;
+    }
+    wave_sync();
+    const int c = __popcll(mask);
+    for (int t = 0; t < c; ++t) {  // uniform: every lane carries the chain
+      if (seen + t == 0) {
+        m0 = (double)L.px[0];
+        m1 = (double)L.py[0];
+        m2 = (double)L.pz[0];
+      } else {
+        const double rt = L.u.c.ratio[t];
+        m0 = m0 * rt + L.u.c.q[0][t];
+        m1 = m1 * rt + L.u.c.q[1][t];
+        m2 = m2 * rt + L.u.c.q[2][t];
+      }
+    }
+    seen += c;
+    wave_sync();
+  }
+  const double mean[3] = {m0, m1, m2};
+  double cx, cy;
+  pillar_canvas(slot, a.g, cx, cy);
+  const int N = a.N;
+  const int live = L.live[k];
+  seen = 0;
+  for (int base = 0; base < nb && seen < N; base += kWave) {
+    const int i = base + lane;
+    const bool match = (i < nb) && (cell_of[i] == slot);
+    const u64 mask = __ballot(match);
+    if (!mask) continue;
+    const int n = seen + __popcll(mask & lt_mask);
+    if (match && n < N) {
+      const TIn x = pts[(int64_t)i * 4 + 0], y = pts[(int64_t)i * 4 + 1],
+                z = pts[(int64_t)i * 4 + 2], r = pts[(int64_t)i * 4 + 3];
+      double f[9];
+      point_features((double)x, (double)y, (double)z, (double)r, cx, cy, mean, f);
+      if (MODE == kModeCompact) {
+        double *o = a.feat_out + ((int64_t)b * a.ncap + L.start[k] + n) * 9;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) o[d] = f[d];
+      } else {
+        float *o = a.out + (int64_t)b * 9 * a.P * N;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) o[((int64_t)d * a.P + p) * N + n] = (float)f[d];
+      }
+    }
+    seen += __popcll(mask);
+  }
+  if (MODE == kModeDenseVec4) {
+    // zero the tail of the 16-byte group that straddles `live`
+    const int up = (live + 3) & ~3;
+    const int e = live + (lane / 9), d = lane % 9;
+    if (lane < 27 && e < up) {
+      float *o = a.out + (int64_t)b * 9 * a.P * N;
+      o[((int64_t)d * a.P + p) * N + e] = 0.0f;
+    }
+  }
+}
+
+// Pillars [kbeg,kend) of this wave, pooled in LDS (their buckets total <= CAPW).
+template <typename TIn, int MODE>
+__device__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0, int kbeg,
+                           int kend, int lane) {
+  const TIn *pts = reinterpret_cast<const TIn *>(a.pts) + (int64_t)b * a.sweep_stride * 4;
+  const int *bucket = a.bucket + (int64_t)b * a.ncap;
+  const int N = a.N;
+  int segbeg[KW], cntk[KW];
+  int T = 0;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const bool in = (k >= kbeg && k < kend);
+    cntk[k] = in ? L.cnt[k] : 0;
+    segbeg[k] = T;
+    T += cntk[k];
+  }
+  if (T == 0) return;
+  const int start0 = L.start[kbeg];  // CSR ranges of consecutive pillars are contiguous
+  for (int j = lane; j < T; j += kWave) L.idx[j] = bucket[start0 + j];
+  wave_sync();
+  // restore input order: rank of every entry inside its bucket (counts are small)
+  for (int j = lane; j < T; j += kWave) {
+    int k = 0;
+#pragma unroll
+    for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
+    int sb = 0, sc = 0;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      sb = (k == kk) ? segbeg[kk] : sb;
+      sc = (k == kk) ? cntk[kk] : sc;
+    }
+    const int my = L.idx[j];
+    int r = 0;
+    for (int jj = sb; jj < sb + sc; ++jj) r += (L.idx[jj] < my) ? 1 : 0;
+    const int pos = sb + r;
+    TIn x, y, z, rr;
+    load_point<TIn>(pts, my, 4, 1, true, x, y, z, rr);
+    L.px[pos] = x;
+    L.py[pos] = y;
+    L.pz[pos] = z;
+    L.pr[pos] = rr;
+    const double n = (double)r, den = n + 1;
+    L.u.c.ratio[pos] = n / den;            // pillars.cpp:322-326: n/(n+1)
+    L.u.c.q[0][pos] = (double)x / den;     //                       v/(n+1)
+    L.u.c.q[1][pos] = (double)y / den;
+    L.u.c.q[2][pos] = (double)z / den;
+  }
+  wave_sync();
+  // sequential running mean per pillar, pillars.cpp:311-328 (one lane each)
+  if (lane < KW) {
+    int sb = 0, sc = 0;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      sb = (lane == kk) ? segbeg[kk] : sb;
+      sc = (lane == kk) ? cntk[kk] : sc;
+    }
+    if (sc > 0) {
+      double m0 = (double)L.px[sb], m1 = (double)L.py[sb], m2 = (double)L.pz[sb];
+      for (int n = 1; n < sc; ++n) {
+        const double rt = L.u.c.ratio[sb + n];
+        m0 = m0 * rt + L.u.c.q[0][sb + n];
+        m1 = m1 * rt + L.u.c.q[1][sb + n];
+        m2 = m2 * rt + L.u.c.q[2][sb + n];
+      }
+      L.mean[lane][0] = m0;
+      L.mean[lane][1] = m1;
+      L.mean[lane][2] = m2;
+    }
+  }
+  wave_sync();
+  // features of the first min(count, N) points of every pillar.  The f32
+  // staging array aliases the (now dead) chain operands.
+  float *outb = a.out + (int64_t)b * 9 * a.P * N;
+  for (int j = lane; j < T; j += kWave) {
+    int k = 0;
+#pragma unroll
+    for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
+    int sb = 0;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) sb = (k == kk) ? segbeg[kk] : sb;
+    const int n = j - sb;
+    if (n < N) {
+      double cx, cy;
+      pillar_canvas(L.slot[k], a.g, cx, cy);
+      double f[9];
+      point_features((double)L.px[j], (double)L.py[j], (double)L.pz[j], (double)L.pr[j],
+                     cx, cy, L.mean[k], f);
+      if (MODE == kModeCompact) {
+        double *o = a.feat_out + ((int64_t)b * a.ncap + start0 + j) * 9;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) o[d] = f[d];
+      } else if (MODE == kModeDenseScalar) {
+#pragma unroll
+        for (int d = 0; d < 9; ++d)
+          outb[((int64_t)d * a.P + (p0 + k)) * N + n] = (float)f[d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) L.u.feat[d][j] = (float)f[d];
+      }
+    }
+  }
+  if (MODE == kModeDenseVec4) {
+    wave_sync();
+    // "head" 16-byte groups: the groups of a pillar row that hold live points
+    // (the live prefix plus, in the last group, its zero tail).
+    int hbeg[KW], nh[KW], livek[KW];
+    int H = 0;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      livek[k] = min(cntk[k], N);
+      nh[k] = (livek[k] + 3) >> 2;
+      hbeg[k] = H;
+      H += nh[k];
+    }
+    const int N4 = N >> 2;
+    float4 *out4 = reinterpret_cast<float4 *>(outb);
+    for (int it = lane; it < H * 9; it += kWave) {
+      const int d = it / H, h = it - d * H;
+      int k = 0;
+#pragma unroll
+      for (int kk = 1; kk < KW; ++kk) k = (h >= hbeg[kk] && nh[kk] > 0) ? kk : k;
+      int hb = 0, lv = 0, sb = 0;
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+        hb = (k == kk) ? hbeg[kk] : hb;
+        lv = (k == kk) ? livek[kk] : lv;
+        sb = (k == kk) ? segbeg[kk] : sb;
+      }
+      const int hh = h - hb;
+      const int j0 = sb + 4 * hh;
+      const float *fr = L.u.feat[d];
+      float4 v;
+      v.x = (4 * hh + 0 < lv) ? fr[min(j0 + 0, CAPW - 1)] : 0.0f;
+      v.y = (4 * hh + 1 < lv) ? fr[min(j0 + 1, CAPW - 1)] : 0.0f;
+      v.z = (4 * hh + 2 < lv) ? fr[min(j0 + 2, CAPW - 1)] : 0.0f;
+      v.w = (4 * hh + 3 < lv) ? fr[min(j0 + 3, CAPW - 1)] : 0.0f;
+      out4[((int64_t)d * a.P + (p0 + k)) * N4 + hh] = v;
+    }
+    wave_sync();
+  }
+}
+
+template <typename TIn, int MODE>
+__global__ __launch_bounds__(kEmitThreads) void k_emit(EmitArgs a) {
+  __shared__ WaveLds<TIn> lds[kEmitWaves];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int N = a.N, P = a.P;
+  // (0) hand the count/cursor array back zeroed for the next call
+  {
+    int4 *c4 = reinterpret_cast<int4 *>(a.cursor + (int64_t)b * a.g.ncells_pad);
+    const int n4 = a.g.ncells_pad >> 2;
+    for (int i = blockIdx.x * kEmitThreads + tid; i < n4; i += gridDim.x * kEmitThreads)
+      c4[i] = make_int4(0, 0, 0, 0);
+  }
+  WaveLds<TIn> &L = lds[w];
+  const int p0 = (blockIdx.x * kEmitWaves + w) * KW;
+  if (p0 >= P) return;
+  const int kw_eff = min(KW, P - p0);
+  const int2 tot = a.totals[b];
+  const int npil = min(tot.x, P);
+  // (1) pillar descriptors
+  if (lane < KW) {
+    const int p = p0 + lane;
+    int4 m = make_int4(-1, 0, 0, 0);
+    if (p < npil) m = a.pillar_meta[(int64_t)b * P + p];
+    L.slot[lane] = m.x;
+    L.start[lane] = m.y;
+    L.cnt[lane] = m.z;
+    L.live[lane] = min(m.z, N);
+  }
+  wave_sync();
+  // (2) dense modes: scatter indices and the zero padding (no dependence on
+  //     the points, so these stores start one load round trip after launch)
+  if (MODE != kModeCompact) {
+    if (lane < kw_eff) {
+      long long *io = a.idx_out + ((int64_t)b * P + p0 + lane) * 3;
+      long long i0 = 0, i1 = 0, i2 = 0;
+      if (L.cnt[lane] > 0) {
+        double cx, cy;
+        pillar_canvas(L.slot[lane], a.g, cx, cy);
+        i0 = 1;               // pillars.cpp:390
+        i1 = (long long)cx;   // pillars.cpp:391 + dataset.py:106 (.long())
+        i2 = (long long)cy;   // pillars.cpp:392
+      }
+      io[0] = i0;
+      io[1] = i1;
+      io[2] = i2;
+    }
+    float *outb = a.out + (int64_t)b * 9 * P * N;
+    if (MODE == kModeDenseVec4) {
+      const int N4 = N >> 2;
+      const unsigned rowf4 = (unsigned)(kw_eff * N4);
+      const unsigned total = 9u * rowf4;
+      const unsigned magic_row = 0xFFFFFFFFu / rowf4 + 1u;
+      const unsigned magic_n4 = 0xFFFFFFFFu / (unsigned)N4 + 1u;
+      float4 *out4 = reinterpret_cast<float4 *>(outb);
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (unsigned f = lane; f < total; f += kWave) {
+        const unsigned d = __umulhi(f, magic_row);
+        const unsigned rem = f - d * rowf4;
+        const unsigned k = __umulhi(rem, magic_n4);
+        const unsigned n4 = rem - k * (unsigned)N4;
+        const unsigned nh = (unsigned)(L.live[k] + 3) >> 2;
+        if (n4 >= nh) out4[((int64_t)d * P + p0) * N4 + rem] = z4;
+      }
+    } else {
+      const int rowf = kw_eff * N;
+      const int total = 9 * rowf;
+      for (int f = lane; f < total; f += kWave) {
+        const int d = f / rowf, rem = f - d * rowf;
+        const int k = rem / N, n = rem - k * N;
+        if (n >= L.live[k]) outb[((int64_t)d * P + p0) * N + rem] = 0.0f;
+      }
+    }
+  }
+  // (3) the points
+  int cnts[KW];
+  int T = 0;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    cnts[k] = __builtin_amdgcn_readfirstlane(L.cnt[k]);
+    T += cnts[k];
+  }
+  if (T == 0) return;
+  if (T <= CAPW) {
+    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane);
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < KW; ++k) {
+      const int c = __builtin_amdgcn_readfirstlane(L.cnt[k]);
+      if (c == 0) continue;
+      if (c <= CAPW)
+        emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane);
+      else
+        emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// host side                                                                  //
+// ------------------------------------------------------------------------- //
+static unsigned long long gcd_u64(unsigned long long a, unsigned long long b) {
+  while (b) {
+    unsigned long long t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+static unsigned long long modinv(unsigned long long a, unsigned long long m) {
+  // extended Euclid on signed 128-bit-safe ranges (m < 2^31)
+  long long t = 0, nt = 1, r = (long long)m, nr = (long long)(a % m);
+  while (nr != 0) {
+    long long q = r / nr;
+    long long tmp = t - q * nt;
+    t = nt;
+    nt = tmp;
+    tmp = r - q * nr;
+    r = nr;
+    nr = tmp;
+  }
+  if (t < 0) t += (long long)m;
+  return (unsigned long long)t;
+}
+
+int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
+  if (!prm) {
+    set_error("voxel params are NULL");
+    return PP_ERR_VALUE;
+  }
+  if (!(prm->x_step > 0.0) || !(prm->y_step > 0.0) || !(prm->x_max > prm->x_min) ||
+      !(prm->y_max > prm->y_min)) {
+    set_error("invalid grid: steps must be > 0 and max > min");
+    return PP_ERR_VALUE;
+  }
+  if (prm->order != PP_ORDER_ROW_MAJOR && prm->order != PP_ORDER_SCRAMBLED) {
+    set_error("unknown pillar order %d", prm->order);
+    return PP_ERR_VALUE;
+  }
+  // same bound as the oracle: floor((x-x_min)/x_step) <= floor((x_max-x_min)/x_step)
+  const double qx = std::floor((prm->x_max - prm->x_min) / prm->x_step);
+  const double qy = std::floor((prm->y_max - prm->y_min) / prm->y_step);
+  if (!(qx < 32768.0) || !(qy < 32768.0)) {
+    set_error("cell grid too large (%g x %g cells; limit 32768 per axis)", qx + 1, qy + 1);
+    return PP_ERR_VALUE;
+  }
+  g->x_step = prm->x_step;
+  g->y_step = prm->y_step;
+  g->x_min = prm->x_min;
+  g->y_min = prm->y_min;
+  g->z_min = prm->z_min;
+  g->x_max = prm->x_max;
+  g->y_max = prm->y_max;
+  g->z_max = prm->z_max;
+  g->canvas_height = prm->canvas_height;
+  g->nx = (int)qx + 1;
+  g->ny = (int)qy + 1;
+  const long long nc = (long long)g->nx * g->ny;
+  if (nc >= (1ll << 30)) {
+    set_error("cell grid too large (%lld cells)", nc);
+    return PP_ERR_VALUE;
+  }
+  g->ncells = (int)nc;
+  g->ncells_pad = (int)((nc + kScanTile - 1) / kScanTile * kScanTile);
+  g->order = prm->order;
+  g->mult = 1;
+  g->mult_inv = 1;
+  if (prm->order == PP_ORDER_SCRAMBLED && nc > 2) {
+    unsigned long long m = (unsigned long long)std::floor((double)nc * 0.6180339887498949);
+    if (m < 1) m = 1;
+    while (gcd_u64(m, (unsigned long long)nc) != 1) ++m;
+    m %= (unsigned long long)nc;
+    g->mult = m;
+    g->mult_inv = modinv(m, (unsigned long long)nc);
+  }
+  return PP_OK;
+}
+
+namespace {
+
+struct VoxLayout {
+  size_t cursor, cell_of, bucket, meta, status, ticket, totals, errflag, bytes;
+  int nwg_scan;
+  int ncap;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P) {
+  VoxLayout l;
+  l.ncap = (int)align_up((size_t)std::max<int64_t>(max_points, 1), 64);
+  l.nwg_scan = g.ncells_pad / kScanTile;
+  size_t off = 0;
+  l.cursor = off;
+  off = align_up(off + (size_t)B * g.ncells_pad * 4, 256);
+  l.cell_of = off;
+  off = align_up(off + (size_t)B * l.ncap * 4, 256);
+  l.bucket = off;
+  off = align_up(off + (size_t)B * l.ncap * 4, 256);
+  l.meta = off;
+  off = align_up(off + (size_t)B * P * 16, 256);
+  l.status = off;
+  off = align_up(off + (size_t)B * l.nwg_scan * 8, 256);
+  l.ticket = off;
+  off = align_up(off + (size_t)B * 4, 256);
+  l.totals = off;
+  off = align_up(off + (size_t)B * 8, 256);
+  l.errflag = off;
+  off = align_up(off + 4, 256);
+  l.bytes = off;
+  return l;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess) {
+      ok = true;
+      if (prev != dev) (void)hipSetDevice(dev);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  ~DeviceGuard() {
+    if (ok) (void)hipSetDevice(prev);
+  }
+};
+
+// Makes the workspace fit (B, max_points, grid, P) and guarantees the "clean"
+// invariant (cursor, status, ticket all zero) whenever the layout changed.
+int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
+               const GridGeom &g, int P, VoxLayout *out) {
+  VoxLayout l = vox_layout(B, max_points, g, P);
+  const unsigned long long key[6] = {(unsigned long long)B, (unsigned long long)l.ncap,
+                                     (unsigned long long)g.ncells_pad,
+                                     (unsigned long long)P, (unsigned long long)l.bytes, 1ull};
+  bool grew = false;
+  int rc = ctx->vox_ws.ensure(l.bytes, &grew);
+  if (rc) return rc;
+  if (grew || std::memcmp(key, ctx->vox_layout_key, sizeof key) != 0) {
+    PP_HIP_TRY(hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream));
+    std::memcpy(ctx->vox_layout_key, key, sizeof key);
+  }
+  *out = l;
+  return PP_OK;
+}
+
+template <typename TIn>
+int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t sweep_stride,
+                    int64_t s0, int64_t s1, int contig, const NPoints &np, int B,
+                    int maxn, const GridGeom &g, int P, int N, const VoxLayout &l,
+                    int mode, float *out, long long *idx_out, double *feat_out,
+                    bool timed) {
+  char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+  int *cursor = reinterpret_cast<int *>(ws + l.cursor);
+  int *cell_of = reinterpret_cast<int *>(ws + l.cell_of);
+  int *bucket = reinterpret_cast<int *>(ws + l.bucket);
+  int4 *meta = reinterpret_cast<int4 *>(ws + l.meta);
+  u64 *status = reinterpret_cast<u64 *>(ws + l.status);
+  unsigned *ticket = reinterpret_cast<unsigned *>(ws + l.ticket);
+  int2 *totals = reinterpret_cast<int2 *>(ws + l.totals);
+  int *errflag = reinterpret_cast<int *>(ws + l.errflag);
+
+  const dim3 grid_pts((unsigned)std::max(1, (maxn + kBinThreads - 1) / kBinThreads), (unsigned)B);
+  hipLaunchKernelGGL((k_bin_count<TIn>), grid_pts, dim3(kBinThreads), 0, stream, pts,
+                     sweep_stride, s0, s1, contig, np, g, cell_of, l.ncap, cursor);
+  hipLaunchKernelGGL(k_scan, dim3((unsigned)l.nwg_scan, (unsigned)B), dim3(kScanThreads), 0,
+                     stream, cursor, g.ncells_pad, P, meta, status, ticket, totals, errflag);
+  hipLaunchKernelGGL(k_fill, grid_pts, dim3(kBinThreads), 0, stream, cell_of, l.ncap, np,
+                     cursor, g.ncells_pad, bucket, status, l.nwg_scan, ticket);
+  EmitArgs a;
+  a.g = g;
+  a.np = np;
+  a.P = P;
+  a.N = N;
+  a.ncap = l.ncap;
+  a.pillar_meta = meta;
+  a.totals = totals;
+  a.bucket = bucket;
+  a.cell_of = cell_of;
+  a.cursor = cursor;
+  a.pts = pts;
+  a.sweep_stride = sweep_stride;
+  a.out = out;
+  a.idx_out = idx_out;
+  a.feat_out = feat_out;
+  const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
+  int slot = -1;
+  if (timed && ctx->ev_slots > 0) {
+    slot = ctx->ev_next;
+    PP_HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+  }
+  switch (mode) {
+    case kModeDenseVec4:
+      hipLaunchKernelGGL((k_emit<TIn, kModeDenseVec4>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      break;
+    case kModeDenseScalar:
+      hipLaunchKernelGGL((k_emit<TIn, kModeDenseScalar>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      break;
+    default:
+      hipLaunchKernelGGL((k_emit<TIn, kModeCompact>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      break;
+  }
+  if (slot >= 0) {
+    PP_HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
+    ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
+    ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
+  }
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+}  // namespace
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_voxelize_reserve(pp_ctx_t *ctx, int batch, int64_t max_points,
+                                   const pp_voxel_params_t *prm) {
+  if (!ctx) {
+    set_error("ctx is NULL");
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || batch > PP_MAX_BATCH || max_points < 0 || max_points > INT_MAX / 2) {
+    set_error("reserve: batch must be in [1,%d] and 0 <= max_points < 2^30", PP_MAX_BATCH);
+    return PP_ERR_VALUE;
+  }
+  GridGeom g;
+  int rc = make_grid(prm, &g);
+  if (rc) return rc;
+  if (prm->max_pillars < 1) {
+    set_error("max_pillars must be >= 1");
+    return PP_ERR_VALUE;
+  }
+  DeviceGuard guard(ctx->device);
+  VoxLayout l;
+  return prepare_ws(ctx, nullptr, batch, max_points, g, prm->max_pillars, &l);
+}
+
+extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                               int64_t points_stride, const int32_t *n_points, int batch,
+                               const pp_voxel_params_t *prm, float *pillars_dev,
+                               int64_t *indices_dev, int32_t *num_cells_dev) {
+  if (!ctx || !points_dev || !n_points || !prm || !pillars_dev || !indices_dev) {
+    set_error("pp_voxelize_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || batch > PP_MAX_BATCH) {
+    set_error("batch must be in [1,%d], got %d", PP_MAX_BATCH, batch);
+    return PP_ERR_VALUE;
+  }
+  const int P = prm->max_pillars, N = prm->max_points_per_pillar;
+  if (P < 1 || N < 1 || N > 65536 || (long long)P * N > (1ll << 31) / 16) {
+    set_error("need 1 <= max_pillars, 1 <= max_points_per_pillar <= 65536 and P*N < 2^27 "
+              "(got P=%d N=%d)", P, N);
+    return PP_ERR_VALUE;
+  }
+  if (points_stride < 0 || points_stride > INT_MAX / 2) {
+    set_error("points_stride out of range");
+    return PP_ERR_VALUE;
+  }
+  NPoints np;
+  std::memset(&np, 0, sizeof np);
+  int maxn = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (n_points[b] < 0 || n_points[b] > points_stride) {
+      set_error("n_points[%d]=%d outside [0, points_stride=%lld]", b, n_points[b],
+                (long long)points_stride);
+      return PP_ERR_VALUE;
+    }
+    np.n[b] = n_points[b];
+    maxn = std::max(maxn, n_points[b]);
+  }
+  if ((reinterpret_cast<uintptr_t>(points_dev) & 15) || (reinterpret_cast<uintptr_t>(pillars_dev) & 15) ||
+      (reinterpret_cast<uintptr_t>(indices_dev) & 7)) {
+    set_error("device pointers must be 16-byte (points, pillars) / 8-byte (indices) aligned");
+    return PP_ERR_VALUE;
+  }
+  GridGeom g;
+  int rc = make_grid(prm, &g);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(ctx->device);
+  VoxLayout l;
+  rc = prepare_ws(ctx, stream, batch, std::max<int64_t>(points_stride, 1), g, P, &l);
+  if (rc) return rc;
+  const int mode = (N % 4 == 0 && N <= 4096) ? kModeDenseVec4 : kModeDenseScalar;
+  rc = launch_pipeline<float>(ctx, stream, points_dev, points_stride, 4, 1, 1, np, batch, maxn,
+                              g, P, N, l, mode, pillars_dev,
+                              reinterpret_cast<long long *>(indices_dev), nullptr, true);
+  if (rc) return rc;
+  if (num_cells_dev) {
+    char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+    PP_HIP_TRY(hipMemcpyAsync(num_cells_dev, ws + l.totals, (size_t)batch * 8,
+                              hipMemcpyDeviceToDevice, stream));
+  }
+  return PP_OK;
+}
+
+extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,
+                                     int64_t ps0, int64_t ps1, void *tensor,
+                                     const int64_t t_shape[3], const int64_t t_strides[3],
+                                     void *indices, const int64_t i_shape[2],
+                                     const int64_t i_strides[2], const pp_voxel_params_t *prm,
+                                     int64_t *num_cells) {
+  if (!ctx || !prm || !t_shape || !t_strides || !i_shape || !i_strides ||
+      (n_points > 0 && !points)) {
+    set_error("pp_create_pillars_f64: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (n_points < 0 || n_points > INT_MAX / 2) {
+    set_error("n_points out of range");
+    return PP_ERR_VALUE;
+  }
+  GridGeom g;
+  int rc = make_grid(prm, &g);
+  if (rc) return rc;
+  if (num_cells) *num_cells = 0;
+  if (n_points == 0) return PP_OK;
+  const int n = (int)n_points;
+  const int max_pillars = std::max(prm->max_pillars, 0);
+  const int N = std::max(prm->max_points_per_pillar, 0);
+  // there are at most min(n, ncells) non-empty cells
+  const int P = std::max(1, std::min(max_pillars, std::min(n, g.ncells)));
+  DeviceGuard guard(ctx->device);
+  hipStream_t stream = nullptr;
+  VoxLayout l;
+  rc = prepare_ws(ctx, stream, 1, n, g, P, &l);
+  if (rc) return rc;
+  // gather the (arbitrarily strided) points into pinned staging: [n][4] f64
+  rc = ctx->pin_in.ensure((size_t)n * 32);
+  if (rc) return rc;
+  rc = ctx->stage_in.ensure((size_t)l.ncap * 32);
+  if (rc) return rc;
+  rc = ctx->stage_out.ensure((size_t)l.ncap * 72);
+  if (rc) return rc;
+  {
+    double *dst = static_cast<double *>(ctx->pin_in.ptr);
+    const char *src = static_cast<const char *>(points);
+    for (int64_t i = 0; i < n; ++i)
+      for (int c = 0; c < 4; ++c)
+        std::memcpy(&dst[i * 4 + c], src + i * ps0 + c * ps1, 8);
+  }
+  PP_HIP_TRY(hipMemcpyAsync(ctx->stage_in.ptr, ctx->pin_in.ptr, (size_t)n * 32,
+                            hipMemcpyHostToDevice, stream));
+  NPoints np;
+  std::memset(&np, 0, sizeof np);
+  np.n[0] = n;
+  rc = launch_pipeline<double>(ctx, stream, static_cast<const double *>(ctx->stage_in.ptr),
+                               l.ncap, 4, 1, 1, np, 1, n, g, P, N, l, kModeCompact, nullptr,
+                               nullptr, static_cast<double *>(ctx->stage_out.ptr), false);
+  if (rc) return rc;
+  // descriptors back: totals, errflag, pillar_meta[P]
+  rc = ctx->pin_meta.ensure(256 + (size_t)P * 16);
+  if (rc) return rc;
+  char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+  char *pm = static_cast<char *>(ctx->pin_meta.ptr);
+  PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.totals, 8, hipMemcpyDeviceToHost, stream));
+  PP_HIP_TRY(hipMemcpyAsync(pm + 16, ws + l.errflag, 4, hipMemcpyDeviceToHost, stream));
+  PP_HIP_TRY(hipMemcpyAsync(pm + 256, ws + l.meta, (size_t)P * 16, hipMemcpyDeviceToHost, stream));
+  PP_HIP_TRY(hipStreamSynchronize(stream));
+  int tot[2], err;
+  std::memcpy(tot, pm, 8);
+  std::memcpy(&err, pm + 16, 4);
+  if (err) {
+    // leave a clean workspace behind
+    (void)hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream);
+    (void)hipStreamSynchronize(stream);
+    set_error("cell scan timed out waiting for a predecessor tile");
+    return PP_ERR_INTERNAL;
+  }
+  if (num_cells) *num_cells = tot[0];
+  const int npil = std::min(tot[0], std::min(P, max_pillars));
+  if (npil == 0) return PP_OK;
+  const int4 *meta = reinterpret_cast<const int4 *>(pm + 256);
+  const int64_t end = (int64_t)meta[npil - 1].y + meta[npil - 1].z;
+  rc = ctx->pin_out.ensure((size_t)end * 72);
+  if (rc) return rc;
+  if (N > 0) {
+    PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, ctx->stage_out.ptr, (size_t)end * 72,
+                              hipMemcpyDeviceToHost, stream));
+    PP_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  // scatter into the caller's arrays with pybind11 .mutable_at() bounds checks,
+  // pillar by pillar like pillars.cpp:335-396 (nothing else is touched)
+  const double *feat = static_cast<const double *>(ctx->pin_out.ptr);
+  char *tp = static_cast<char *>(tensor);
+  char *ip = static_cast<char *>(indices);
+  for (int p = 0; p < npil; ++p) {
+    const int live = std::min(meta[p].z, N);
+    for (int k = 0; k < live; ++k) {
+      const double *f = feat + ((int64_t)meta[p].y + k) * 9;
+      for (int d = 0; d < 9; ++d) {
+        if (!tensor || p >= t_shape[0] || k >= t_shape[1] || d >= t_shape[2]) {
+          set_error("create_pillars: tensor index (%d,%d,%d) out of range", p, k, d);
+          return PP_ERR_INDEX;
+        }
+        std::memcpy(tp + p * t_strides[0] + k * t_strides[1] + d * t_strides[2], &f[d], 8);
+      }
+    }
+    if (!indices || p >= i_shape[0] || 2 >= i_shape[1]) {
+      set_error("create_pillars: indices index (%d,2) out of range", p);
+      return PP_ERR_INDEX;
+    }
+    int cell = meta[p].x;
+    if (g.order != PP_ORDER_ROW_MAJOR)
+      cell = (int)(((unsigned long long)cell * g.mult_inv) % (unsigned long long)g.ncells);
+    const double canvas_x = (double)(cell % g.nx);
+    const double fy = (double)((g.ny - 1) - cell / g.nx);
+    const double canvas_y = (g.canvas_height - 1) - fy;
+    const double one = 1.0;
+    std::memcpy(ip + p * i_strides[0] + 0 * i_strides[1], &one, 8);
+    std::memcpy(ip + p * i_strides[0] + 1 * i_strides[1], &canvas_x, 8);
+    std::memcpy(ip + p * i_strides[0] + 2 * i_strides[1], &canvas_y, 8);
+  }
+  return PP_OK;
+}

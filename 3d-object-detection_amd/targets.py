@@ -1,0 +1,91 @@
+"""Device-resident anchor-target assignment and IoU (torch tensors in/out).
+
+Counterpart of ``create_target`` (/root/reference utils/box_utils.py:162-232)
+with ``make_ious`` (data/pillars.cpp:400-427) and ``make_target``
+(box_utils.py:70-109) fused into HIP kernels; outputs are the float32 tensors
+``PPDataset.__getitem__`` returns (data/dataset.py:117-118).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, boxes
+
+
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+
+
+class TargetAssigner:
+    """Holds the (constant) anchor arrays on the device; ``assign(gt...)`` returns
+    ``(cls_targets[A,C] f32, reg_targets[A,9] f32)`` for one sample."""
+
+    def __init__(self, anchors, canvas_height, pos_thresh=0.6, num_classes=9, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("TargetAssigner needs a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None
+                                   else torch.device(device).index or 0)
+        self.canvas_height = float(canvas_height)
+        self.pos_thresh = float(pos_thresh)
+        self.num_classes = int(num_classes)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.a_corners = torch.as_tensor(np.ascontiguousarray(anchors["corners"]), **f64).contiguous()
+        self.a_centers = torch.as_tensor(np.ascontiguousarray(anchors["centers"]), **f64).contiguous()
+        self.a_wlh = torch.as_tensor(np.ascontiguousarray(anchors["wlh"]), **f64).contiguous()
+        self.a_yaw = torch.as_tensor(np.ascontiguousarray(anchors["yaw"]), **f64).contiguous()
+        self.A = self.a_corners.shape[0]
+        self._ctx = _lib.Context(self.device.index)
+        self._prm = _lib.TargetParams(self.pos_thresh, self.canvas_height, self.num_classes, 0)
+
+    def _gt_to_device(self, gt_centers, gt_wlh, gt_yaw, gt_classes):
+        gt_centers = np.asarray(gt_centers, np.float64).reshape(-1, 3)
+        gt_wlh = np.asarray(gt_wlh, np.float64).reshape(-1, 3)
+        gt_yaw = np.asarray(gt_yaw, np.float64).reshape(-1)
+        centers_img, corners_img = boxes.boxes_to_image_space(gt_centers, gt_wlh, gt_yaw,
+                                                              self.canvas_height)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        return (torch.as_tensor(np.ascontiguousarray(corners_img), **f64),
+                torch.as_tensor(np.ascontiguousarray(centers_img), **f64),
+                torch.as_tensor(np.ascontiguousarray(gt_centers), **f64),
+                torch.as_tensor(np.ascontiguousarray(gt_wlh), **f64),
+                torch.as_tensor(np.ascontiguousarray(gt_yaw), **f64),
+                torch.as_tensor(np.asarray(gt_classes, np.int32).reshape(-1), dtype=torch.int32,
+                                device=self.device))
+
+    def assign(self, gt_centers, gt_wlh, gt_yaw, gt_classes, check=False):
+        """gt_* describe the sample's boxes in canvas space (the fields of the lyft
+        ``Box`` objects the reference pickles: center, wlh, yaw, class index)."""
+        g = self._gt_to_device(gt_centers, gt_wlh, gt_yaw, gt_classes)
+        return self.assign_device(*g, check=check)
+
+    def assign_device(self, g_corners, g_centers_img, g_centers, g_wlh, g_yaw, g_class, check=False):
+        G = int(g_corners.shape[0])
+        cls_t = torch.empty((self.A, self.num_classes), dtype=torch.float32, device=self.device)
+        reg_t = torch.empty((self.A, 9), dtype=torch.float32, device=self.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _lib.lib().pp_assign_targets_dev(
+            self._ctx.handle, stream, self.A, _vp(self.a_corners), _vp(self.a_centers),
+            _vp(self.a_wlh), _vp(self.a_yaw), G, _vp(g_corners), _vp(g_centers_img),
+            _vp(g_centers), _vp(g_wlh), _vp(g_yaw), _vp(g_class), ctypes.byref(self._prm),
+            _vp(cls_t), _vp(reg_t))
+        _lib.check(rc, "pp_assign_targets_dev")
+        if check:
+            _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_dev")
+        return cls_t, reg_t
+
+    def ious(self, g_corners_img, g_centers_img, check=True):
+        """Dense [A,G] f64 IoU matrix on the device (make_ious, pillars.cpp:400-427)."""
+        f64 = dict(dtype=torch.float64, device=self.device)
+        gc = torch.as_tensor(np.ascontiguousarray(g_corners_img), **f64).contiguous()
+        gn = torch.as_tensor(np.ascontiguousarray(g_centers_img), **f64).contiguous()
+        G = int(gc.shape[0])
+        out = torch.empty((self.A, G), **f64)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _lib.lib().pp_make_ious_dev(self._ctx.handle, stream, _vp(self.a_corners),
+                                         _vp(self.a_centers), 3, self.A, _vp(gc), _vp(gn),
+                                         int(gn.shape[1]) if G else 3, G, _vp(out))
+        _lib.check(rc, "pp_make_ious_dev")
+        if check:
+            _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_make_ious_dev")
+        return out

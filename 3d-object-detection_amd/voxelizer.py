@@ -1,0 +1,125 @@
+"""Device-resident pillar voxelizer (torch tensors in, torch tensors out).
+
+Counterpart of the voxel stage of ``PPDataset.__getitem__`` (/root/reference
+data/dataset.py:88-106): ``np.zeros`` + ``pillars.create_pillars`` + transpose
+to ``[9,P,N]`` + ``.float()`` + ``indices.long()``, done by the HIP kernels of
+libpp_hip.so on the caller's current HIP stream.  torch is used for device
+memory and streams only.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class VoxelConfig:
+    """The grid constants of config.py:46-61,119-120 as explicit parameters."""
+    max_points_per_pillar: int = 100     # N  (config.py:119 ships 200)
+    max_pillars: int = 12000             # P  (config.py:120 ships 24000)
+    x_step: float = 0.2
+    y_step: float = 0.2
+    x_min: float = -50.0
+    y_min: float = -50.0
+    z_min: float = -10.0
+    x_max: float = 50.0
+    y_max: float = 50.0
+    z_max: float = 10.0
+    canvas_height: int = 500
+    order: int = _lib.ORDER_ROW_MAJOR
+
+    @staticmethod
+    def reference_default():
+        """config.py:46-53,60,119-120 exactly."""
+        return VoxelConfig(200, 24000, .2, .2, -60, -60, -10, 60, 60, 10, 600)
+
+    @staticmethod
+    def square(half, step, max_pillars, max_points, z_min=-10.0, z_max=10.0, order=0):
+        n = int(round(2 * half / step))
+        return VoxelConfig(max_points, max_pillars, step, step, -half, -half, z_min,
+                           half, half, z_max, n, order)
+
+    @property
+    def canvas_width(self):
+        # config.py:61
+        return int((self.x_max - self.x_min) / self.x_step)
+
+    def params(self):
+        return _lib.make_voxel_params(self.max_points_per_pillar, self.max_pillars, self.x_step,
+                                      self.y_step, self.x_min, self.y_min, self.z_min, self.x_max,
+                                      self.y_max, self.z_max, self.canvas_height, self.order)
+
+    def algorithmic_bytes(self, n_points):
+        """mandatory input read + mandatory dense write per sweep."""
+        return (16 * n_points + 4 * _lib.NUM_FEATURES * self.max_pillars * self.max_points_per_pillar
+                + 24 * self.max_pillars)
+
+
+class PillarVoxelizer:
+    """``voxelizer(points) -> (pillars[B,9,P,N] f32, indices[B,P,3] i64)``.
+
+    ``points`` is a float32 CUDA(HIP) tensor ``[B, n_cap, 4]`` (or ``[n,4]`` for a
+    single sweep); ``n_points`` gives the valid row count per sweep (default:
+    all rows).  Everything runs on ``torch.cuda.current_stream()``.
+    """
+
+    def __init__(self, cfg: VoxelConfig, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("PillarVoxelizer needs a HIP device; there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None
+                                   else torch.device(device).index or 0)
+        self._ctx = _lib.Context(self.device.index)
+        self._prm = cfg.params()
+
+    def reserve(self, batch, max_points):
+        _lib.check(_lib.lib().pp_voxelize_reserve(self._ctx.handle, int(batch), int(max_points),
+                                                  ctypes.byref(self._prm)), "pp_voxelize_reserve")
+
+    def set_timing(self, slots):
+        _lib.check(_lib.lib().pp_ctx_set_timing(self._ctx.handle, int(slots)), "pp_ctx_set_timing")
+
+    def read_emit_ms(self, cap=4096):
+        buf = (ctypes.c_float * cap)()
+        cnt = ctypes.c_int()
+        _lib.check(_lib.lib().pp_ctx_read_emit_ms(self._ctx.handle, buf, cap, ctypes.byref(cnt)),
+                   "pp_ctx_read_emit_ms")
+        return [buf[i] for i in range(cnt.value)]
+
+    def __call__(self, points, n_points=None, out=None, return_counts=False):
+        cfg = self.cfg
+        if points.dim() == 2:
+            points = points.unsqueeze(0)
+        if (points.dim() != 3 or points.shape[-1] != 4 or points.dtype != torch.float32
+                or not points.is_cuda or points.device != self.device):
+            raise ValueError("points must be a float32 tensor [B, n, 4] on " + str(self.device))
+        if not points.is_contiguous():
+            points = points.contiguous()
+        B, ncap = points.shape[0], points.shape[1]
+        if n_points is None:
+            n_points = [ncap] * B
+        n_arr = (ctypes.c_int32 * B)(*[int(v) for v in n_points])
+        P, N = cfg.max_pillars, cfg.max_points_per_pillar
+        if out is None:
+            pillars = torch.empty((B, _lib.NUM_FEATURES, P, N), dtype=torch.float32, device=self.device)
+            indices = torch.empty((B, P, 3), dtype=torch.int64, device=self.device)
+        else:
+            pillars, indices = out
+            if (pillars.shape != (B, _lib.NUM_FEATURES, P, N) or pillars.dtype != torch.float32
+                    or indices.shape != (B, P, 3) or indices.dtype != torch.int64
+                    or not pillars.is_contiguous() or not indices.is_contiguous()):
+                raise ValueError("out buffers have the wrong shape/dtype/layout")
+        counts = (torch.empty((B, 2), dtype=torch.int32, device=self.device)
+                  if return_counts else None)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.lib().pp_voxelize_dev(
+            self._ctx.handle, ctypes.c_void_p(stream), ctypes.c_void_p(points.data_ptr()),
+            ncap, n_arr, B, ctypes.byref(self._prm), ctypes.c_void_p(pillars.data_ptr()),
+            ctypes.c_void_p(indices.data_ptr()),
+            ctypes.c_void_p(counts.data_ptr()) if counts is not None else None)
+        _lib.check(rc, "pp_voxelize_dev")
+        if return_counts:
+            return pillars, indices, counts
+        return pillars, indices

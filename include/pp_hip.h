@@ -1,0 +1,168 @@
+/*
+ * pp_hip.h -- C ABI of the MI355X-native PointPillars hot path (libpp_hip.so).
+ *
+ * The reference (mr3543/3d-Object-Detection) defines no C ABI of its own: its
+ * only native surface is the pybind11 module of data/pillars.cpp:429-435 with
+ * two functions, create_pillars (pillars.cpp:236-249) and make_ious
+ * (pillars.cpp:400-404).  The entry points below are what a binding for that
+ * path binds to -- plain pointers, sizes, BYTE strides and scalars, no torch or
+ * numpy types.  Each one cites the reference interface it replaces.
+ *
+ * All functions return 0 on success or a negative PP_ERR_* code;
+ * pp_last_error() returns a thread-local description of the last failure.
+ * Nothing here ever falls back to a CPU implementation: without a HIP device
+ * every compute entry point fails with PP_ERR_HIP.
+ */
+#ifndef PP_HIP_H
+#define PP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK 0
+#define PP_ERR_INDEX (-2)   /* reference: pybind11 index_error -> IndexError      */
+#define PP_ERR_VALUE (-3)   /* invalid argument                                    */
+#define PP_ERR_WINDING (-4) /* reference: "IOU < 0" -> std::exit(1), pillars.cpp:166-169 */
+#define PP_ERR_NOMEM (-5)
+#define PP_ERR_HIP (-6)     /* HIP runtime error / no device                       */
+#define PP_ERR_INTERNAL (-7)
+
+/* Pillar emission order.  The reference emits pillars in boost::unordered_map
+ * iteration order (pillars.cpp:335), which is implementation-defined; these are
+ * the deterministic replacements (DESIGN.md "pillar order"). */
+#define PP_ORDER_ROW_MAJOR 0 /* ascending (canvas_y, canvas_x)        */
+#define PP_ORDER_SCRAMBLED 1 /* ascending (cell * mult) mod ncells    */
+
+#define PP_NUM_FEATURES 9 /* x,y,z,r,xp,yp,xc,yc,zc -- pillars.cpp:48-56 */
+#define PP_MAX_BATCH 32
+
+/* The scalar arguments of create_pillars, pillars.cpp:239-249, in its order. */
+typedef struct pp_voxel_params {
+  int32_t max_points_per_pillar; /* N */
+  int32_t max_pillars;           /* P */
+  double x_step, y_step;
+  double x_min, y_min, z_min;
+  double x_max, y_max, z_max;
+  double canvas_height;
+  int32_t order; /* PP_ORDER_*; not a reference argument (see above) */
+  int32_t reserved;
+} pp_voxel_params_t;
+
+typedef struct pp_ctx pp_ctx_t; /* per-device, per-stream workspace owner */
+
+const char *pp_last_error(void);
+const char *pp_version(void);
+int pp_device_count(void);
+
+/* A context owns the scratch buffers (cell ids, counts, buckets).  Use one
+ * context per HIP stream; calls on one context are serialised by that stream. */
+int pp_ctx_create(int device, pp_ctx_t **out);
+void pp_ctx_destroy(pp_ctx_t *ctx);
+
+/* Pre-size the workspace so that later pp_voxelize_dev calls allocate nothing
+ * (needed before HIP-graph capture). */
+int pp_voxelize_reserve(pp_ctx_t *ctx, int batch, int64_t max_points,
+                        const pp_voxel_params_t *prm);
+
+/*
+ * Device-resident voxelizer: replaces the whole voxel stage of
+ * PPDataset.__getitem__ (data/dataset.py:88-106): np.zeros + create_pillars
+ * (pillars.cpp:236-398) + transpose to [9,P,N] + f64->f32 + indices->int64.
+ *
+ *   points_dev   [batch][points_stride rows][4] f32 (x,y,z,r), device memory;
+ *                sweep b uses its first n_points[b] rows (n_points is a HOST array)
+ *   pillars_dev  [batch][9][P][N] f32, fully written (zero padded)
+ *   indices_dev  [batch][P][3] int64 {1, canvas_x, canvas_y} / {0,0,0}
+ *   num_cells_dev[batch][2] int32 or NULL: {non-empty cells (uncapped), in-range points}
+ *   stream       hipStream_t (NULL = default stream)
+ */
+int pp_voxelize_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
+                    int64_t points_stride, const int32_t *n_points, int batch,
+                    const pp_voxel_params_t *prm, float *pillars_dev,
+                    int64_t *indices_dev, int32_t *num_cells_dev);
+
+/*
+ * Host drop-in for create_pillars (pillars.cpp:236-249, exported :433).
+ * points [n,>=4], tensor [P',N',>=9], indices [P',>=3]: f64 host arrays with
+ * arbitrary BYTE strides, mutated in place; nothing is zeroed (pillars.cpp never
+ * zeroes); out-of-range writes return PP_ERR_INDEX after the in-range part was
+ * written (pybind11 .mutable_at semantics).  num_cells (may be NULL) receives
+ * the number of non-empty cells.
+ */
+int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,
+                          int64_t p_stride0, int64_t p_stride1, void *tensor,
+                          const int64_t t_shape[3], const int64_t t_strides[3],
+                          void *indices, const int64_t i_shape[2],
+                          const int64_t i_strides[2],
+                          const pp_voxel_params_t *prm, int64_t *num_cells);
+
+/*
+ * Host drop-in for make_ious (pillars.cpp:400-404, exported :432): gated
+ * all-pairs rotated IoU; every ious[i][j] is written.  f64 host arrays, BYTE
+ * strides.  a_corners [A,4,2], g_corners [G,4,2], a_centers [A,>=2],
+ * g_centers [G,>=2], ious [A,G].
+ */
+int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
+                     const int64_t ac_strides[3], const void *g_corners,
+                     int64_t G, const int64_t gc_strides[3],
+                     const void *a_centers, const int64_t an_strides[2],
+                     const void *g_centers, const int64_t gn_strides[2],
+                     void *ious, const int64_t io_strides[2]);
+
+/* Error flag of the most recent IoU / target-assignment launch on this
+ * context: synchronises `stream`, returns PP_ERR_WINDING if a pair that passed
+ * the centre gate had a wrongly wound box (the reference's "IOU < 0" exit,
+ * pillars.cpp:166-169), else PP_OK.  pp_make_ious_f64 calls it itself. */
+int pp_iou_check(pp_ctx_t *ctx, void *stream);
+
+/* Device-resident make_ious: contiguous f64 device arrays, ious_dev [A][G]. */
+int pp_make_ious_dev(pp_ctx_t *ctx, void *stream, const double *a_corners_dev,
+                     const double *a_centers_dev, int64_t a_center_cols,
+                     int64_t A, const double *g_corners_dev,
+                     const double *g_centers_dev, int64_t g_center_cols,
+                     int64_t G, double *ious_dev);
+
+/*
+ * Device-resident fused target assignment: replaces create_target
+ * (utils/box_utils.py:162-232) including make_ious (pillars.cpp:400-427) and
+ * make_target (box_utils.py:70-109); the [A,G] IoU matrix is never
+ * materialised.  All inputs contiguous f64 device arrays:
+ *   a_corners [A,4,2] a_centers [A,3] a_wlh [A,3] a_yaw [A]          (anchors,
+ *       image space, box_utils.py:111-159)
+ *   g_corners [G,4,2] g_centers_img [G,3]  (boxes_to_image_space, :19-32)
+ *   g_centers [G,3] g_wlh [G,3] g_yaw [G]  (canvas space Box fields)
+ *   g_class [G] int32
+ * Outputs f32 (data/dataset.py:117-118 casts to float):
+ *   cls_targets [A,num_classes], reg_targets [A,9]
+ */
+typedef struct pp_target_params {
+  double pos_thresh;    /* cfg.DATA.IOU_POS_THRESH, config.py:122 */
+  double canvas_height; /* cfg.DATA.CANVAS_HEIGHT, config.py:60   */
+  int32_t num_classes;  /* cfg.DATA.NUM_CLASSES, config.py:97     */
+  int32_t reserved;
+} pp_target_params_t;
+
+int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream, int64_t A,
+                          const double *a_corners, const double *a_centers,
+                          const double *a_wlh, const double *a_yaw, int64_t G,
+                          const double *g_corners, const double *g_centers_img,
+                          const double *g_centers, const double *g_wlh,
+                          const double *g_yaw, const int32_t *g_class,
+                          const pp_target_params_t *prm, float *cls_targets,
+                          float *reg_targets);
+
+/* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
+ * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
+ * stream around the k_emit launch.  pp_ctx_read_emit_ms synchronises on the
+ * recorded stop events, returns up to `cap` elapsed times (oldest first, in
+ * milliseconds) and empties the ring. */
+int pp_ctx_set_timing(pp_ctx_t *ctx, int slots);
+int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

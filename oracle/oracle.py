@@ -1,0 +1,313 @@
+"""NumPy/ctypes front end of the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg -- never from the product package.
+
+PARITY STATUS: parity unpinned against the real reference build (Boost missing,
+no reference fixtures; see pp_oracle.h).  Pinned by SURVEY.md 5.9/8c probe values
+and analytic IoU known answers (tests/test_oracle_*.py).
+
+Citations are relative to /root/reference.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpp_oracle.so")
+
+OK, ERR_INDEX, ERR_VALUE, ERR_WINDING, ERR_NOMEM = 0, -2, -3, -4, -5
+ORDER_ROW_MAJOR, ORDER_SCRAMBLED, ORDER_HASH = 0, 1, 2
+
+
+def build(force=False):
+    """Compile oracle/pp_oracle.c with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "pp_oracle.c")
+    hdr = os.path.join(_HERE, "pp_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libpp_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        i64, dbl, vp, ci = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
+        L.ppo_grid_dims.argtypes = [dbl] * 6 + [ctypes.POINTER(i64)] * 2
+        L.ppo_grid_dims.restype = ci
+        L.ppo_scramble_mult.argtypes = [i64]
+        L.ppo_scramble_mult.restype = i64
+        L.ppo_create_pillars.argtypes = (
+            [vp, i64, i64, i64] + [vp] + [i64] * 6 + [vp] + [i64] * 4 + [ci, ci]
+            + [dbl] * 9 + [ci, ctypes.POINTER(i64)])
+        L.ppo_create_pillars.restype = ci
+        L.ppo_cell_counts.argtypes = [vp, i64, i64, i64, vp, i64] + [dbl] * 9
+        L.ppo_cell_counts.restype = i64
+        L.ppo_iou_pair.argtypes = [vp, vp, ctypes.POINTER(ci)]
+        L.ppo_iou_pair.restype = dbl
+        L.ppo_make_ious.argtypes = ([vp] + [i64] * 4 + [vp] + [i64] * 4 + [vp, i64, i64]
+                                    + [vp, i64, i64] + [vp, i64, i64])
+        L.ppo_make_ious.restype = ci
+        _lib = L
+    return _lib
+
+
+def _raise(rc, what):
+    if rc == OK:
+        return
+    if rc == ERR_INDEX:
+        raise IndexError(f"{what}: index out of range")  # pybind11 index_error
+    if rc == ERR_WINDING:
+        raise ValueError(f"{what}: IOU < 0 (wrong corner winding)")
+    if rc == ERR_NOMEM:
+        raise MemoryError(what)
+    raise ValueError(f"{what}: invalid argument (rc={rc})")
+
+
+def _f64(a, name, writable=False):
+    a = np.asarray(a) if not isinstance(a, np.ndarray) else a
+    if a.dtype != np.float64:
+        if writable:
+            # the reference silently writes into a forcecast temporary and the
+            # results vanish; the oracle refuses instead.
+            raise TypeError(f"{name} must be a float64 array")
+        a = a.astype(np.float64)
+    if writable and not a.flags.writeable:
+        raise TypeError(f"{name} must be writable")
+    return a
+
+
+def grid_dims(x_step, y_step, x_min, y_min, x_max, y_max):
+    nx, ny = ctypes.c_int64(), ctypes.c_int64()
+    _raise(lib().ppo_grid_dims(x_step, y_step, x_min, y_min, x_max, y_max,
+                               ctypes.byref(nx), ctypes.byref(ny)), "grid_dims")
+    return nx.value, ny.value
+
+
+def scramble_mult(ncells):
+    return lib().ppo_scramble_mult(ncells)
+
+
+def create_pillars(points, tensor, indices, max_points_per_pillar, max_pillars,
+                   x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max,
+                   canvas_height, order=ORDER_ROW_MAJOR):
+    """data/pillars.cpp:236-398 (positional signature of pillars.cpp:236-249).
+
+    Returns the number of non-empty cells (the reference returns None)."""
+    points = _f64(points, "points")
+    tensor = _f64(tensor, "tensor", writable=True)
+    indices = _f64(indices, "indices", writable=True)
+    if points.ndim != 2 or tensor.ndim != 3 or indices.ndim != 2:
+        raise IndexError("create_pillars: wrong number of dimensions")
+    if points.shape[0] and points.shape[1] < 4:
+        raise IndexError("create_pillars: points needs >= 4 columns")
+    ncell = ctypes.c_int64()
+    rc = lib().ppo_create_pillars(
+        points.ctypes.data, points.shape[0], points.strides[0], points.strides[1],
+        tensor.ctypes.data, *tensor.shape, *tensor.strides,
+        indices.ctypes.data, *indices.shape, *indices.strides,
+        int(max_points_per_pillar), int(max_pillars),
+        float(x_step), float(y_step), float(x_min), float(y_min), float(z_min),
+        float(x_max), float(y_max), float(z_max), float(canvas_height),
+        int(order), ctypes.byref(ncell))
+    _raise(rc, "create_pillars")
+    return ncell.value
+
+
+def cell_counts(points, x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max,
+                canvas_height):
+    """[M,3] int64 (canvas_x, canvas_y, count) of every non-empty cell, row-major."""
+    points = _f64(points, "points")
+    cap = max(1, points.shape[0])
+    out = np.zeros((cap, 3), np.int64)
+    m = lib().ppo_cell_counts(points.ctypes.data, points.shape[0], points.strides[0],
+                              points.strides[1], out.ctypes.data, cap,
+                              float(x_step), float(y_step), float(x_min), float(y_min),
+                              float(z_min), float(x_max), float(y_max), float(z_max),
+                              float(canvas_height))
+    if m < 0:
+        _raise(int(m), "cell_counts")
+    return out[:m].copy()
+
+
+def iou_pair(anchor, gt):
+    """data/pillars.cpp:132-172 for one (anchor CCW, gt CW) quad pair."""
+    a = np.ascontiguousarray(anchor, np.float64).reshape(8)
+    g = np.ascontiguousarray(gt, np.float64).reshape(8)
+    s = ctypes.c_int()
+    v = lib().ppo_iou_pair(a.ctypes.data, g.ctypes.data, ctypes.byref(s))
+    _raise(s.value, "iou")
+    return v
+
+
+def make_ious(a_corners, g_corners, a_centers, g_centers, ious):
+    """data/pillars.cpp:400-427 (positional signature of pillars.cpp:400-404)."""
+    a_corners = _f64(a_corners, "a_corners")
+    g_corners = _f64(g_corners, "g_corners")
+    a_centers = _f64(a_centers, "a_centers")
+    g_centers = _f64(g_centers, "g_centers")
+    ious = _f64(ious, "ious", writable=True)
+    A, G = a_corners.shape[0], g_corners.shape[0]
+    if (a_corners.shape[1:] != (4, 2) or g_corners.shape[1:] != (4, 2)
+            or a_centers.shape[0] < A or g_centers.shape[0] < G
+            or a_centers.shape[1] < 2 or g_centers.shape[1] < 2
+            or ious.shape[0] < A or ious.shape[1] < G):
+        raise IndexError("make_ious: shape mismatch")
+    rc = lib().ppo_make_ious(
+        a_corners.ctypes.data, A, *a_corners.strides,
+        g_corners.ctypes.data, G, *g_corners.strides,
+        a_centers.ctypes.data, *a_centers.strides,
+        g_centers.ctypes.data, *g_centers.strides,
+        ious.ctypes.data, *ious.strides)
+    _raise(rc, "make_ious")
+
+
+# --------------------------------------------------------------------------- #
+# caller glue: data/dataset.py:88-106                                          #
+# --------------------------------------------------------------------------- #
+
+def dataset_voxel_stage(lidar_points, max_pillars, max_points, x_step, y_step,
+                        x_min, y_min, z_min, x_max, y_max, z_max, canvas_height,
+                        order=ORDER_ROW_MAJOR):
+    """np.zeros + create_pillars + transpose + f32 cast, exactly the work of
+    data/dataset.py:89-106 (minus the optional data_mean).  Returns
+    (pillar[9,P,N] float32, indices[P,3] int64, num_cells)."""
+    pillar = np.zeros((max_pillars, max_points, 9))          # dataset.py:89
+    indices = np.zeros((max_pillars, 3))                     # dataset.py:90
+    m = create_pillars(lidar_points, pillar, indices, max_points, max_pillars,
+                       x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max,
+                       canvas_height, order)                 # dataset.py:92-97
+    pillar = pillar.transpose([2, 0, 1])                     # dataset.py:99
+    pillar = np.ascontiguousarray(pillar, dtype=np.float32)  # dataset.py:101 (.float())
+    indices = indices.astype(np.int64)                       # dataset.py:106 (.long())
+    return pillar, indices, m
+
+
+# --------------------------------------------------------------------------- #
+# boxes: lyft_dataset_sdk Box.bottom_corners (absent third-party, RECALLED)    #
+# --------------------------------------------------------------------------- #
+
+def box_bottom_corners_xy(center, wlh, yaw):
+    """xy of Box.bottom_corners() for a yaw-only box: corners
+    (+l/2,-w/2), (+l/2,+w/2), (-l/2,+w/2), (-l/2,-w/2) rotated by yaw, plus the
+    centre -> counter-clockwise in a y-up frame.  lyft_dataset_sdk is not in the
+    image (call sites utils/box_utils.py:27,149): this is its published layout,
+    recalled and unverified."""
+    center = np.asarray(center, np.float64)
+    wlh = np.asarray(wlh, np.float64)
+    yaw = np.asarray(yaw, np.float64)
+    w, l = wlh[..., 0], wlh[..., 1]
+    lx = np.stack([l / 2, l / 2, -l / 2, -l / 2], -1)
+    ly = np.stack([-w / 2, w / 2, w / 2, -w / 2], -1)
+    c, s = np.cos(yaw)[..., None], np.sin(yaw)[..., None]
+    x = c * lx - s * ly + center[..., 0:1]
+    y = s * lx + c * ly + center[..., 1:2]
+    return np.stack([x, y], -1)
+
+
+def boxes_to_image_space(centers, wlh, yaw, canvas_height):
+    """utils/box_utils.py:19-32: flip y into image rows."""
+    centers = np.array(centers, np.float64, copy=True)
+    corners = box_bottom_corners_xy(centers, wlh, yaw)
+    centers[..., 1] = (canvas_height - 1) - centers[..., 1]
+    corners[..., 1] = (canvas_height - 1) - corners[..., 1]
+    return centers, corners
+
+
+def make_anchor_boxes(fm_height, fm_width, fm_scale, anchor_dims, anchor_yaws_deg,
+                      anchor_zs):
+    """utils/box_utils.py:111-159: anchors ordered (y, x, d); returns
+    corners[A,4,2], centers[A,3], wlh[A,3], yaw[A] (radians)."""
+    dims = np.asarray(anchor_dims, np.float64)
+    nd = dims.shape[0]
+    yy, xx, dd = np.meshgrid(np.arange(fm_height), np.arange(fm_width), np.arange(nd),
+                             indexing="ij")
+    xc = (xx.reshape(-1) + 0.5) / fm_scale
+    yc = (yy.reshape(-1) + 0.5) / fm_scale
+    d = dd.reshape(-1)
+    centers = np.stack([xc, yc, np.asarray(anchor_zs, np.float64)[d]], -1)
+    wlh = dims[d]
+    yaw = np.deg2rad(np.asarray(anchor_yaws_deg, np.float64))[d]
+    corners = box_bottom_corners_xy(centers, wlh, yaw)
+    return corners, centers, wlh, yaw
+
+
+# --------------------------------------------------------------------------- #
+# targets: utils/box_utils.py:70-109 and 162-232                               #
+# --------------------------------------------------------------------------- #
+
+def make_target(a_center, a_wlh, a_yaw, g_center, g_wlh, g_yaw, canvas_height):
+    """utils/box_utils.py:70-109 for one (anchor, ground-truth) pair.
+    g_center is in canvas space (y not yet flipped), as in the reference."""
+    ax, ay, az = a_center
+    gx, gy, gz = g_center
+    aw, al, ah = a_wlh
+    gw, gl, gh = g_wlh
+    ad = np.sqrt(aw ** 2 + al ** 2)
+    at, gt = float(a_yaw), float(g_yaw)
+    gy = (canvas_height - 1) - gy
+    dx = (gx - ax) / ad
+    dy = (gy - ay) / ad
+    dz = (gz - az) / ah
+    dw = np.log(gw / aw)
+    dl = np.log(gl / al)
+    dh = np.log(gh / ah)
+    if gt <= np.pi and gt >= np.pi / 2:
+        gt -= np.pi
+    elif gt >= -np.pi and gt <= -np.pi / 2:
+        gt += np.pi
+    dt = np.sin(gt - at)
+    if ((gt - at) <= np.pi and (gt - at) >= np.pi / 2) or \
+            ((gt - at) >= -np.pi and (gt - at) <= -np.pi / 2):
+        ort = 1
+    else:
+        ort = 0
+    return [1, dx, dy, dz, dw, dl, dh, dt, ort]
+
+
+def create_target(anchor_corners, gt_corners, anchor_centers, gt_centers_img,
+                  anchor_wlh, anchor_yaw, gt_centers_canvas, gt_wlh, gt_yaw,
+                  gt_classes, canvas_height, pos_thresh=0.6, num_classes=9, reg_dims=8):
+    """utils/box_utils.py:162-232 on flat arrays instead of lyft Box lists.
+
+    gt_corners / gt_centers_img are the image-space arrays of
+    boxes_to_image_space; gt_centers_canvas the un-flipped Box.center values
+    that make_target flips itself (box_utils.py:83)."""
+    A, G = len(anchor_corners), len(gt_corners)
+    ious = np.zeros((A, G))
+    make_ious(anchor_corners, gt_corners, anchor_centers, gt_centers_img, ious)
+    cls_targets = np.zeros((A, num_classes))
+    reg_targets = np.zeros((A, reg_dims + 1))
+    gt_box_classes = np.asarray(gt_classes, np.int32)
+    max_ious = np.max(ious, axis=1)
+    arg_max_ious = np.argmax(ious, axis=1)
+    pos_anchors = np.where(max_ious > pos_thresh)[0]
+    pos_boxes = arg_max_ious[pos_anchors]
+    iousT = ious.transpose([1, 0])
+    top_anchor_for_box = np.argmax(iousT, axis=1)
+    filter_inds = np.nonzero(top_anchor_for_box)
+    top_anchor_for_box = top_anchor_for_box[filter_inds]
+    cls_targets[pos_anchors, gt_box_classes[pos_boxes]] = 1
+    cls_targets[top_anchor_for_box, :] = 0
+    cls_targets[top_anchor_for_box, gt_box_classes[filter_inds]] = 1
+    for i, anch in enumerate(pos_anchors):
+        g = pos_boxes[i]
+        reg_targets[anch, :] = make_target(anchor_centers[anch], anchor_wlh[anch],
+                                           anchor_yaw[anch], gt_centers_canvas[g],
+                                           gt_wlh[g], gt_yaw[g], canvas_height)
+    for i, anch in enumerate(top_anchor_for_box):
+        g = filter_inds[0][i]
+        reg_targets[anch, :] = make_target(anchor_centers[anch], anchor_wlh[anch],
+                                           anchor_yaw[anch], gt_centers_canvas[g],
+                                           gt_wlh[g], gt_yaw[g], canvas_height)
+    return cls_targets, reg_targets, ious

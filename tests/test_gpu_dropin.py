@@ -1,0 +1,123 @@
+"""GPU tests of the host drop-in module (the reference's pybind11 surface,
+data/pillars.cpp:429-435) through pp_create_pillars_f64 / pp_make_ious_f64."""
+import numpy as np
+import pytest
+
+from util import grid_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _v1_points():
+    # cell (1,2) x5 points, cell (0,0) x2 points, 3 boundary rejects
+    return np.array([[1.1, 2.1, 0.0, 10], [0.5, 0.5, 0, 1], [1.2, 2.2, 0.1, 11], [1.3, 2.3, 0.2, 12],
+                     [4.0, 1, 0, 0], [1, 1, 1.0, 0], [-0.001, 1, 0, 0], [1.5, 2.5, 0.3, 13],
+                     [0.25, 0.75, 0.5, 2], [1.8, 2.8, 0.4, 14]])
+
+
+def test_v1_hand_case_bit_exact(gpu, oracle):
+    from pp_amd import pillars
+    pts = _v1_points()
+    T, I = np.zeros((4, 3, 9)), np.zeros((4, 3))
+    assert pillars.create_pillars(pts, T, I, 3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4) is None
+    Tr, Ir = np.zeros((4, 3, 9)), np.zeros((4, 3))
+    oracle.create_pillars(pts, Tr, Ir, 3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4)
+    assert np.array_equal(T, Tr) and np.array_equal(I, Ir)
+    # the row recorded by the survey probe
+    assert np.allclose(T[0, 0], [1.1, 2.1, 0, 10, -0.1, -1.1, 0.28, 0.28, 0.2], atol=1e-12)
+    assert list(I[0]) == [1, 1, 1] and list(I[1]) == [1, 0, 3]
+
+
+def test_f64_points_strided_prefilled(gpu, oracle):
+    """f64 (not f32-representable) coordinates, F-order strided view like
+    data/dataset.py:88, outputs pre-filled with a sentinel stay untouched where
+    the reference would not write, Python ints / numpy ints as scalars."""
+    from pp_amd import pillars
+    rng = np.random.default_rng(3)
+    agg = rng.uniform(-12, 12, (4, 30000))          # [4, n] like agg_pc
+    agg[2] = rng.uniform(-3, 3, 30000)
+    pts = agg.transpose([1, 0])                     # strided view, dataset.py:88
+    P, N = 20000, 12
+    T = np.full((P, N, 9), 7.5)
+    I = np.full((P, 3), -3.0)
+    pillars.create_pillars(pts, T, I, N, P, .2, .2, -10, -10, -3, 10, 10, 3, np.int32(100))
+    Tr = np.full((P, N, 9), 7.5)
+    Ir = np.full((P, 3), -3.0)
+    m = oracle.create_pillars(pts, Tr, Ir, N, P, .2, .2, -10, -10, -3, 10, 10, 3, 100)
+    assert m < P
+    assert np.array_equal(T, Tr) and np.array_equal(I, Ir)   # bit-exact f64 incl. sentinels
+    assert (T == 7.5).any() and (I[m:] == -3.0).all()
+
+
+def test_non_contiguous_outputs_and_f32_input(gpu, oracle):
+    from pp_amd import pillars, synth
+    pts32 = synth.lidar_like(5000, 8.0, 2)          # f32 input is force-cast (harmless)
+    P, N = 4000, 8
+    big = np.zeros((P, N, 18))
+    T = big[:, :, ::2]                              # strided output view
+    Ibig = np.zeros((P, 6))
+    I = Ibig[:, ::2]
+    pillars.create_pillars(pts32, T, I, N, P, .2, .2, -8, -8, -10, 8, 8, 10, 80)
+    Tr, Ir = np.zeros((P, N, 9)), np.zeros((P, 3))
+    oracle.create_pillars(pts32.astype(np.float64), Tr, Ir, N, P, .2, .2, -8, -8, -10, 8, 8, 10, 80)
+    assert np.array_equal(T, Tr) and np.array_equal(I, Ir)
+    assert not big[:, :, 1::2].any() and not Ibig[:, 1::2].any()
+
+
+def test_errors_match_reference_surface(gpu, oracle):
+    from pp_amd import pillars
+    pts = _v1_points()
+    # non-f64 outputs are rejected loudly (the reference silently loses the writes)
+    with pytest.raises(TypeError):
+        pillars.create_pillars(pts, np.zeros((4, 3, 9), np.float32), np.zeros((4, 3)),
+                               3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4)
+    with pytest.raises(TypeError):
+        pillars.create_pillars(pts, np.zeros((4, 3, 9)), np.zeros((4, 3), np.int64),
+                               3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4)
+    # undersized tensor -> IndexError after the in-range part was written (pybind11 .mutable_at)
+    T, I = np.zeros((1, 3, 9)), np.zeros((4, 3))
+    with pytest.raises(IndexError):
+        pillars.create_pillars(pts, T, I, 3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4)
+    Tr, Ir = np.zeros((1, 3, 9)), np.zeros((4, 3))
+    with pytest.raises(IndexError):
+        oracle.create_pillars(pts, Tr, Ir, 3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4)
+    assert np.array_equal(T, Tr) and np.array_equal(I, Ir) and T.any()
+    with pytest.raises(ValueError):
+        pillars.create_pillars(pts, np.zeros((4, 3, 9)), np.zeros((4, 3)), 3, 4, 0.0, 1, 0, 0, -1, 4, 4, 1, 4)
+
+
+def test_max_pillars_and_max_points_caps(gpu, oracle):
+    from pp_amd import pillars, synth
+    pts = synth.lidar_like(20000, 10.0, 9).astype(np.float64)
+    for P, N in ((50, 3), (0, 5), (5, 0), (100000, 1000)):
+        shape_p = max(P, 1) if P < 100000 else 12000
+        T, I = np.zeros((shape_p, max(N, 1), 9)), np.zeros((shape_p, 3))
+        Tr, Ir = T.copy(), I.copy()
+        pillars.create_pillars(pts, T, I, N, min(P, shape_p), *grid_args(10.0, 0.2))
+        oracle.create_pillars(pts, Tr, Ir, N, min(P, shape_p), *grid_args(10.0, 0.2))
+        assert np.array_equal(T, Tr) and np.array_equal(I, Ir), (P, N)
+
+
+def test_make_ious_host_dropin(gpu, oracle):
+    from pp_amd import boxes, pillars, synth
+    anchors = boxes.make_anchors(boxes.AnchorConfig(60, 60))
+    gt = synth.gt_boxes(12, 120, seed=4, margin=15.0)
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 120)
+    A, G = len(anchors["corners"]), 12
+    ious = np.full((A, G), -5.0)
+    assert pillars.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious) is None
+    ref = np.full((A, G), -5.0)
+    oracle.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ref)
+    assert np.array_equal(ious, ref)            # bit-exact: same f64 operation sequence
+    assert (ious > 0.6).any() and (ious == 0).sum() > 0.9 * A * G
+    # strided / transposed output and f32 output
+    iousT = np.zeros((G, A)).T
+    pillars.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, iousT)
+    assert np.array_equal(iousT, ref)
+    with pytest.raises(TypeError):
+        pillars.make_ious(anchors["corners"], k_img, anchors["centers"], c_img,
+                          np.zeros((A, G), np.float32))
+    # wrong winding raises instead of std::exit(1) (pillars.cpp:166-169)
+    with pytest.raises(ValueError):
+        pillars.make_ious(anchors["corners"], k_img[:, ::-1].copy(), anchors["centers"], c_img,
+                          np.zeros((A, G)))

@@ -1,0 +1,200 @@
+"""GPU parity tests of the HIP voxelizer against the CPU oracle (through the C ABI).
+
+Bar (BASELINE.json north_star): pillar indices / counts bit-exact; float features
+within 1e-5.  The kernels are written to do better (same f64 operation order as
+the oracle, one final f32 rounding), so most cases also assert bit equality.
+"""
+import numpy as np
+import pytest
+
+from util import C1, C2, C5, grid_args, oracle_stage, pillars_by_cell
+
+pytestmark = pytest.mark.gpu
+
+FEATURE_TOL = 1e-5  # north_star tolerance on the float D-features
+
+
+def _vox(gpu, half, step, P, N, order=0):
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    return PillarVoxelizer(VoxelConfig.square(half, step, P, N, order=order), device=gpu)
+
+
+def _run(gpu, vox, pts32, n_points=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(pts32)).to(gpu)
+    pil, idx, cnt = vox(t, n_points=n_points, return_counts=True)
+    torch.cuda.synchronize()
+    return pil.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+
+
+def _check_exact(pil, idx, ref_p, ref_i):
+    assert np.array_equal(idx, ref_i), "pillar indices differ"
+    # occupancy pattern (which slots are non-zero) is integer work: exact
+    assert np.array_equal(pil != 0, ref_p != 0)
+    assert np.abs(pil - ref_p).max() <= FEATURE_TOL
+    return np.array_equal(pil, ref_p)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_below_cap_exact(gpu, oracle, seed):
+    """cells <= P: exact set + content equality."""
+    from pp_amd import synth
+    pts = synth.lidar_like(20000, 20.0, seed)
+    vox = _vox(gpu, 20.0, 0.2, 16000, 32)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, 16000, 32, 20.0, 0.2)
+    assert m <= 16000 and cnt[0, 0] == m
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i), "features not bit-identical"
+
+
+def test_overflow_same_order_and_subset_rule(gpu, oracle):
+    """cells > P (the normal regime): identical to the oracle run in the same
+    deterministic order, and every emitted pillar equals the UNCAPPED oracle's
+    pillar for that cell whatever order the oracle used (SURVEY 7 hard part 1)."""
+    from pp_amd import synth
+    pts = synth.lidar_like(60000, 50.0, 3)
+    P, N = 6000, 20
+    vox = _vox(gpu, 50.0, 0.2, P, N)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 50.0, 0.2)
+    assert m > P and cnt[0, 0] == m
+    assert (idx[0][:, 0] == 1).all(), "exactly P rows must be filled"
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+    unc_p, unc_i, _ = oracle_stage(oracle, pts, m, N, 50.0, 0.2, order=oracle.ORDER_HASH)
+    unc = pillars_by_cell(unc_p, unc_i)
+    mine = pillars_by_cell(pil[0], idx[0])
+    assert len(mine) == P
+    for cell, block in mine.items():
+        assert np.array_equal(block, unc[cell]), cell
+
+
+def test_scrambled_order(gpu, oracle):
+    from pp_amd import synth
+    pts = synth.lidar_like(30000, 30.0, 5)
+    P, N = 4000, 16
+    vox = _vox(gpu, 30.0, 0.2, P, N, order=1)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 30.0, 0.2, order=oracle.ORDER_SCRAMBLED)
+    assert m > P
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+    # the scrambled survivors are spread over the whole canvas, not the first rows
+    rows = idx[0][:, 2]
+    assert rows.max() - rows.min() > 0.8 * 300
+
+
+def test_config1_dense_cells_big_pillar_path(gpu, oracle):
+    """BASELINE config 1 (100x100 grid): hundreds of points per cell, i.e. the
+    N-cap truncation and the ballot-rescan path for buckets beyond the LDS pool."""
+    from pp_amd import synth
+    c = C1
+    pts = synth.lidar_like(c["n"], c["half"], 0)
+    vox = _vox(gpu, c["half"], c["step"], c["P"], c["N"])
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, c["P"], c["N"], c["half"], c["step"])
+    cc = oracle.cell_counts(pts.astype(np.float64), *grid_args(c["half"], c["step"]))
+    assert cc[:, 2].max() > 128, "case must exercise the big-pillar path"
+    assert cnt[0, 0] == m and cnt[0, 1] == cc[:, 2].sum()
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+
+
+def test_all_points_in_one_cell(gpu, oracle):
+    rng = np.random.default_rng(7)
+    pts = np.zeros((5000, 4), np.float32)
+    pts[:, 0] = 0.05 + 0.1 * rng.random(5000)
+    pts[:, 1] = 0.05 + 0.1 * rng.random(5000)
+    pts[:, 2] = rng.random(5000)
+    pts[:, 3] = rng.random(5000)
+    vox = _vox(gpu, 4.0, 0.2, 64, 100)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, 64, 100, 4.0, 0.2)
+    assert m == 1 and cnt[0, 0] == 1 and cnt[0, 1] == 5000
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+
+
+@pytest.mark.parametrize("P,N", [(1000, 7), (37, 10), (1, 1), (50, 13), (16, 64), (4095, 4)])
+def test_odd_shapes(gpu, oracle, P, N):
+    """N not a multiple of 4 (scalar store path), P not a multiple of the
+    workgroup's pillar tile, tiny shapes."""
+    from pp_amd import synth
+    pts = synth.lidar_like(8000, 10.0, 11)
+    vox = _vox(gpu, 10.0, 0.2, P, N)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 10.0, 0.2)
+    assert cnt[0, 0] == m
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+
+
+def test_boundaries_nan_and_empty(gpu, oracle):
+    """half-open box on all four sides, NaN/inf rows, empty cloud."""
+    half, step = 2.0, 1.0
+    nxt = np.nextafter
+    f32 = np.float32
+    rows = [
+        [-2.0, 0.5, 0.0, 1],            # x == x_min      -> kept
+        [nxt(f32(2.0), f32(0)), 0.5, 0, 2],   # just below x_max -> kept
+        [2.0, 0.5, 0.0, 3],             # x == x_max      -> dropped
+        [0.5, -2.0, 0.0, 4],            # y == y_min      -> kept
+        [0.5, 2.0, 0.0, 5],             # y == y_max      -> dropped
+        [0.5, 0.5, -10.0, 6],           # z == z_min      -> kept
+        [0.5, 0.5, 10.0, 7],            # z == z_max      -> dropped
+        [np.nan, 0.5, 0.0, 8],          # NaN             -> dropped (documented)
+        [0.5, np.inf, 0.0, 9],
+        [-0.0, -0.0, 0.0, 10],          # negative zero
+    ]
+    pts = np.array(rows, np.float32)
+    vox = _vox(gpu, half, step, 16, 4)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, 16, 4, half, step)
+    cc = oracle.cell_counts(pts.astype(np.float64), *grid_args(half, step))
+    assert m == 4 and cc[:, 2].sum() == 5          # 4 cells, 5 surviving points
+    assert cnt[0, 0] == m and cnt[0, 1] == cc[:, 2].sum()
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+    # empty cloud and a cloud entirely out of range: all-zero outputs
+    for cloud, npts in ((np.zeros((4, 4), np.float32), [0]),
+                        (np.full((4, 4), 100.0, np.float32), None)):
+        pil, idx, cnt = _run(gpu, vox, cloud, n_points=npts)
+        assert not pil.any() and not idx.any() and cnt[0, 0] == 0 and cnt[0, 1] == 0
+
+
+def test_batch_ragged_and_rerun_identical(gpu, oracle):
+    """grid.y = sweep: a ragged batch equals per-sweep oracle runs; a second call
+    on the same context (self-cleaned workspace) is bit-identical."""
+    from pp_amd import synth
+    ns = [9000, 12000, 1, 7000]
+    clouds = [synth.lidar_like(12000, 15.0, 20 + i) for i in range(4)]
+    batch = np.stack(clouds)
+    P, N = 3000, 24
+    vox = _vox(gpu, 15.0, 0.2, P, N)
+    pil, idx, cnt = _run(gpu, vox, batch, n_points=ns)
+    for b in range(4):
+        ref_p, ref_i, m = oracle_stage(oracle, clouds[b][:ns[b]], P, N, 15.0, 0.2)
+        assert cnt[b, 0] == m
+        assert _check_exact(pil[b], idx[b], ref_p, ref_i), b
+    pil2, idx2, cnt2 = _run(gpu, vox, batch, n_points=ns)
+    assert np.array_equal(pil, pil2) and np.array_equal(idx, idx2) and np.array_equal(cnt, cnt2)
+
+
+@pytest.mark.parametrize("cfg", [C2, C5], ids=["config2", "config5"])
+def test_full_size_configs(gpu, oracle, cfg):
+    """BASELINE configs 2 and 5 at full size: oracle comparison plus the
+    size-independent properties (exactly min(cells,P) rows, counts per cell,
+    sortedness of the row-major order, points conserved)."""
+    from pp_amd import synth
+    pts = synth.lidar_like(cfg["n"], cfg["half"], 0)
+    P, N = cfg["P"], cfg["N"]
+    vox = _vox(gpu, cfg["half"], cfg["step"], P, N)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    pil, idx = pil[0], idx[0]
+    cc = oracle.cell_counts(pts.astype(np.float64), *grid_args(cfg["half"], cfg["step"]))
+    assert cnt[0, 0] == len(cc) and cnt[0, 1] == cc[:, 2].sum()
+    nrow = min(len(cc), P)
+    assert idx[:nrow, 0].all() and not idx[nrow:].any()
+    # row-major order: (row, col) strictly increasing and equal to the first nrow cells
+    assert np.array_equal(idx[:nrow, 1], cc[:nrow, 0]) and np.array_equal(idx[:nrow, 2], cc[:nrow, 1])
+    key = idx[:nrow, 2] * 100000 + idx[:nrow, 1]
+    assert (np.diff(key) > 0).all()
+    # per-pillar live slot count == min(count, N); intensity channel (> 0 a.s.) marks live slots
+    live = (pil[3] != 0).sum(axis=1)
+    assert np.array_equal(live[:nrow], np.minimum(cc[:nrow, 2], N))
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, cfg["half"], cfg["step"])
+    assert _check_exact(pil, idx, ref_p, ref_i)
