@@ -1,0 +1,147 @@
+"""PyTorch-ROCm counterpart of /root/reference model/model.py.
+
+BASELINE.json's north_star keeps the feature net, the pillar->BEV scatter and
+the conv/SSD backbone on PyTorch-ROCm (MIOpen / rocBLAS); the reference's
+``model/model.py`` itself cannot travel to the GPU box, so this file states the
+same network with the same attribute names -- a reference ``state_dict`` loads
+unchanged -- and is pinned by ``tests/golden/model_golden.npz`` (outputs of the
+imported reference module).  Differences, none of them numerical:
+  * canvas size and ConvTranspose ``output_padding`` are constructor
+    arguments instead of the import-time global ``cfg`` (model/model.py:55,122-129);
+  * the scatter never calls ``nonzero`` (a host sync, model/model.py:56): empty
+    pillars are routed to a spill column that is sliced away.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class PPFeatureNet(nn.Module):
+    """model/model.py:13-40: 1x1 conv D->C, ReLU, THEN BatchNorm, max over N."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):                  # [B,D,P,N]
+        x = self.conv1(x)
+        x = F.relu(x)
+        x = self.bn1(x)
+        return torch.max(x, dim=3)[0]      # [B,C,P]
+
+
+class PPScatter(nn.Module):
+    """model/model.py:42-62: ``out[b,:,row,col] = x[b,:,p]`` for flagged pillars.
+    ``inds[b,p] = [flag, col, row]`` (pillars.cpp:390-392)."""
+
+    def __init__(self, canvas_height, canvas_width):
+        super().__init__()
+        self.h, self.w = int(canvas_height), int(canvas_width)
+
+    def forward(self, x, inds):            # x [B,C,P], inds [B,P,3] int64
+        B, C, P = x.shape
+        hw = self.h * self.w
+        lin = inds[:, :, 2] * self.w + inds[:, :, 1]
+        lin = torch.where(inds[:, :, 0] != 0, lin, torch.full_like(lin, hw))
+        out = x.new_zeros((B, C, hw + 1))
+        out.scatter_(2, lin.unsqueeze(1).expand(B, C, P), x)
+        return out[:, :, :hw].reshape(B, C, self.h, self.w)
+
+
+class PPDownBlock(nn.Module):
+    """model/model.py:64-87."""
+
+    def __init__(self, num_layers, in_channels, out_channels):
+        super().__init__()
+        block = [nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1),
+                 nn.ReLU(), nn.BatchNorm2d(out_channels)]
+        for _ in range(num_layers - 1):
+            block += [nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1),
+                      nn.ReLU(), nn.BatchNorm2d(out_channels)]
+        self.block = nn.Sequential(*block)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class PPUpBlock(nn.Module):
+    """model/model.py:89-110."""
+
+    def __init__(self, in_channels, out_channels, stride, padding, output_padding):
+        super().__init__()
+        self.conv2d_t = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=3, stride=stride,
+                                           padding=padding, output_padding=output_padding)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        return self.bn(F.relu(self.conv2d_t(x)))
+
+
+def up3_output_padding(canvas):
+    """output_padding of the stride-4 up block so that it lands on canvas/2
+    (model/model.py:127-129: 500 -> 1, 600 -> 3).  Solves
+    (ceil(canvas/8) - 1)*4 - 2 + 3 + op == canvas/2."""
+    h1 = (canvas + 1) // 2          # each stride-2 conv (k3, p1) maps n -> ceil(n/2)
+    h3 = ((h1 + 1) // 2 + 1) // 2
+    op = h1 - ((h3 - 1) * 4 + 1)
+    if not 0 <= op < 4:
+        raise ValueError(f"canvas {canvas} is not reachable by the stride-4 up block")
+    return op
+
+
+class PPBackbone(nn.Module):
+    """model/model.py:112-141."""
+
+    def __init__(self, in_channels, up3_op=3):
+        super().__init__()
+        c = in_channels
+        self.down1 = PPDownBlock(4, c, c)
+        self.up1 = PPUpBlock(c, 2 * c, 1, 1, 0)
+        self.down2 = PPDownBlock(6, c, 2 * c)
+        self.up2 = PPUpBlock(2 * c, 2 * c, 2, 1, 1)
+        self.down3 = PPDownBlock(6, 2 * c, 4 * c)
+        self.up3 = PPUpBlock(4 * c, 2 * c, 4, 1, up3_op)
+
+    def forward(self, x):
+        x = self.down1(x)
+        out1 = self.up1(x)
+        x = self.down2(x)
+        out2 = self.up2(x)
+        x = self.down3(x)
+        out3 = self.up3(x)
+        return torch.cat((out1, out2, out3), dim=1)
+
+
+class PPDetectionHead(nn.Module):
+    """model/model.py:144-160."""
+
+    def __init__(self, in_channels, cls_out_channels, reg_out_channels):
+        super().__init__()
+        self.cls = nn.Conv2d(in_channels, cls_out_channels, kernel_size=1, stride=1)
+        self.reg = nn.Conv2d(in_channels, reg_out_channels, kernel_size=1, stride=1)
+
+    def forward(self, x):
+        return self.cls(x), self.reg(x)
+
+
+class PPModel(nn.Module):
+    """model/model.py:162-180.  ``forward(x[B,9,P,N], inds[B,P,3]) ->
+    (cls[B,A*9,H/2,W/2], reg[B,A*8,H/2,W/2])``."""
+
+    def __init__(self, feature_net_in_channels, feature_net_out_channels, class_layer_channels,
+                 reg_layer_channels, canvas_height=600, canvas_width=600, up3_op=None):
+        super().__init__()
+        if up3_op is None:
+            up3_op = up3_output_padding(canvas_height)
+        self.feature_net = PPFeatureNet(feature_net_in_channels, feature_net_out_channels)
+        self.scatter = PPScatter(canvas_height, canvas_width)
+        self.backbone = PPBackbone(feature_net_out_channels, up3_op)
+        self.det_head = PPDetectionHead(6 * feature_net_out_channels, class_layer_channels,
+                                        reg_layer_channels)
+
+    def forward(self, x, inds):
+        x = self.feature_net(x)
+        x = self.scatter(x, inds)
+        x = self.backbone(x)
+        return self.det_head(x)

@@ -1,0 +1,70 @@
+"""Device-resident sample pipeline: raw points -> pillars -> network (-> loss).
+
+Counterpart of what /root/reference does per step between the lidar file and
+the loss: ``PPDataset.__getitem__``'s voxel stage and target stage
+(data/dataset.py:88-120) on the HIP kernels, then ``PPModel`` / ``PPLoss``
+(train.py:144-145, evaluate.py:228) on PyTorch-ROCm.  Nothing crosses PCIe
+except the raw points (0.96 MB per 60k-point sweep) and the boxes.
+"""
+import torch
+
+from . import boxes
+from .loss import PPLoss
+from .model import PPModel
+from .targets import TargetAssigner
+from .voxelizer import PillarVoxelizer, VoxelConfig
+
+
+class PillarPipeline:
+    def __init__(self, vox_cfg: VoxelConfig, anchor_cfg: boxes.AnchorConfig = None,
+                 feature_channels=64, num_classes=9, reg_dims=8, device=None, seed=0,
+                 pos_thresh=0.6, with_targets=False):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.vox_cfg = vox_cfg
+        h, w = vox_cfg.canvas_height, vox_cfg.canvas_width
+        if anchor_cfg is None:
+            anchor_cfg = boxes.AnchorConfig(fm_height=(h + 1) // 2, fm_width=(w + 1) // 2)
+        self.anchor_cfg = anchor_cfg
+        self.voxelizer = PillarVoxelizer(vox_cfg, device=self.device)
+        torch.manual_seed(seed)  # model/model.py:9
+        self.model = PPModel(9, feature_channels, anchor_cfg.per_cell * num_classes,
+                             anchor_cfg.per_cell * reg_dims, h, w).to(self.device)
+        self.loss = PPLoss()
+        self.assigner = None
+        if with_targets:
+            self.assigner = TargetAssigner(boxes.make_anchors(anchor_cfg), canvas_height=h,
+                                           pos_thresh=pos_thresh, num_classes=num_classes,
+                                           device=self.device)
+        self._bufs = None
+
+    def _buffers(self, batch):
+        cfg = self.vox_cfg
+        if self._bufs is None or self._bufs[0].shape[0] != batch:
+            self._bufs = (torch.empty((batch, 9, cfg.max_pillars, cfg.max_points_per_pillar),
+                                      dtype=torch.float32, device=self.device),
+                          torch.empty((batch, cfg.max_pillars, 3), dtype=torch.int64, device=self.device))
+        return self._bufs
+
+    def voxelize(self, points, n_points=None):
+        if points.dim() == 2:
+            points = points.unsqueeze(0)
+        return self.voxelizer(points, n_points=n_points, out=self._buffers(points.shape[0]))
+
+    @torch.no_grad()
+    def forward(self, points, n_points=None):
+        """evaluate.py:216-228: voxel stage + network forward (inference)."""
+        pillars, indices = self.voxelize(points, n_points)
+        return self.model(pillars, indices)
+
+    def train_forward_backward(self, points, gts, n_points=None):
+        """train.py:139-147 without the optimizer: voxel stage, target stage, forward,
+        loss, backward.  ``gts`` is a list (one per sweep) of dicts with
+        centers / wlh / yaw / classes in canvas space."""
+        pillars, indices = self.voxelize(points, n_points)
+        targets = [self.assigner.assign(g["centers"], g["wlh"], g["yaw"], g["classes"]) for g in gts]
+        cls_t = torch.stack([t[0] for t in targets])
+        reg_t = torch.stack([t[1] for t in targets])
+        cls, reg = self.model(pillars, indices)
+        p, cls_loss, reg_loss, ort_loss, total = self.loss(cls, reg, cls_t, reg_t)
+        total.backward()
+        return cls_loss.detach(), reg_loss.detach(), ort_loss.detach(), total.detach()

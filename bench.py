@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic sweeps that
+are already resident in HBM: HIP pillar voxelizer -> PPFeatureNet -> scatter ->
+backbone -> detection head (inference forward, f32).  Workload = BASELINE
+configs[1]: 60k-point lidar-like clouds, 500x500 BEV grid, P=12000, N=100, D=9,
+random backbone weights.  Multi-GPU: one process per GPU, every rank owns its
+own sweeps (seed = global sweep id), no data-path collective ("weak" scaling).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     the dominant hand-written kernel (k_emit, the dense [9,P,N] store):
+               algorithmic bytes per launch / its mean duration, timed live with
+               HIP events on the launch stream during the timed steps
+  cpu_baseline the CPU oracle's reference-style voxel stage (hash map of heap
+               nodes + the caller's np.zeros/transpose/.float() glue,
+               data/dataset.py:89-106) timed on this host, 1 core
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import pp_amd  # noqa: E402
+from pp_amd import shard, synth  # noqa: E402
+from pp_amd.pipeline import PillarPipeline  # noqa: E402
+from pp_amd.voxelizer import VoxelConfig  # noqa: E402
+
+METRIC = "lidar sweeps/sec end-to-end fwd (pillarize+backbone), 60k pts, 500×500 BEV"
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md:36
+N_POINTS, HALF, STEP, P, N = 60000, 50.0, 0.2, 12000, 100
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """Reference-style CPU voxel stage (oracle, ORDER_HASH) on one core."""
+    from oracle import oracle as O
+    O.build()
+    pts = synth.lidar_like(N_POINTS, HALF, 0).astype(np.float64)  # dataset.py:82 hands over f64
+    args = (P, N, STEP, STEP, -HALF, -HALF, -10.0, HALF, HALF, 10.0, int(2 * HALF / STEP))
+    for _ in range(2):
+        O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
+    times = []
+    t_end = time.perf_counter() + seconds_budget
+    while time.perf_counter() < t_end or len(times) < 5:
+        t0 = time.perf_counter()
+        O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} calls of the voxel stage only (np.zeros + create_pillars "
+                      f"[reference-style hash map of heap nodes] + transpose + f32 cast, "
+                      f"dataset.py:89-106) on one {N_POINTS}-pt cloud, median {med * 1e3:.1f} ms; "
+                      f"host has {os.cpu_count()} cores; the backbone is not part of this leg"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="sweeps per GPU per step")
+    ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
+                    help="fwd: BASELINE metric (configs[1]); train: configs[2] -- adds HIP target "
+                         "assignment, loss forward/backward and the loss-scalar all-reduce")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    ctx = shard.init_from_env("nccl")
+    if ctx.world_size != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world_size}: launch with "
+                         f"torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(ctx.local_rank)
+    dev = torch.device("cuda", ctx.local_rank)
+    torch.backends.cudnn.benchmark = True  # let MIOpen pick its fastest f32 algorithms
+
+    cfg = VoxelConfig.square(HALF, STEP, P, N)
+    pipe = PillarPipeline(cfg, device=dev, seed=0, with_targets=(a.mode == "train"))
+    pipe.model.eval() if a.mode == "fwd" else pipe.model.train()
+    sweep_ids = [ctx.rank * a.batch + i for i in range(a.batch)]
+    clouds = np.stack([synth.lidar_like(N_POINTS, HALF, s) for s in sweep_ids])
+    points = torch.from_numpy(clouds).to(dev)          # resident in HBM before timing
+    gts = [synth.gt_boxes(40, cfg.canvas_height, s) for s in sweep_ids]
+
+    def step():
+        if a.mode == "fwd":
+            return pipe.forward(points)
+        pipe.model.zero_grad(set_to_none=True)
+        losses = pipe.train_forward_backward(points, gts)
+        return shard.reduce_loss_scalars(ctx, *losses, n_local=a.batch, device=dev)
+
+    for _ in range(a.warmup):
+        step()
+    pipe.voxelizer.set_timing(min(a.steps, 4096))
+    torch.cuda.synchronize()
+    shard.barrier(ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier(ctx)
+    torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(ctx, time.perf_counter() - t0, device=dev)
+    emit_ms = pipe.voxelizer.read_emit_ms(4096)
+    pipe.voxelizer.set_timing(0)
+
+    # voxelizer alone (same resident inputs), for the per-stage picture
+    vox_steps = 200
+    for _ in range(20):
+        pipe.voxelize(points)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(vox_steps):
+        pipe.voxelize(points)
+    torch.cuda.synchronize()
+    vox_dt = (time.perf_counter() - t1) / vox_steps
+
+    if ctx.rank == 0:
+        total_sweeps = a.steps * a.batch * ctx.world_size
+        bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
+        emit_s = float(np.mean(emit_ms)) * 1e-3 if emit_ms else float("nan")
+        achieved = bytes_per_launch / emit_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "emit_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"batch{a.batch}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": METRIC, "value": total_sweeps / elapsed, "unit": "sweeps/s",
+            "n_gpus": ctx.world_size, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: HIP pillarizer + PPFeatureNet + scatter + backbone + "
+                                   "head fwd, 60k-pt lidar-like clouds, 500x500 grid, P=12000 N=100 D=9, "
+                                   "random weights" + ("; configs[2] additions: HIP target assign "
+                                                       "(2 anchors/cell, G=40), loss fwd/bwd, loss-scalar "
+                                                       "all-reduce" if a.mode == "train" else ""),
+                       "mode": a.mode, "sweeps_per_gpu_per_step": a.batch,
+                       "global_batch": a.batch * ctx.world_size,
+                       "voxelizer_arithmetic": "f64 binning/mean, f32 features",
+                       "parallelism": f"1 sweep-shard per GPU x{ctx.world_size}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "pp::k_emit<float,0>", "achieved": achieved,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+                         "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": emit_s * 1e6, "launches_timed": len(emit_ms)},
+            "voxelizer_only": {"sweeps_per_s": a.batch / vox_dt, "us_per_step": vox_dt * 1e6,
+                               "pipeline_GBps": bytes_per_launch / vox_dt / 1e9},
+        }
+        if not a.no_cpu_baseline and ctx.world_size == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    shard.barrier(ctx)
+    shard.shutdown(ctx)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/pp_hip.h declares; without a device the compute entry points fail
+loudly (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported():
+    import pp_amd
+    L = pp_amd._lib.lib()
+    names = declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(L, n), f"libpp_hip.so does not export {n}"
+    assert sorted(pp_amd._lib.EXPORTS) == names
+    assert b"gfx950" in L.pp_version()
+
+
+def test_struct_layout_matches_header():
+    import pp_amd
+    assert ctypes.sizeof(pp_amd._lib.VoxelParams) == 4 + 4 + 9 * 8 + 4 + 4
+    assert ctypes.sizeof(pp_amd._lib.TargetParams) == 8 + 8 + 4 + 4
+    assert pp_amd._lib.VoxelParams.x_step.offset == 8 and pp_amd._lib.VoxelParams.order.offset == 80
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the CPU-only container")
+    import pp_amd
+    from pp_amd import pillars
+    import numpy as np
+    assert pp_amd._lib.lib().pp_device_count() == 0
+    with pytest.raises(pp_amd.PPError, match="no CPU fallback"):
+        pp_amd._lib.Context(0)
+    with pytest.raises(pp_amd.PPError):
+        pillars.create_pillars(np.zeros((3, 4)), np.zeros((2, 2, 9)), np.zeros((2, 3)),
+                               2, 2, 1, 1, 0, 0, 0, 4, 4, 4, 4)
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PillarVoxelizer(VoxelConfig())
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may import,
+    link, include or load it (comments may mention it)."""
+    pkg = os.path.join(ROOT, "3d-object-detection_amd")
+    bad = re.compile(r"^\s*(import\s+oracle|from\s+oracle|from\s+\.+oracle)|libpp_oracle|"
+                     r"#include\s+\"pp_oracle|ppo_[a-z_]+\s*\(|dlopen", re.M)
+    checked = 0
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(src), f"{f} reaches into oracle/"
+                checked += 1
+    assert checked >= 10
+
+
+def test_argument_validation_surface():
+    """Host-side checks that need no device (dtype / shape / writability)."""
+    import numpy as np
+    from pp_amd import pillars
+    with pytest.raises(TypeError):
+        pillars.create_pillars(np.zeros((3, 4)), np.zeros((2, 2, 9), np.float32), np.zeros((2, 3)),
+                               2, 2, 1, 1, 0, 0, 0, 4, 4, 4, 4)
+    ro = np.zeros((2, 3))
+    ro.flags.writeable = False
+    with pytest.raises(TypeError):
+        pillars.create_pillars(np.zeros((3, 4)), np.zeros((2, 2, 9)), ro, 2, 2, 1, 1, 0, 0, 0, 4, 4, 4, 4)
+    with pytest.raises(IndexError):
+        pillars.create_pillars(np.zeros((3, 3)), np.zeros((2, 2, 9)), np.zeros((2, 3)),
+                               2, 2, 1, 1, 0, 0, 0, 4, 4, 4, 4)
+    with pytest.raises(IndexError):
+        pillars.create_pillars(np.zeros((3, 4)), np.zeros((2, 18)), np.zeros((2, 3)),
+                               2, 2, 1, 1, 0, 0, 0, 4, 4, 4, 4)
+    with pytest.raises(IndexError):
+        pillars.make_ious(np.zeros((5, 4, 2)), np.zeros((2, 4, 2)), np.zeros((5, 3)), np.zeros((2, 3)),
+                          np.zeros((4, 2)))
+    assert pillars.create_pillars.__doc__.startswith("pillars") and pillars.make_ious.__doc__.startswith("ious")
+    assert pillars.__doc__.startswith("point pillars data prep functions")   # pillars.cpp:431-433

@@ -1,0 +1,115 @@
+"""GPU parity tests of the rotated-IoU and fused anchor-target kernels against
+the CPU oracle (create_target, utils/box_utils.py:162-232).
+
+Bar: IoU bit-exact (same f64 operation sequence, contraction off); class targets
+exact (integer work); regression targets within 1e-6 of the f32-cast oracle
+(log/sin come from different libms)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REG_TOL = 1e-6
+
+
+def _oracle_targets(O, anchors, gt, H, thresh=0.6):
+    c_img, k_img = O.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
+    return O.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                           anchors["yaw"], gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], H,
+                           pos_thresh=thresh)
+
+
+def _check(cls_t, reg_t, ref_c, ref_r):
+    cls_t, reg_t = cls_t.cpu().numpy(), reg_t.cpu().numpy()
+    assert np.array_equal(cls_t, ref_c.astype(np.float32)), "class targets differ"
+    assert np.array_equal(reg_t[:, 0], ref_r[:, 0].astype(np.float32)), "positive flags differ"
+    assert np.array_equal(reg_t[:, 8], ref_r[:, 8].astype(np.float32)), "orientation bits differ"
+    assert np.abs(reg_t - ref_r.astype(np.float32)).max() <= REG_TOL
+
+
+def test_config3_full_size(gpu, oracle):
+    """BASELINE config 3: 250x250 feature map x 2 anchors = 125 000 anchors, G = 40."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    anchors = boxes.make_anchors(boxes.AnchorConfig(250, 250))
+    assert len(anchors["corners"]) == 125000
+    ta = TargetAssigner(anchors, canvas_height=500, device=gpu)
+    for seed in (0, 1):
+        gt = synth.gt_boxes(40, 500, seed)
+        cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+        torch.cuda.synchronize()
+        ref_c, ref_r, ious = _oracle_targets(oracle, anchors, gt, 500)
+        assert (ref_r[:, 0] == 1).sum() > 40            # there are positives beyond the forced ones
+        _check(cls_t, reg_t, ref_c, ref_r)
+        # dense IoU matrix on the device: bit-exact
+        c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 500)
+        d = ta.ious(k_img, c_img).cpu().numpy()
+        assert np.array_equal(d, ious)
+
+
+def test_reference_default_anchor_set_sampled(gpu, oracle):
+    """config.py default: 6 anchors/cell (3 sizes x 2 yaws); 120x120 map keeps the oracle quick."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    ref = boxes.AnchorConfig.reference_default()
+    cfg = boxes.AnchorConfig(120, 120, 0.5, ref.dims, ref.yaws_deg, ref.zs)
+    anchors = boxes.make_anchors(cfg)
+    ta = TargetAssigner(anchors, canvas_height=240, device=gpu)
+    gt = synth.gt_boxes(25, 240, 7, margin=20.0)
+    gt["wlh"][::3, :2] = [4.0, 8.0]                    # some small boxes too
+    cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+    torch.cuda.synchronize()
+    ref_c, ref_r, _ = _oracle_targets(oracle, anchors, gt, 240)
+    _check(cls_t, reg_t, ref_c, ref_r)
+
+
+def test_quirks_anchor0_duplicates_ties_threshold(gpu, oracle):
+    """a ground truth whose best anchor is index 0 is dropped; two
+    ground truths sharing one best anchor set both classes, last regression row
+    wins; exact IoU ties resolve to the first index; IoU == threshold is not positive."""
+    import torch
+    from pp_amd.targets import TargetAssigner
+    O = oracle
+    xs = [20.0, 60.0, 63.0, 100.0, 140.0, 148.0]
+    centers = np.array([[x, 20.0, 0.5] for x in xs])
+    wlh = np.tile([4.0, 8.0, 1.5], (len(xs), 1))
+    yaw = np.zeros(len(xs))
+    anchors = {"corners": O.box_bottom_corners_xy(centers, wlh, yaw), "centers": centers,
+               "wlh": wlh, "yaw": yaw}
+    H = 41
+    gt = {"centers": np.array([[23.5, 20, .7],      # best anchor is index 0 -> dropped
+                               [102.5, 20, .7], [97.5, 20, .7],   # both forced onto anchor 3
+                               [144.0, 20, .7],     # exact tie between anchors 4 and 5 -> first
+                               [60.0, 20, .7]]),    # exact match of anchor 1, overlaps anchor 2
+          "wlh": np.tile([4.0, 8.0, 1.6], (5, 1)), "yaw": np.zeros(5),
+          "classes": np.array([2, 1, 6, 4, 8], np.int32)}
+    ta = TargetAssigner(anchors, canvas_height=H, device=gpu)
+    cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+    torch.cuda.synchronize()
+    ref_c, ref_r, ious = _oracle_targets(O, anchors, gt, H)
+    assert ious[4, 3] == ious[5, 3] > 0 and not ref_c[0].any()
+    assert ref_c[3].tolist() == [0, 1, 0, 0, 0, 0, 1, 0, 0] and ref_c[4, 4] == 1 and not ref_c[5].any()
+    _check(cls_t, reg_t, ref_c, ref_r)
+    thr = float(ious[2, 4])                            # IoU exactly at the threshold
+    ta2 = TargetAssigner(anchors, canvas_height=H, pos_thresh=thr, device=gpu)
+    cls2, reg2 = ta2.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"])
+    ref_c2, ref_r2, _ = _oracle_targets(O, anchors, gt, H, thresh=thr)
+    assert not ref_c2[2].any()
+    _check(cls2, reg2, ref_c2, ref_r2)
+
+
+def test_no_ground_truth_and_wrong_winding(gpu, oracle):
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    anchors = boxes.make_anchors(boxes.AnchorConfig(20, 20))
+    ta = TargetAssigner(anchors, canvas_height=40, device=gpu)
+    cls_t, reg_t = ta.assign(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0), np.zeros(0, np.int32), check=True)
+    assert not cls_t.any() and not reg_t.any()
+    # ground truth handed over counter-clockwise (not flipped): raises, never exits
+    c = np.array([[20.0, 20.0, 0.5]])
+    k = boxes.bottom_corners_xy(c, np.array([[10.0, 25.0, 1.7]]), np.array([0.2]))
+    with pytest.raises(ValueError):
+        ta.ious(k, c)
+    torch.cuda.synchronize()

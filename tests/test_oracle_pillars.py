@@ -1,0 +1,120 @@
+"""Pins the CPU oracle of create_pillars against the behavioural probes recorded
+in SURVEY.md 5.9 / 8c (the reference ships no tests or fixtures of its own)."""
+import numpy as np
+import pytest
+
+from util import grid_args
+
+
+def v1_points():
+    return np.array([[1.1, 2.1, 0.0, 10], [0.5, 0.5, 0, 1], [1.2, 2.2, 0.1, 11], [1.3, 2.3, 0.2, 12],
+                     [4.0, 1, 0, 0], [1, 1, 1.0, 0], [-0.001, 1, 0, 0], [1.5, 2.5, 0.3, 13],
+                     [0.25, 0.75, 0.5, 2], [1.8, 2.8, 0.4, 14]])
+
+
+V1_ARGS = (3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4)   # N=3, P=4, 4x4 canvas, z in [-1,1)
+
+
+def test_v1_hand_case(oracle):
+    """5 points in cell (1,2), 2 in (0,0), 3 rejects, N=3."""
+    T, I = np.zeros((4, 3, 9)), np.zeros((4, 3))
+    m = oracle.create_pillars(v1_points(), T, I, *V1_ARGS)
+    assert m == 2
+    # row-major order: (col 1,row 1) before (col 0,row 3); y is flipped into rows
+    assert I.tolist() == [[1, 1, 1], [1, 0, 3], [0, 0, 0], [0, 0, 0]]
+    # the row printed by the survey probe; means are over all 5 points, not the first 3
+    assert np.allclose(T[0, 0], [1.1, 2.1, 0, 10, -0.1, -1.1, 0.28, 0.28, 0.2], atol=1e-12)
+    assert np.allclose(T[0, :, 0], [1.1, 1.2, 1.3]) and np.allclose(T[0, :, 3], [10, 11, 12])
+    # SURVEY 5.9-7 probe: pt (0.5,0.5) on a 4-row canvas -> yp = 3 - 0.5 = 2.5
+    assert T[1, 0, 5] == 2.5 and T[1, 0, 4] == -0.5
+    assert not T[1, 2].any() and not T[2:].any()
+
+
+def test_running_mean_is_sequential_not_two_pass(oracle):
+    """pillars.cpp:311-328: m <- m*(n/(n+1)) + v/(n+1) in input order."""
+    rng = np.random.default_rng(0)
+    pts = np.zeros((50, 4))
+    pts[:, :3] = 0.5 + rng.random((50, 3)) * 0.4
+    T, I = np.zeros((1, 50, 9)), np.zeros((1, 3))
+    oracle.create_pillars(pts, T, I, 50, 1, 1, 1, 0, 0, 0, 4, 4, 4, 4)
+    m = pts[0, :3].copy()
+    for n in range(1, 50):
+        m = m * (n / (n + 1)) + pts[n, :3] / (n + 1)
+    assert np.array_equal(T[0, :, 6:9], m[None, :] - pts[:, :3])     # bit-exact
+
+
+def test_half_open_boundaries(oracle):
+    """x_min <= x < x_max on every axis."""
+    e = np.nextafter
+    pts = np.array([[0.0, 1, 0, 1], [e(4.0, 0), 1, 0, 2], [4.0, 1, 0, 3], [1, 0.0, 0, 4], [1, 4.0, 0, 5],
+                    [1, 1, -1.0, 6], [1, 1, 1.0, 7], [1, 1, e(1.0, 0), 8]])
+    T, I = np.zeros((8, 4, 9)), np.zeros((8, 3))
+    m = oracle.create_pillars(pts, T, I, 4, 8, 1, 1, 0, 0, -1, 4, 4, 1, 4)
+    kept = sorted(T[..., 3][T[..., 3] != 0].tolist())
+    assert kept == [1, 2, 4, 6, 8] and m == 4
+
+
+def test_never_zeroes_and_partial_write_on_index_error(oracle):
+    T, I = np.full((4, 3, 9), 9.0), np.full((4, 3), 9.0)
+    oracle.create_pillars(v1_points(), T, I, *V1_ARGS)
+    assert (T[1, 2] == 9.0).all() and (T[2:] == 9.0).all() and (I[2:] == 9.0).all()
+    T, I = np.zeros((1, 3, 9)), np.zeros((4, 3))
+    with pytest.raises(IndexError):
+        oracle.create_pillars(v1_points(), T, I, *V1_ARGS)
+    assert T[0].any() and I[0].tolist() == [1, 1, 1] and not I[1:].any()
+
+
+def test_non_f64_outputs_rejected_and_strided_inputs(oracle):
+    with pytest.raises(TypeError):
+        oracle.create_pillars(v1_points(), np.zeros((4, 3, 9), np.float32), np.zeros((4, 3)), *V1_ARGS)
+    pts = np.asfortranarray(v1_points())              # F-order, like dataset.py:88
+    big = np.zeros((4, 3, 18))
+    T, I = big[..., ::2], np.zeros((4, 3))
+    oracle.create_pillars(pts, T, I, *V1_ARGS)
+    Tr, Ir = np.zeros((4, 3, 9)), np.zeros((4, 3))
+    oracle.create_pillars(v1_points(), Tr, Ir, *V1_ARGS)
+    assert np.array_equal(T, Tr) and np.array_equal(I, Ir) and not big[..., 1::2].any()
+
+
+def test_orders_agree_as_sets_and_overflow_subset_rule(oracle):
+    """Same pillar contents whatever the emission order; under overflow every
+    emitted pillar equals the uncapped pillar of that cell (SURVEY 7 hard part 1)."""
+    import pp_amd.synth as synth
+    from util import pillars_by_cell
+    pts = synth.lidar_like(6000, 8.0, 1).astype(np.float64)
+    g = grid_args(8.0, 0.2)
+    outs = {}
+    for order in (oracle.ORDER_ROW_MAJOR, oracle.ORDER_SCRAMBLED, oracle.ORDER_HASH):
+        p, i, m = oracle.dataset_voxel_stage(pts, 6000, 16, *g, order=order)
+        outs[order] = pillars_by_cell(p, i)
+        assert len(outs[order]) == m
+    ref = outs[oracle.ORDER_ROW_MAJOR]
+    for order, d in outs.items():
+        assert d.keys() == ref.keys()
+        assert all(np.array_equal(d[k], ref[k]) for k in ref)
+    cc = oracle.cell_counts(pts, *g)
+    assert len(cc) == len(ref)
+    assert np.minimum(cc[:, 2], 16).sum() == sum(int((v[3] != 0).sum()) for v in ref.values())
+    for order in (oracle.ORDER_ROW_MAJOR, oracle.ORDER_SCRAMBLED, oracle.ORDER_HASH):
+        p, i, m = oracle.dataset_voxel_stage(pts, 500, 16, *g, order=order)
+        capped = pillars_by_cell(p, i)
+        assert len(capped) == 500 and m == len(ref)
+        assert all(np.array_equal(v, ref[k]) for k, v in capped.items())
+    # row-major keeps the first P cells in (row, col) order
+    p, i, m = oracle.dataset_voxel_stage(pts, 500, 16, *g)
+    assert np.array_equal(i[:, 1:], cc[:500, :2])
+
+
+def test_scramble_mult_is_a_bijection(oracle):
+    from math import gcd
+    for n in (1, 2, 3, 10, 10201, 251001, 1002001):
+        m = oracle.scramble_mult(n)
+        assert gcd(m, n) == 1 or n <= 2
+
+
+def test_grid_dims_bound(oracle):
+    nx, ny = oracle.grid_dims(.2, .2, -60, -60, 60, 60)
+    assert nx >= 600 and ny >= 600
+    assert np.floor((np.nextafter(60.0, 0) - -60) / .2) < nx
+    with pytest.raises(ValueError):
+        oracle.grid_dims(0, .2, -60, -60, 60, 60)

@@ -1,0 +1,62 @@
+"""world_size-2 test of the multi-process path on CPU (gloo): sweep sharding,
+the loss-scalar all-reduce and the max-over-ranks timing reduction."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from pp_amd import shard
+    ctx = shard.init_from_env("gloo")
+    mine = shard.sweeps_for_rank(5, ctx.rank, ctx.world_size)
+    # per-rank "losses": functions of the owned sweep ids
+    vals = [float(sum(mine)) + k for k in range(4)]
+    red = shard.reduce_loss_scalars(ctx, *vals, n_local=len(mine))
+    tmax = shard.max_over_ranks(ctx, 1.0 + rank)
+    shard.barrier(ctx)
+    q.put((rank, mine, red.tolist(), tmax))
+    shard.shutdown(ctx)
+
+
+def test_two_rank_shard_and_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4]
+    # sweep-weighted mean: (3*(3+k) + 2*(7+k)) / 5
+    exp = [(3 * (3 + k) + 2 * (7 + k)) / 5 for k in range(4)]
+    for r in res:
+        assert torch.allclose(torch.tensor(r[2]), torch.tensor(exp), atol=1e-6)
+        assert r[3] == 2.0
+
+
+def test_single_process_is_world_one(monkeypatch):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    from pp_amd import shard
+    ctx = shard.init_from_env("gloo")
+    assert (ctx.rank, ctx.world_size, ctx.distributed) == (0, 1, False)
+    red = shard.reduce_loss_scalars(ctx, 1.0, 2.0, 3.0, 4.0, n_local=2)
+    assert red.tolist() == [1.0, 2.0, 3.0, 4.0] and shard.max_over_ranks(ctx, 0.5) == 0.5
