@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libpp_hip.so")
+LIB_PATH = os.environ.get("PP_HIP_LIB") or os.path.join(_HERE, "libpp_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f)
            for f in ("pp_runtime.hip", "pp_voxelize.hip", "pp_iou.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "pp_common.h"), os.path.join(_ROOT, "include", "pp_hip.h")]

@@ -6,18 +6,23 @@
 //
 // Pipeline (one launch each, grid.y = sweep of the batch):
 //   k_bin_count  point -> cell slot (f64 true division + floor, half-open range
-//                test: pillars.cpp:271-280), per-cell population count
+//                test: pillars.cpp:271-280); ONE returning atomic per point gives
+//                the per-cell population and the point's arrival rank
 //   k_scan       single-pass decoupled-look-back scan over the cell grid:
 //                pillar index of every non-empty cell (P-index compaction) and
-//                CSR offset of its bucket; the count array becomes the cursor
-//   k_fill       CSR bucket fill (point index lists per cell)
-//   k_emit       one wave per 4 consecutive pillars: LDS-staged buckets, input
-//                order restored, sequential running mean (pillars.cpp:311-328),
-//                N-cap, 9 features (pillars.cpp:30-31,48-56,381-383), dense
-//                [9,P,N] f32 store incl. the zero padding, [P,3] int64 indices
+//                CSR offset of its bucket, written in place of the counts
+//   k_fill       atomic-free CSR fill: point record + point index go to
+//                bucket start + arrival rank
+//   k_emit       one wave per 4 consecutive pillars: coalesced bucket read,
+//                LDS-staged, input order restored, sequential running mean
+//                (pillars.cpp:311-328), N-cap, 9 features (pillars.cpp:30-31,
+//                48-56,381-383), dense [9,P,N] f32 store incl. the zero padding,
+//                [P,3] int64 indices
 //
 // The path is HBM-bound: 97% of the bytes are the dense store of
-// k_emit, issued as 16-byte stores that each touch a byte exactly once.
+// k_emit.  Every 128-byte line of the output is written once, whole: lines
+// without live points are zero-filled before the bucket data arrives, lines
+// with live points are written (data + zero tail) after it.
 // All arithmetic that decides a value is f64 with contraction disabled
 // (-ffp-contract=off), matching the reference's x86-64 build.
 
@@ -35,7 +40,7 @@ namespace pp {
 // ------------------------------------------------------------------------- //
 constexpr int kWave = 64;
 constexpr int kBinThreads = 256;
-constexpr int kScanThreads = 256;
+constexpr int kScanThreads = 1024;
 constexpr int kScanTile = kScanThreads * 4;  // cells per scan workgroup
 constexpr int kEmitWaves = 4;                // waves per emit workgroup
 constexpr int kEmitThreads = kEmitWaves * kWave;
@@ -128,7 +133,7 @@ __device__ __forceinline__ int point_cell(double x, double y, double z,
 template <typename T>
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(
     const T *__restrict__ pts, int64_t sweep_stride, int64_t s0, int64_t s1,
-    int contig, NPoints np, GridGeom g, int *__restrict__ cell_of, int ncap,
+    int contig, NPoints np, GridGeom g, int2 *__restrict__ cell_rank, int ncap,
     int *__restrict__ cursor) {
   const int b = blockIdx.y;
   const int n = np.n[b];
@@ -137,12 +142,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(
   T x, y, z, r;
   load_point<T>(pts + (int64_t)b * sweep_stride * 4, i, s0, s1, contig != 0, x, y, z, r);
   const int cell = point_cell((double)x, (double)y, (double)z, g);
-  int slot = -1;
+  int slot = -1, rank = 0;
   if (cell >= 0) {
     slot = cell_to_slot(cell, g);
-    atomicAdd(&cursor[(int64_t)b * g.ncells_pad + slot], 1);  // no return value used
+    // the only atomic of the pipeline: population count + arrival rank in one
+    rank = atomicAdd(&cursor[(int64_t)b * g.ncells_pad + slot], 1);
   }
-  cell_of[(int64_t)b * ncap + i] = slot;
+  cell_rank[(int64_t)b * ncap + i] = make_int2(slot, rank);
 }
 
 // ------------------------------------------------------------------------- //
@@ -265,12 +271,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(
 }
 
 // ------------------------------------------------------------------------- //
-// k_fill: CSR bucket fill; also re-arms the scan's ticket/status words        //
+// k_fill: atomic-free CSR fill; also re-arms the scan's ticket/status words   //
 // ------------------------------------------------------------------------- //
+template <typename T> struct Rec4;
+template <> struct Rec4<float> { using type = float4; };
+template <> struct Rec4<double> { using type = double4; };
+
+template <typename T>
 __global__ __launch_bounds__(kBinThreads) void k_fill(
-    const int *__restrict__ cell_of, int ncap, NPoints np, int *__restrict__ cursor,
-    int ncells_pad, int *__restrict__ bucket, u64 *status, int nwg_scan,
-    unsigned *ticket) {
+    const T *__restrict__ pts, int64_t sweep_stride, const int2 *__restrict__ cell_rank,
+    int ncap, NPoints np, const int *__restrict__ cursor, int ncells_pad,
+    typename Rec4<T>::type *__restrict__ sorted_pts, int *__restrict__ sorted_idx,
+    u64 *status, int nwg_scan, unsigned *ticket) {
   const int b = blockIdx.y;
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < nwg_scan; i += kBinThreads)
@@ -279,10 +291,13 @@ __global__ __launch_bounds__(kBinThreads) void k_fill(
   }
   const int i = blockIdx.x * kBinThreads + threadIdx.x;
   if (i >= np.n[b]) return;
-  const int slot = cell_of[(int64_t)b * ncap + i];
-  if (slot < 0) return;
-  const int pos = atomicAdd(&cursor[(int64_t)b * ncells_pad + slot], 1);
-  bucket[(int64_t)b * ncap + pos] = i;
+  const int2 cr = cell_rank[(int64_t)b * ncap + i];
+  if (cr.x < 0) return;
+  const typename Rec4<T>::type rec =
+      reinterpret_cast<const typename Rec4<T>::type *>(pts + (int64_t)b * sweep_stride * 4)[i];
+  const int pos = cursor[(int64_t)b * ncells_pad + cr.x] + cr.y;  // bucket start + arrival rank
+  sorted_pts[(int64_t)b * ncap + pos] = rec;
+  sorted_idx[(int64_t)b * ncap + pos] = i;
 }
 
 // ------------------------------------------------------------------------- //
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(kBinThreads) void k_fill(
 // ------------------------------------------------------------------------- //
 template <typename TIn>
 struct WaveLds {
-  int idx[CAPW];                        // bucket entries as fetched (unordered)
+  int idx[CAPW];                               // point indices as stored by k_fill (arrival order)
   TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar
   union {
     struct {
@@ -300,7 +315,7 @@ struct WaveLds {
     float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense mode), aliases c
   } u;
   double mean[KW][3];
-  int cnt[KW], live[KW], segbeg[KW], slot[KW], start[KW];
+  int cnt[KW], live[KW], slot[KW], start[KW];
 };
 
 struct EmitArgs {
@@ -309,13 +324,14 @@ struct EmitArgs {
   int P, N, ncap;
   const int4 *pillar_meta;  // [B][P] {slot, start, count, -}
   const int2 *totals;       // [B]    {cells, points}
-  const int *bucket;        // [B][ncap]
-  const int *cell_of;       // [B][ncap]
+  const int *sorted_idx;    // [B][ncap] point index, CSR (bucket) order
+  const void *sorted_pts;   // [B][ncap] point record (x,y,z,r), CSR order
+  const int2 *cell_rank;    // [B][ncap] {slot, arrival rank} per input point
   int *cursor;              // [B][ncells_pad], zeroed here for the next call
   const void *pts;          // [B][sweep_stride][4] (contiguous rows)
   int64_t sweep_stride;
   // dense mode
-  float *out;        // [B][9][P][N]
+  float *out;          // [B][9][P][N]
   long long *idx_out;  // [B][P][3]
   // compact mode
   double *feat_out;  // [B][ncap][9]
@@ -357,13 +373,13 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
   const int slot = L.slot[k];
   const int nb = a.np.n[b];
   const TIn *pts = reinterpret_cast<const TIn *>(a.pts) + (int64_t)b * a.sweep_stride * 4;
-  const int *cell_of = a.cell_of + (int64_t)b * a.ncap;
+  const int2 *cell_rank = a.cell_rank + (int64_t)b * a.ncap;
   const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   double m0 = 0, m1 = 0, m2 = 0;
   int seen = 0;
   for (int base = 0; base < nb; base += kWave) {
     const int i = base + lane;
-    const bool match = (i < nb) && (cell_of[i] == slot);
+    const bool match = (i < nb) && (cell_rank[i].x == slot);
     const u64 mask = __ballot(match);
     if (!mask) continue;
     const int rank = __popcll(mask & lt_mask);
@@ -404,7 +420,7 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
   seen = 0;
   for (int base = 0; base < nb && seen < N; base += kWave) {
     const int i = base + lane;
-    const bool match = (i < nb) && (cell_of[i] == slot);
+    const bool match = (i < nb) && (cell_rank[i].x == slot);
     const u64 mask = __ballot(match);
     if (!mask) continue;
     const int n = seen + __popcll(mask & lt_mask);
@@ -436,52 +452,49 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
   }
 }
 
-// Pillars [kbeg,kend) of this wave, pooled in LDS (their buckets total <= CAPW).
+// Pooled pillars [kbeg,kend) of this wave: entries j (pooled bucket position)
+// were prefetched by the caller into registers (idx0/rec0 for j = lane, idx1/rec1
+// for j = lane + 64) straight from the CSR arrays.  Leaves the f32 features of
+// the live points in L.u.feat (dense vec4 mode) or stores them (other modes).
 template <typename TIn, int MODE>
-__device__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0, int kbeg,
-                           int kend, int lane) {
-  const TIn *pts = reinterpret_cast<const TIn *>(a.pts) + (int64_t)b * a.sweep_stride * 4;
-  const int *bucket = a.bucket + (int64_t)b * a.ncap;
+__device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0,
+                                           int kbeg, int kend, int lane, int idx0,
+                                           typename Rec4<TIn>::type rec0, int idx1,
+                                           typename Rec4<TIn>::type rec1, int segbeg[KW],
+                                           int cntk[KW], int T) {
   const int N = a.N;
-  int segbeg[KW], cntk[KW];
-  int T = 0;
-#pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    const bool in = (k >= kbeg && k < kend);
-    cntk[k] = in ? L.cnt[k] : 0;
-    segbeg[k] = T;
-    T += cntk[k];
-  }
-  if (T == 0) return;
-  const int start0 = L.start[kbeg];  // CSR ranges of consecutive pillars are contiguous
-  for (int j = lane; j < T; j += kWave) L.idx[j] = bucket[start0 + j];
+  if (lane < T) L.idx[lane] = idx0;
+  if (lane + kWave < T) L.idx[lane + kWave] = idx1;
   wave_sync();
   // restore input order: rank of every entry inside its bucket (counts are small)
-  for (int j = lane; j < T; j += kWave) {
-    int k = 0;
 #pragma unroll
-    for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
-    int sb = 0, sc = 0;
+  for (int it = 0; it < CAPW / kWave; ++it) {
+    const int j = lane + it * kWave;
+    if (j < T) {
+      int k = 0;
 #pragma unroll
-    for (int kk = 0; kk < KW; ++kk) {
-      sb = (k == kk) ? segbeg[kk] : sb;
-      sc = (k == kk) ? cntk[kk] : sc;
+      for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
+      int sb = 0, sc = 0;
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+        sb = (k == kk) ? segbeg[kk] : sb;
+        sc = (k == kk) ? cntk[kk] : sc;
+      }
+      const int my = it == 0 ? idx0 : idx1;
+      const typename Rec4<TIn>::type rec = it == 0 ? rec0 : rec1;
+      int r = 0;
+      for (int jj = sb; jj < sb + sc; ++jj) r += (L.idx[jj] < my) ? 1 : 0;
+      const int pos = sb + r;
+      L.px[pos] = rec.x;
+      L.py[pos] = rec.y;
+      L.pz[pos] = rec.z;
+      L.pr[pos] = rec.w;
+      const double n = (double)r, den = n + 1;
+      L.u.c.ratio[pos] = n / den;             // pillars.cpp:322-326: n/(n+1)
+      L.u.c.q[0][pos] = (double)rec.x / den;  //                       v/(n+1)
+      L.u.c.q[1][pos] = (double)rec.y / den;
+      L.u.c.q[2][pos] = (double)rec.z / den;
     }
-    const int my = L.idx[j];
-    int r = 0;
-    for (int jj = sb; jj < sb + sc; ++jj) r += (L.idx[jj] < my) ? 1 : 0;
-    const int pos = sb + r;
-    TIn x, y, z, rr;
-    load_point<TIn>(pts, my, 4, 1, true, x, y, z, rr);
-    L.px[pos] = x;
-    L.py[pos] = y;
-    L.pz[pos] = z;
-    L.pr[pos] = rr;
-    const double n = (double)r, den = n + 1;
-    L.u.c.ratio[pos] = n / den;            // pillars.cpp:322-326: n/(n+1)
-    L.u.c.q[0][pos] = (double)x / den;     //                       v/(n+1)
-    L.u.c.q[1][pos] = (double)y / den;
-    L.u.c.q[2][pos] = (double)z / den;
   }
   wave_sync();
   // sequential running mean per pillar, pillars.cpp:311-328 (one lane each)
@@ -509,7 +522,11 @@ __device__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0, in
   // features of the first min(count, N) points of every pillar.  The f32
   // staging array aliases the (now dead) chain operands.
   float *outb = a.out + (int64_t)b * 9 * a.P * N;
-  for (int j = lane; j < T; j += kWave) {
+  const int start0 = L.start[kbeg];
+#pragma unroll
+  for (int it = 0; it < CAPW / kWave; ++it) {
+    const int j = lane + it * kWave;
+    if (j >= T) continue;
     int k = 0;
 #pragma unroll
     for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
@@ -537,50 +554,125 @@ __device__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0, in
       }
     }
   }
-  if (MODE == kModeDenseVec4) {
-    wave_sync();
-    // "head" 16-byte groups: the groups of a pillar row that hold live points
-    // (the live prefix plus, in the last group, its zero tail).
-    int hbeg[KW], nh[KW], livek[KW];
-    int H = 0;
+  wave_sync();
+}
+
+// Dense vec4 mode.  The wave owns, per feature d, one contiguous slab of
+// kw_eff*N floats (rowf4 16-byte groups); group `rem` of the slab of feature d
+// is group g4 = (d*P + p0)*N4 + rem of the sweep's output, line = g4 >> 3 (128 B).
+// A line is "late" when it holds a live point of a POOLED pillar: late lines are
+// written whole -- data + zeros -- once the features are in LDS; every other
+// line is zero-filled early, before the bucket data has arrived.  The decision
+// depends on `rem` only (not on d) when P*N4 is a multiple of 8 groups, which
+// lets one decision drive nine back-to-back stores; otherwise the unit of
+// deferral falls back from the line to the 16-byte group.  For a non-pooled
+// (big) pillar only its head groups are skipped; emit_big_pillar writes those.
+struct SlabGeom {
+  unsigned rowf4, N4, magic_n4;
+  int nh[KW];       // head groups (ceil(live/4)) per pillar
+  unsigned pooled;  // bit k: pillar k's features are (will be) in L.u.feat
+  bool aligned;     // (P*N4) % 8 == 0: same line phase for every feature
+  unsigned H4;      // groups >= H4 of every row were zero-filled speculatively
+};
+
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned d, unsigned magic) {
+  return d == 1u ? n : __umulhi(n, magic);  // magic = floor((2^32-1)/d)+1, exact for n*d < 2^32
+}
+
+template <bool LATE, typename TIn>
+__device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom &sg,
+                                           float4 *__restrict__ out4, int64_t P, int p0,
+                                           int lane, const int segbeg[KW]) {
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t PN4 = P * (int64_t)sg.N4;
+  const unsigned base0 = (unsigned)((int64_t)p0 * sg.N4);
+  float4 *o0 = out4 + (int64_t)p0 * sg.N4;
+  for (unsigned rem = lane; rem < sg.rowf4; rem += kWave) {
+    const unsigned k = fastdiv(rem, sg.N4, sg.magic_n4);
+    const unsigned n4 = rem - k * sg.N4;
+    int nhk = 0, sb = 0;
+    bool pooled_k = false;
 #pragma unroll
-    for (int k = 0; k < KW; ++k) {
-      livek[k] = min(cntk[k], N);
-      nh[k] = (livek[k] + 3) >> 2;
-      hbeg[k] = H;
-      H += nh[k];
+    for (int kk = 0; kk < KW; ++kk) {
+      nhk = (k == (unsigned)kk) ? sg.nh[kk] : nhk;
+      sb = (k == (unsigned)kk) ? segbeg[kk] : sb;
+      pooled_k = (k == (unsigned)kk) ? (((sg.pooled >> kk) & 1u) != 0) : pooled_k;
     }
-    const int N4 = N >> 2;
-    float4 *out4 = reinterpret_cast<float4 *>(outb);
-    for (int it = lane; it < H * 9; it += kWave) {
-      const int d = it / H, h = it - d * H;
-      int k = 0;
-#pragma unroll
-      for (int kk = 1; kk < KW; ++kk) k = (h >= hbeg[kk] && nh[kk] > 0) ? kk : k;
-      int hb = 0, lv = 0, sb = 0;
+    const bool head = (int)n4 < nhk;
+    bool late = head && pooled_k;
+    if (sg.aligned) {
+      const unsigned line = (base0 + rem) >> 3;
 #pragma unroll
       for (int kk = 0; kk < KW; ++kk) {
-        hb = (k == kk) ? hbeg[kk] : hb;
-        lv = (k == kk) ? livek[kk] : lv;
-        sb = (k == kk) ? segbeg[kk] : sb;
+        const unsigned lo = (base0 + (unsigned)kk * sg.N4) >> 3;
+        const unsigned hi = (base0 + (unsigned)kk * sg.N4 + (unsigned)max(sg.nh[kk], 1) - 1u) >> 3;
+        late = late || (((sg.pooled >> kk) & 1u) && sg.nh[kk] > 0 && line >= lo && line <= hi);
       }
-      const int hh = h - hb;
-      const int j0 = sb + 4 * hh;
-      const float *fr = L.u.feat[d];
-      float4 v;
-      v.x = (4 * hh + 0 < lv) ? fr[min(j0 + 0, CAPW - 1)] : 0.0f;
-      v.y = (4 * hh + 1 < lv) ? fr[min(j0 + 1, CAPW - 1)] : 0.0f;
-      v.z = (4 * hh + 2 < lv) ? fr[min(j0 + 2, CAPW - 1)] : 0.0f;
-      v.w = (4 * hh + 3 < lv) ? fr[min(j0 + 3, CAPW - 1)] : 0.0f;
-      out4[((int64_t)d * a.P + (p0 + k)) * N4 + hh] = v;
     }
-    wave_sync();
+    if (!LATE) {
+      if (!late && !head && n4 < sg.H4) {
+#pragma unroll
+        for (int d = 0; d < PP_NUM_FEATURES; ++d) o0[d * PN4 + rem] = z4;
+      }
+    } else if (late && (head ? pooled_k : n4 < sg.H4)) {
+      if (head) {
+        const int lv = L.live[k];
+        const int j0 = sb + 4 * (int)n4;
+        const int j1 = min(j0 + 1, CAPW - 1), j2 = min(j0 + 2, CAPW - 1), j3 = min(j0 + 3, CAPW - 1);
+        const bool h1 = 4 * (int)n4 + 1 < lv, h2 = 4 * (int)n4 + 2 < lv, h3 = 4 * (int)n4 + 3 < lv;
+#pragma unroll
+        for (int d = 0; d < PP_NUM_FEATURES; ++d) {
+          const float *fr = L.u.feat[d];
+          float4 v;
+          v.x = fr[j0];
+          v.y = h1 ? fr[j1] : 0.0f;
+          v.z = h2 ? fr[j2] : 0.0f;
+          v.w = h3 ? fr[j3] : 0.0f;
+          o0[d * PN4 + rem] = v;
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < PP_NUM_FEATURES; ++d) o0[d * PN4 + rem] = z4;
+      }
+    }
+  }
+}
+
+// Speculative zero fill: the groups n4 >= H4 of every pillar row hold live data
+// only for pillars with more than 4*H4 points, so they are zero-filled at kernel
+// entry, before ANY load has returned -- two thirds of the kernel's bytes at
+// N = 100.  A pillar that does reach into that region overwrites it later; the
+// overwrite is ordered behind these stores because it depends on loads that were
+// issued after them (vmcnt retires in issue order) and on an explicit wait.
+#ifndef PP_SPEC_H4
+#define PP_SPEC_H4 100000  /* measured: early store bursts delay the loads (profiles/r01/NOTES.md) */
+#endif
+constexpr unsigned kSpecH4 = PP_SPEC_H4;
+
+__device__ __forceinline__ void spec_zero_fill(float4 *__restrict__ out4, int64_t P, int p0,
+                                               unsigned rowf4, unsigned N4, unsigned H4,
+                                               unsigned magic_n4, int lane) {
+  if (H4 >= N4) return;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t PN4 = P * (int64_t)N4;
+  float4 *o0 = out4 + (int64_t)p0 * N4;
+  for (unsigned rem = lane; rem < rowf4; rem += kWave) {
+    const unsigned k = fastdiv(rem, N4, magic_n4);
+    const unsigned n4 = rem - k * N4;
+    if (n4 >= H4) {
+#pragma unroll
+      for (int d = 0; d < PP_NUM_FEATURES; ++d) o0[d * PN4 + rem] = z4;
+    }
   }
 }
 
 template <typename TIn, int MODE>
-__global__ __launch_bounds__(kEmitThreads) void k_emit(EmitArgs a) {
+#ifndef PP_EMIT_MINWAVES
+#define PP_EMIT_MINWAVES 4
+#endif
+__global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArgs a) {
   __shared__ WaveLds<TIn> lds[kEmitWaves];
+  using Rec = typename Rec4<TIn>::type;
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int N = a.N, P = a.P;
@@ -595,21 +687,60 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EmitArgs a) {
   const int p0 = (blockIdx.x * kEmitWaves + w) * KW;
   if (p0 >= P) return;
   const int kw_eff = min(KW, P - p0);
+  // (1) pillar descriptors: the loads go out first, the speculative fill below
+  //     overlaps their latency
   const int2 tot = a.totals[b];
+  int4 m = make_int4(-1, 0, 0, 0);
+  if (lane < KW && p0 + lane < P) m = a.pillar_meta[(int64_t)b * P + p0 + lane];
+  SlabGeom sg;
+  if (MODE == kModeDenseVec4) {
+    sg.N4 = (unsigned)(N >> 2);
+    sg.rowf4 = (unsigned)kw_eff * sg.N4;
+    sg.magic_n4 = 0xFFFFFFFFu / sg.N4 + 1u;
+    sg.aligned = (((int64_t)P * sg.N4) & 7) == 0;
+    sg.H4 = min(kSpecH4, sg.N4);
+    spec_zero_fill(reinterpret_cast<float4 *>(a.out + (int64_t)b * 9 * P * N), P, p0, sg.rowf4,
+                   sg.N4, sg.H4, sg.magic_n4, lane);
+  }
   const int npil = min(tot.x, P);
-  // (1) pillar descriptors
   if (lane < KW) {
-    const int p = p0 + lane;
-    int4 m = make_int4(-1, 0, 0, 0);
-    if (p < npil) m = a.pillar_meta[(int64_t)b * P + p];
+    if (p0 + lane >= npil) m = make_int4(-1, 0, 0, 0);  // rows beyond the occupied cells hold stale descriptors
     L.slot[lane] = m.x;
     L.start[lane] = m.y;
     L.cnt[lane] = m.z;
     L.live[lane] = min(m.z, N);
   }
   wave_sync();
-  // (2) dense modes: scatter indices and the zero padding (no dependence on
-  //     the points, so these stores start one load round trip after launch)
+  int cnts[KW], segbeg[KW];
+  int T = 0;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    cnts[k] = __builtin_amdgcn_readfirstlane(L.cnt[k]);
+    segbeg[k] = T;
+    T += cnts[k];
+  }
+  const bool pooled = (T <= CAPW);
+  // (2) prefetch the pooled bucket (coalesced: consecutive pillars own consecutive
+  //     CSR ranges); consumed after the early zero fill has been issued
+  int idx0 = 0, idx1 = 0;
+  Rec rec0, rec1;
+  rec0.x = rec0.y = rec0.z = rec0.w = 0;
+  rec1 = rec0;
+  if (pooled && T > 0) {
+    const int start0 = __builtin_amdgcn_readfirstlane(L.start[0]);
+    const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + start0;
+    const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + start0;
+    if (lane < T) {
+      idx0 = sidx[lane];
+      rec0 = srec[lane];
+    }
+    if (lane + kWave < T) {
+      idx1 = sidx[lane + kWave];
+      rec1 = srec[lane + kWave];
+    }
+  }
+  // (3) dense modes: scatter indices + the rest of the zero padding that needs no point data
+  float *outb = nullptr;
   if (MODE != kModeCompact) {
     if (lane < kw_eff) {
       long long *io = a.idx_out + ((int64_t)b * P + p0 + lane) * 3;
@@ -625,23 +756,18 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EmitArgs a) {
       io[1] = i1;
       io[2] = i2;
     }
-    float *outb = a.out + (int64_t)b * 9 * P * N;
+    outb = a.out + (int64_t)b * 9 * P * N;
     if (MODE == kModeDenseVec4) {
-      const int N4 = N >> 2;
-      const unsigned rowf4 = (unsigned)(kw_eff * N4);
-      const unsigned total = 9u * rowf4;
-      const unsigned magic_row = 0xFFFFFFFFu / rowf4 + 1u;
-      const unsigned magic_n4 = 0xFFFFFFFFu / (unsigned)N4 + 1u;
-      float4 *out4 = reinterpret_cast<float4 *>(outb);
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (unsigned f = lane; f < total; f += kWave) {
-        const unsigned d = __umulhi(f, magic_row);
-        const unsigned rem = f - d * rowf4;
-        const unsigned k = __umulhi(rem, magic_n4);
-        const unsigned n4 = rem - k * (unsigned)N4;
-        const unsigned nh = (unsigned)(L.live[k] + 3) >> 2;
-        if (n4 >= nh) out4[((int64_t)d * P + p0) * N4 + rem] = z4;
+      sg.pooled = 0;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        sg.nh[k] = (min(cnts[k], N) + 3) >> 2;
+        // pooled together, or alone in its own pass when the pool overflowed
+        if (cnts[k] > 0 && (pooled || cnts[k] <= CAPW)) sg.pooled |= 1u << k;
       }
+#ifndef PP_EXP_NO_EARLY
+      store_slab<false, TIn>(L, sg, reinterpret_cast<float4 *>(outb), P, p0, lane, segbeg);
+#endif
     } else {
       const int rowf = kw_eff * N;
       const int total = 9 * rowf;
@@ -652,26 +778,57 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EmitArgs a) {
       }
     }
   }
-  // (3) the points
-  int cnts[KW];
-  int T = 0;
-#pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    cnts[k] = __builtin_amdgcn_readfirstlane(L.cnt[k]);
-    T += cnts[k];
-  }
+#ifdef PP_EXP_NO_POINTS
+  return;
+#endif
+  // (4) the points
   if (T == 0) return;
-  if (T <= CAPW) {
-    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane);
+  if (MODE == kModeDenseVec4) {
+    bool deep = false;  // some pillar's live data reaches the speculatively zeroed groups
+#pragma unroll
+    for (int k = 0; k < KW; ++k) deep = deep || (sg.nh[k] > (int)sg.H4);
+    if (deep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (pooled) {
+    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx0, rec0, idx1, rec1, segbeg, cnts, T);
+    if (MODE == kModeDenseVec4)
+      store_slab<true, TIn>(L, sg, reinterpret_cast<float4 *>(outb), P, p0, lane, segbeg);
   } else {
+    // the pool overflowed: one pillar at a time
 #pragma unroll 1
     for (int k = 0; k < KW; ++k) {
-      const int c = __builtin_amdgcn_readfirstlane(L.cnt[k]);
+      const int c = cnts[k];
       if (c == 0) continue;
-      if (c <= CAPW)
-        emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane);
-      else
+      if (c <= CAPW) {
+        int sb1[KW], ck1[KW];
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+          sb1[kk] = 0;
+          ck1[kk] = (kk == k) ? c : 0;
+        }
+        const int st = __builtin_amdgcn_readfirstlane(L.start[k]);
+        const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + st;
+        const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + st;
+        if (lane < c) {
+          idx0 = sidx[lane];
+          rec0 = srec[lane];
+        }
+        if (lane + kWave < c) {
+          idx1 = sidx[lane + kWave];
+          rec1 = srec[lane + kWave];
+        }
+        emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane, idx0, rec0, idx1, rec1, sb1, ck1, c);
+        if (MODE == kModeDenseVec4) {
+          // late pass restricted to this pillar's lines: lines shared with another
+          // pooled pillar of this wave are completed by that pillar's own pass
+          // (both passes write identical zeros outside their own head groups)
+          SlabGeom s1 = sg;
+          s1.pooled = 1u << k;
+          store_slab<true, TIn>(L, s1, reinterpret_cast<float4 *>(outb), P, p0, lane, sb1);
+        }
+      } else {
         emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane);
+      }
     }
   }
 }
@@ -760,24 +917,26 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
 namespace {
 
 struct VoxLayout {
-  size_t cursor, cell_of, bucket, meta, status, ticket, totals, errflag, bytes;
+  size_t cursor, cell_rank, sorted_idx, sorted_pts, meta, status, ticket, totals, errflag, bytes;
   int nwg_scan;
   int ncap;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P) {
+VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int rec_bytes) {
   VoxLayout l;
   l.ncap = (int)align_up((size_t)std::max<int64_t>(max_points, 1), 64);
   l.nwg_scan = g.ncells_pad / kScanTile;
   size_t off = 0;
   l.cursor = off;
   off = align_up(off + (size_t)B * g.ncells_pad * 4, 256);
-  l.cell_of = off;
+  l.cell_rank = off;
+  off = align_up(off + (size_t)B * l.ncap * 8, 256);
+  l.sorted_idx = off;
   off = align_up(off + (size_t)B * l.ncap * 4, 256);
-  l.bucket = off;
-  off = align_up(off + (size_t)B * l.ncap * 4, 256);
+  l.sorted_pts = off;
+  off = align_up(off + (size_t)B * l.ncap * rec_bytes, 256);
   l.meta = off;
   off = align_up(off + (size_t)B * P * 16, 256);
   l.status = off;
@@ -811,11 +970,12 @@ struct DeviceGuard {
 // Makes the workspace fit (B, max_points, grid, P) and guarantees the "clean"
 // invariant (cursor, status, ticket all zero) whenever the layout changed.
 int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
-               const GridGeom &g, int P, VoxLayout *out) {
-  VoxLayout l = vox_layout(B, max_points, g, P);
+               const GridGeom &g, int P, int rec_bytes, VoxLayout *out) {
+  VoxLayout l = vox_layout(B, max_points, g, P, rec_bytes);
   const unsigned long long key[6] = {(unsigned long long)B, (unsigned long long)l.ncap,
                                      (unsigned long long)g.ncells_pad,
-                                     (unsigned long long)P, (unsigned long long)l.bytes, 1ull};
+                                     (unsigned long long)P, (unsigned long long)l.bytes,
+                                     (unsigned long long)rec_bytes};
   bool grew = false;
   int rc = ctx->vox_ws.ensure(l.bytes, &grew);
   if (rc) return rc;
@@ -835,8 +995,10 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     bool timed) {
   char *ws = static_cast<char *>(ctx->vox_ws.ptr);
   int *cursor = reinterpret_cast<int *>(ws + l.cursor);
-  int *cell_of = reinterpret_cast<int *>(ws + l.cell_of);
-  int *bucket = reinterpret_cast<int *>(ws + l.bucket);
+  int2 *cell_rank = reinterpret_cast<int2 *>(ws + l.cell_rank);
+  int *sorted_idx = reinterpret_cast<int *>(ws + l.sorted_idx);
+  typename Rec4<TIn>::type *sorted_pts =
+      reinterpret_cast<typename Rec4<TIn>::type *>(ws + l.sorted_pts);
   int4 *meta = reinterpret_cast<int4 *>(ws + l.meta);
   u64 *status = reinterpret_cast<u64 *>(ws + l.status);
   unsigned *ticket = reinterpret_cast<unsigned *>(ws + l.ticket);
@@ -845,11 +1007,12 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
 
   const dim3 grid_pts((unsigned)std::max(1, (maxn + kBinThreads - 1) / kBinThreads), (unsigned)B);
   hipLaunchKernelGGL((k_bin_count<TIn>), grid_pts, dim3(kBinThreads), 0, stream, pts,
-                     sweep_stride, s0, s1, contig, np, g, cell_of, l.ncap, cursor);
+                     sweep_stride, s0, s1, contig, np, g, cell_rank, l.ncap, cursor);
   hipLaunchKernelGGL(k_scan, dim3((unsigned)l.nwg_scan, (unsigned)B), dim3(kScanThreads), 0,
                      stream, cursor, g.ncells_pad, P, meta, status, ticket, totals, errflag);
-  hipLaunchKernelGGL(k_fill, grid_pts, dim3(kBinThreads), 0, stream, cell_of, l.ncap, np,
-                     cursor, g.ncells_pad, bucket, status, l.nwg_scan, ticket);
+  hipLaunchKernelGGL((k_fill<TIn>), grid_pts, dim3(kBinThreads), 0, stream, pts, sweep_stride,
+                     cell_rank, l.ncap, np, cursor, g.ncells_pad, sorted_pts, sorted_idx, status,
+                     l.nwg_scan, ticket);
   EmitArgs a;
   a.g = g;
   a.np = np;
@@ -858,8 +1021,9 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.ncap = l.ncap;
   a.pillar_meta = meta;
   a.totals = totals;
-  a.bucket = bucket;
-  a.cell_of = cell_of;
+  a.sorted_idx = sorted_idx;
+  a.sorted_pts = sorted_pts;
+  a.cell_rank = cell_rank;
   a.cursor = cursor;
   a.pts = pts;
   a.sweep_stride = sweep_stride;
@@ -916,7 +1080,7 @@ extern "C" int pp_voxelize_reserve(pp_ctx_t *ctx, int batch, int64_t max_points,
   }
   DeviceGuard guard(ctx->device);
   VoxLayout l;
-  return prepare_ws(ctx, nullptr, batch, max_points, g, prm->max_pillars, &l);
+  return prepare_ws(ctx, nullptr, batch, max_points, g, prm->max_pillars, 16, &l);
 }
 
 extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
@@ -964,7 +1128,7 @@ extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(ctx->device);
   VoxLayout l;
-  rc = prepare_ws(ctx, stream, batch, std::max<int64_t>(points_stride, 1), g, P, &l);
+  rc = prepare_ws(ctx, stream, batch, std::max<int64_t>(points_stride, 1), g, P, 16, &l);
   if (rc) return rc;
   const int mode = (N % 4 == 0 && N <= 4096) ? kModeDenseVec4 : kModeDenseScalar;
   rc = launch_pipeline<float>(ctx, stream, points_dev, points_stride, 4, 1, 1, np, batch, maxn,
@@ -1007,7 +1171,7 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   DeviceGuard guard(ctx->device);
   hipStream_t stream = nullptr;
   VoxLayout l;
-  rc = prepare_ws(ctx, stream, 1, n, g, P, &l);
+  rc = prepare_ws(ctx, stream, 1, n, g, P, 32, &l);
   if (rc) return rc;
   // gather the (arbitrarily strided) points into pinned staging: [n][4] f64
   rc = ctx->pin_in.ensure((size_t)n * 32);
