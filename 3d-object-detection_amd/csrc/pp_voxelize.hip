@@ -315,6 +315,7 @@ struct WaveLds {
     float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense mode), aliases c
   } u;
   double mean[KW][3];
+  double cx[KW], cy[KW];  // canvas_x / canvas_y (pillars.cpp:278-280), once per pillar
   int cnt[KW], live[KW], slot[KW], start[KW];
 };
 
@@ -413,8 +414,7 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
     wave_sync();
   }
   const double mean[3] = {m0, m1, m2};
-  double cx, cy;
-  pillar_canvas(slot, a.g, cx, cy);
+  const double cx = L.cx[k], cy = L.cy[k];
   const int N = a.N;
   const int live = L.live[k];
   seen = 0;
@@ -535,11 +535,9 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
     for (int kk = 0; kk < KW; ++kk) sb = (k == kk) ? segbeg[kk] : sb;
     const int n = j - sb;
     if (n < N) {
-      double cx, cy;
-      pillar_canvas(L.slot[k], a.g, cx, cy);
       double f[9];
       point_features((double)L.px[j], (double)L.py[j], (double)L.pz[j], (double)L.pr[j],
-                     cx, cy, L.mean[k], f);
+                     L.cx[k], L.cy[k], L.mean[k], f);
       if (MODE == kModeCompact) {
         double *o = a.feat_out + ((int64_t)b * a.ncap + start0 + j) * 9;
 #pragma unroll
@@ -709,6 +707,10 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     L.start[lane] = m.y;
     L.cnt[lane] = m.z;
     L.live[lane] = min(m.z, N);
+    double cx = 0, cy = 0;
+    if (m.z > 0) pillar_canvas(m.x, a.g, cx, cy);
+    L.cx[lane] = cx;
+    L.cy[lane] = cy;
   }
   wave_sync();
   int cnts[KW], segbeg[KW];
@@ -746,11 +748,9 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       long long *io = a.idx_out + ((int64_t)b * P + p0 + lane) * 3;
       long long i0 = 0, i1 = 0, i2 = 0;
       if (L.cnt[lane] > 0) {
-        double cx, cy;
-        pillar_canvas(L.slot[lane], a.g, cx, cy);
-        i0 = 1;               // pillars.cpp:390
-        i1 = (long long)cx;   // pillars.cpp:391 + dataset.py:106 (.long())
-        i2 = (long long)cy;   // pillars.cpp:392
+        i0 = 1;                        // pillars.cpp:390
+        i1 = (long long)L.cx[lane];    // pillars.cpp:391 + dataset.py:106 (.long())
+        i2 = (long long)L.cy[lane];    // pillars.cpp:392
       }
       io[0] = i0;
       io[1] = i1;
