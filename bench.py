@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1, help="sweeps per GPU per step")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="sweeps per GPU per step (default: the reference's BATCH_SIZE, config.py:137)")
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
                     help="fwd: BASELINE metric (configs[1]); train: configs[2] -- adds HIP target "
                          "assignment, loss forward/backward and the loss-scalar all-reduce")
