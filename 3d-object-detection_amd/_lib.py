@@ -23,7 +23,7 @@ MAX_BATCH = 32
 
 EXPORTS = [
     "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
-    "pp_voxelize_reserve", "pp_voxelize_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
+    "pp_voxelize_reserve", "pp_voxelize_dev", "pp_voxelize_pfn_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
     "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_ctx_set_timing",
     "pp_ctx_read_emit_ms",
 ]
@@ -99,6 +99,8 @@ def lib():
         L.pp_voxelize_reserve.argtypes = [vp, c_int, i64, ctypes.POINTER(VoxelParams)]
         L.pp_voxelize_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
                                       ctypes.POINTER(VoxelParams), vp, vp, vp]
+        L.pp_voxelize_pfn_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                          ctypes.POINTER(VoxelParams), vp, c_int, vp, vp, vp]
         L.pp_create_pillars_f64.argtypes = [vp, vp, i64, i64, i64, vp, pi64, pi64, vp, pi64, pi64,
                                             ctypes.POINTER(VoxelParams), pi64]
         L.pp_make_ious_f64.argtypes = [vp, vp, i64, pi64, vp, i64, pi64, vp, pi64, vp, pi64, vp, pi64]

@@ -336,9 +336,30 @@ struct EmitArgs {
   long long *idx_out;  // [B][P][3]
   // compact mode
   double *feat_out;  // [B][ncap][9]
+  // fused feature-net mode
+  const float *pfn_w;  // [64][12]: w[0..8], bias, bn scale, bn shift per output channel
+  float *pfn_out;      // [B][64][P]
 };
 
-enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2 };
+enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 };
+
+constexpr int kPfnChannels = 64;  // one lane per output channel (model/model.py:28: 9 -> 64)
+
+// Fused PPFeatureNet (inference): y[c,p] = max_n BN_c(ReLU(b_c + sum_d W[c,d] x[d,p,n]))
+// over ALL N slots of the pillar, zero-padded ones included (model/model.py:31-40:
+// conv1x1, ReLU, THEN BatchNorm, max over N).  BN in eval mode is the affine map
+// s*r + t, so the max over n moves inside: s >= 0 ? s*max(r) + t : s*min(r) + t.
+struct PfnAcc {
+  float w[9], bias, scale, shift;
+  float rmax[KW], rmin[KW];
+};
+
+__device__ __forceinline__ float pfn_relu_conv(const PfnAcc &A, const float x[9]) {
+  float r = A.bias;
+#pragma unroll
+  for (int d = 0; d < 9; ++d) r = fmaf(A.w[d], x[d], r);
+  return fmaxf(r, 0.0f);
+}
 
 __device__ __forceinline__ void pillar_canvas(int slot, const GridGeom &g,
                                               double &canvas_x, double &canvas_y) {
@@ -370,7 +391,8 @@ __device__ __forceinline__ void point_features(double x, double y, double z, dou
 // the order is restored without sorting.  O(n_points/64) per such pillar.
 template <typename TIn, int MODE>
 __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k, int p,
-                                int lane) {
+                                int lane, PfnAcc *acc = nullptr, float *rmax = nullptr,
+                                float *rmin = nullptr) {
   const int slot = L.slot[k];
   const int nb = a.np.n[b];
   const TIn *pts = reinterpret_cast<const TIn *>(a.pts) + (int64_t)b * a.sweep_stride * 4;
@@ -433,11 +455,29 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
         double *o = a.feat_out + ((int64_t)b * a.ncap + L.start[k] + n) * 9;
 #pragma unroll
         for (int d = 0; d < 9; ++d) o[d] = f[d];
+      } else if (MODE == kModePfn) {
+        const int t = __popcll(mask & lt_mask);  // position inside this chunk
+#pragma unroll
+        for (int d = 0; d < 9; ++d) L.u.feat[d][t] = (float)f[d];
       } else {
         float *o = a.out + (int64_t)b * 9 * a.P * N;
 #pragma unroll
         for (int d = 0; d < 9; ++d) o[((int64_t)d * a.P + p) * N + n] = (float)f[d];
       }
+    }
+    if (MODE == kModePfn) {
+      // every lane is a channel: fold this chunk's live points into its max/min
+      wave_sync();
+      const int c = min(__popcll(mask), N - seen);
+      for (int t = 0; t < c; ++t) {
+        float xv[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) xv[d] = L.u.feat[d][t];
+        const float rr = pfn_relu_conv(*acc, xv);
+        *rmax = fmaxf(*rmax, rr);
+        *rmin = fminf(*rmin, rr);
+      }
+      wave_sync();
     }
     seen += __popcll(mask);
   }
@@ -741,7 +781,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       rec1 = srec[lane + kWave];
     }
   }
-  // (3) dense modes: scatter indices + the rest of the zero padding that needs no point data
+  // (3) scatter indices; dense modes: the zero padding that needs no point data
   float *outb = nullptr;
   if (MODE != kModeCompact) {
     if (lane < kw_eff) {
@@ -756,6 +796,8 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       io[1] = i1;
       io[2] = i2;
     }
+  }
+  if (MODE == kModeDenseVec4 || MODE == kModeDenseScalar) {
     outb = a.out + (int64_t)b * 9 * P * N;
     if (MODE == kModeDenseVec4) {
       sg.pooled = 0;
@@ -778,11 +820,69 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       }
     }
   }
+  // fused feature net: this lane's output channel
+  PfnAcc acc;
+  if constexpr (MODE == kModePfn) {
+    const float *wp = a.pfn_w + lane * 12;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) acc.w[d] = wp[d];
+    acc.bias = wp[9];
+    acc.scale = wp[10];
+    acc.shift = wp[11];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      acc.rmax[k] = -INFINITY;
+      acc.rmin[k] = INFINITY;
+    }
+  }
+  // folds the live points [sb, sb+live) of pillar k (features in L.u.feat) into acc
+  auto pfn_fold = [&](int k, int sb, int live) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int j = sb; j < sb + live; ++j) {
+      float xv[9];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) xv[d] = L.u.feat[d][j];
+      const float rr = pfn_relu_conv(acc, xv);
+      mx = fmaxf(mx, rr);
+      mn = fminf(mn, rr);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk)
+      if (kk == k) {
+        acc.rmax[kk] = fmaxf(acc.rmax[kk], mx);
+        acc.rmin[kk] = fminf(acc.rmin[kk], mn);
+      }
+  };
+  auto pfn_finish = [&]() {
+    // zero-padded slots take part in the max (model/model.py:36-39)
+    const float rpad = fmaxf(acc.bias, 0.0f);
+    float yv[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      float mx = acc.rmax[k], mn = acc.rmin[k];
+      if (min(cnts[k], N) < N) {
+        mx = fmaxf(mx, rpad);
+        mn = fminf(mn, rpad);
+      }
+      yv[k] = fmaf(acc.scale >= 0.0f ? mx : mn, acc.scale, acc.shift);
+    }
+    float *o = a.pfn_out + ((int64_t)b * kPfnChannels + lane) * P + p0;
+    if (kw_eff == KW && (P & 3) == 0) {
+      *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < KW; ++k)
+        if (k < kw_eff) o[k] = yv[k];
+    }
+  };
 #ifdef PP_EXP_NO_POINTS
   return;
 #endif
   // (4) the points
-  if (T == 0) return;
+  if (T == 0) {
+    if constexpr (MODE == kModePfn) pfn_finish();
+    return;
+  }
   if (MODE == kModeDenseVec4) {
     bool deep = false;  // some pillar's live data reaches the speculatively zeroed groups
 #pragma unroll
@@ -793,6 +893,10 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx0, rec0, idx1, rec1, segbeg, cnts, T);
     if (MODE == kModeDenseVec4)
       store_slab<true, TIn>(L, sg, reinterpret_cast<float4 *>(outb), P, p0, lane, segbeg);
+    if constexpr (MODE == kModePfn) {
+#pragma unroll
+      for (int k = 0; k < KW; ++k) pfn_fold(k, segbeg[k], min(cnts[k], N));
+    }
   } else {
     // the pool overflowed: one pillar at a time
 #pragma unroll 1
@@ -818,6 +922,10 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
           rec1 = srec[lane + kWave];
         }
         emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane, idx0, rec0, idx1, rec1, sb1, ck1, c);
+        if constexpr (MODE == kModePfn) {
+          pfn_fold(k, 0, min(c, N));
+          wave_sync();
+        }
         if (MODE == kModeDenseVec4) {
           // late pass restricted to this pillar's lines: lines shared with another
           // pooled pillar of this wave are completed by that pillar's own pass
@@ -827,10 +935,22 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
           store_slab<true, TIn>(L, s1, reinterpret_cast<float4 *>(outb), P, p0, lane, sb1);
         }
       } else {
-        emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane);
+        if constexpr (MODE == kModePfn) {
+          float mx = -INFINITY, mn = INFINITY;
+          emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane, &acc, &mx, &mn);
+#pragma unroll
+          for (int kk = 0; kk < KW; ++kk)
+            if (kk == k) {
+              acc.rmax[kk] = fmaxf(acc.rmax[kk], mx);
+              acc.rmin[kk] = fminf(acc.rmin[kk], mn);
+            }
+        } else {
+          emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane);
+        }
       }
     }
   }
+  if constexpr (MODE == kModePfn) pfn_finish();
 }
 
 // ------------------------------------------------------------------------- //
@@ -992,7 +1112,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     int64_t s0, int64_t s1, int contig, const NPoints &np, int B,
                     int maxn, const GridGeom &g, int P, int N, const VoxLayout &l,
                     int mode, float *out, long long *idx_out, double *feat_out,
-                    bool timed) {
+                    bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr) {
   char *ws = static_cast<char *>(ctx->vox_ws.ptr);
   int *cursor = reinterpret_cast<int *>(ws + l.cursor);
   int2 *cell_rank = reinterpret_cast<int2 *>(ws + l.cell_rank);
@@ -1030,6 +1150,8 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.out = out;
   a.idx_out = idx_out;
   a.feat_out = feat_out;
+  a.pfn_w = pfn_w;
+  a.pfn_out = pfn_out;
   const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
   int slot = -1;
   if (timed && ctx->ev_slots > 0) {
@@ -1042,6 +1164,9 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
       break;
     case kModeDenseScalar:
       hipLaunchKernelGGL((k_emit<TIn, kModeDenseScalar>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      break;
+    case kModePfn:
+      hipLaunchKernelGGL((k_emit<TIn, kModePfn>), grid_emit, dim3(kEmitThreads), 0, stream, a);
       break;
     default:
       hipLaunchKernelGGL((k_emit<TIn, kModeCompact>), grid_emit, dim3(kEmitThreads), 0, stream, a);
@@ -1134,6 +1259,70 @@ extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points
   rc = launch_pipeline<float>(ctx, stream, points_dev, points_stride, 4, 1, 1, np, batch, maxn,
                               g, P, N, l, mode, pillars_dev,
                               reinterpret_cast<long long *>(indices_dev), nullptr, true);
+  if (rc) return rc;
+  if (num_cells_dev) {
+    char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+    PP_HIP_TRY(hipMemcpyAsync(num_cells_dev, ws + l.totals, (size_t)batch * 8,
+                              hipMemcpyDeviceToDevice, stream));
+  }
+  return PP_OK;
+}
+
+extern "C" int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                   int64_t points_stride, const int32_t *n_points, int batch,
+                                   const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                                   int channels, float *features_dev, int64_t *indices_dev,
+                                   int32_t *num_cells_dev) {
+  if (!ctx || !points_dev || !n_points || !prm || !pfn_params_dev || !features_dev || !indices_dev) {
+    set_error("pp_voxelize_pfn_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (channels != kPfnChannels) {
+    set_error("the fused feature net is built for %d output channels (got %d)", kPfnChannels, channels);
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || batch > PP_MAX_BATCH) {
+    set_error("batch must be in [1,%d], got %d", PP_MAX_BATCH, batch);
+    return PP_ERR_VALUE;
+  }
+  const int P = prm->max_pillars, N = prm->max_points_per_pillar;
+  if (P < 1 || N < 1 || N > 65536) {
+    set_error("need max_pillars >= 1 and 1 <= max_points_per_pillar <= 65536 (got P=%d N=%d)", P, N);
+    return PP_ERR_VALUE;
+  }
+  if (points_stride < 0 || points_stride > INT_MAX / 2) {
+    set_error("points_stride out of range");
+    return PP_ERR_VALUE;
+  }
+  NPoints np;
+  std::memset(&np, 0, sizeof np);
+  int maxn = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (n_points[b] < 0 || n_points[b] > points_stride) {
+      set_error("n_points[%d]=%d outside [0, points_stride=%lld]", b, n_points[b],
+                (long long)points_stride);
+      return PP_ERR_VALUE;
+    }
+    np.n[b] = n_points[b];
+    maxn = std::max(maxn, n_points[b]);
+  }
+  if ((reinterpret_cast<uintptr_t>(points_dev) & 15) || (reinterpret_cast<uintptr_t>(features_dev) & 15) ||
+      (reinterpret_cast<uintptr_t>(indices_dev) & 7) || (reinterpret_cast<uintptr_t>(pfn_params_dev) & 3)) {
+    set_error("device pointers must be 16-byte (points, features) / 8-byte (indices) aligned");
+    return PP_ERR_VALUE;
+  }
+  GridGeom g;
+  int rc = make_grid(prm, &g);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(ctx->device);
+  VoxLayout l;
+  rc = prepare_ws(ctx, stream, batch, std::max<int64_t>(points_stride, 1), g, P, 16, &l);
+  if (rc) return rc;
+  rc = launch_pipeline<float>(ctx, stream, points_dev, points_stride, 4, 1, 1, np, batch, maxn,
+                              g, P, N, l, kModePfn, nullptr,
+                              reinterpret_cast<long long *>(indices_dev), nullptr, true,
+                              pfn_params_dev, features_dev);
   if (rc) return rc;
   if (num_cells_dev) {
     char *ws = static_cast<char *>(ctx->vox_ws.ptr);

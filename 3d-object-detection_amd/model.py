@@ -30,6 +30,17 @@ class PPFeatureNet(nn.Module):
         x = self.bn1(x)
         return torch.max(x, dim=3)[0]      # [B,C,P]
 
+    @torch.no_grad()
+    def fused_params(self):
+        """[C,12] f32 table for the fused HIP feature net (inference): per output
+        channel the conv weight w[0..8], the conv bias, and eval-mode BatchNorm as
+        an affine map: scale = gamma/sqrt(var+eps), shift = beta - mean*scale."""
+        w = self.conv1.weight.detach().double().reshape(self.conv1.out_channels, -1)
+        b = self.conv1.bias.detach().double()
+        scale = self.bn1.weight.detach().double() / torch.sqrt(self.bn1.running_var.double() + self.bn1.eps)
+        shift = self.bn1.bias.detach().double() - self.bn1.running_mean.double() * scale
+        return torch.cat([w, b[:, None], scale[:, None], shift[:, None]], dim=1).float().contiguous()
+
 
 class PPScatter(nn.Module):
     """model/model.py:42-62: ``out[b,:,row,col] = x[b,:,p]`` for flagged pillars.
@@ -143,5 +154,12 @@ class PPModel(nn.Module):
     def forward(self, x, inds):
         x = self.feature_net(x)
         x = self.scatter(x, inds)
+        x = self.backbone(x)
+        return self.det_head(x)
+
+    def forward_features(self, feats, inds):
+        """Same network from PPFeatureNet's output ``feats[B,C,P]`` on (the fused
+        HIP voxelizer + feature net produces it directly)."""
+        x = self.scatter(feats, inds)
         x = self.backbone(x)
         return self.det_head(x)

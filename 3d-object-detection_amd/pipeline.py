@@ -36,6 +36,8 @@ class PillarPipeline:
                                            pos_thresh=pos_thresh, num_classes=num_classes,
                                            device=self.device)
         self._bufs = None
+        self._fbufs = None
+        self._pfn_params = None
 
     def _buffers(self, batch):
         cfg = self.vox_cfg
@@ -55,6 +57,29 @@ class PillarPipeline:
         """evaluate.py:216-228: voxel stage + network forward (inference)."""
         pillars, indices = self.voxelize(points, n_points)
         return self.model(pillars, indices)
+
+    @torch.no_grad()
+    def forward_fused(self, points, n_points=None):
+        """Inference with PPFeatureNet fused into the voxelizer:
+        the dense [9,P,N] tensor and the [64,P,N] intermediate never exist.  Needs
+        ``model.eval()`` (BatchNorm as an affine map)."""
+        if self.model.training:
+            raise RuntimeError("forward_fused is inference only: call model.eval() first")
+        if self._pfn_params is None:
+            self._pfn_params = self.model.feature_net.fused_params().to(self.device)
+        if points.dim() == 2:
+            points = points.unsqueeze(0)
+        B = points.shape[0]
+        if self._fbufs is None or self._fbufs[0].shape[0] != B:
+            P = self.vox_cfg.max_pillars
+            self._fbufs = (torch.empty((B, 64, P), dtype=torch.float32, device=self.device),
+                           torch.empty((B, P, 3), dtype=torch.int64, device=self.device))
+        feats, indices = self.voxelizer.pfn(points, self._pfn_params, n_points=n_points, out=self._fbufs)
+        return self.model.forward_features(feats, indices)
+
+    def invalidate_fused_params(self):
+        """Call after changing the feature net's weights / BN statistics."""
+        self._pfn_params = None
 
     def train_forward_backward(self, points, gts, n_points=None):
         """train.py:139-147 without the optimizer: voxel stage, target stage, forward,

@@ -88,8 +88,7 @@ class PillarVoxelizer:
                    "pp_ctx_read_emit_ms")
         return [buf[i] for i in range(cnt.value)]
 
-    def __call__(self, points, n_points=None, out=None, return_counts=False):
-        cfg = self.cfg
+    def _prep(self, points, n_points):
         if points.dim() == 2:
             points = points.unsqueeze(0)
         if (points.dim() != 3 or points.shape[-1] != 4 or points.dtype != torch.float32
@@ -100,7 +99,39 @@ class PillarVoxelizer:
         B, ncap = points.shape[0], points.shape[1]
         if n_points is None:
             n_points = [ncap] * B
-        n_arr = (ctypes.c_int32 * B)(*[int(v) for v in n_points])
+        return points, B, ncap, (ctypes.c_int32 * B)(*[int(v) for v in n_points])
+
+    def pfn(self, points, pfn_params, n_points=None, out=None, return_counts=False):
+        """Voxelizer with the feature net fused in (inference): returns
+        ``(features[B,64,P] f32, indices[B,P,3] i64)`` -- PPFeatureNet's output
+        (model/model.py:31-40) without ever building the dense [9,P,N] tensor.
+        ``pfn_params`` is the [64,12] tensor of ``PPFeatureNet.fused_params()``."""
+        points, B, ncap, n_arr = self._prep(points, n_points)
+        P = self.cfg.max_pillars
+        if (pfn_params.shape != (64, 12) or pfn_params.dtype != torch.float32
+                or pfn_params.device != self.device or not pfn_params.is_contiguous()):
+            raise ValueError("pfn_params must be a contiguous float32 [64,12] tensor on " + str(self.device))
+        if out is None:
+            feats = torch.empty((B, 64, P), dtype=torch.float32, device=self.device)
+            indices = torch.empty((B, P, 3), dtype=torch.int64, device=self.device)
+        else:
+            feats, indices = out
+        counts = (torch.empty((B, 2), dtype=torch.int32, device=self.device)
+                  if return_counts else None)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.lib().pp_voxelize_pfn_dev(
+            self._ctx.handle, ctypes.c_void_p(stream), ctypes.c_void_p(points.data_ptr()),
+            ncap, n_arr, B, ctypes.byref(self._prm), ctypes.c_void_p(pfn_params.data_ptr()), 64,
+            ctypes.c_void_p(feats.data_ptr()), ctypes.c_void_p(indices.data_ptr()),
+            ctypes.c_void_p(counts.data_ptr()) if counts is not None else None)
+        _lib.check(rc, "pp_voxelize_pfn_dev")
+        if return_counts:
+            return feats, indices, counts
+        return feats, indices
+
+    def __call__(self, points, n_points=None, out=None, return_counts=False):
+        cfg = self.cfg
+        points, B, ncap, n_arr = self._prep(points, n_points)
         P, N = cfg.max_pillars, cfg.max_points_per_pillar
         if out is None:
             pillars = torch.empty((B, _lib.NUM_FEATURES, P, N), dtype=torch.float32, device=self.device)

@@ -74,6 +74,7 @@ def main():
                     help="fwd: BASELINE metric (configs[1]); train: configs[2] -- adds HIP target "
                          "assignment, loss forward/backward and the loss-scalar all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the fused-feature-net side measurement")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -128,6 +129,25 @@ def main():
     torch.cuda.synchronize()
     vox_dt = (time.perf_counter() - t1) / vox_steps
 
+    # next row: the feature net fused into the voxelizer -- the dense
+    # [9,P,N] tensor is never built.  Reported beside the headline, not as it.
+    fused = None
+    if a.mode == "fwd" and not a.no_fused:
+        for _ in range(max(3, a.warmup // 2)):
+            pipe.forward_fused(points)
+        torch.cuda.synchronize()
+        shard.barrier(ctx)
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            pipe.forward_fused(points)
+        torch.cuda.synchronize()
+        shard.barrier(ctx)
+        f_el = shard.max_over_ranks(ctx, time.perf_counter() - t2, device=dev)
+        fused = {"value": a.steps * a.batch * ctx.world_size / f_el, "unit": "sweeps/s",
+                 "ms_per_step": f_el / a.steps * 1e3,
+                 "what": "same forward with PPFeatureNet (conv1x1+ReLU+BN(eval)+max) fused into the HIP "
+                         "voxelizer (pp_voxelize_pfn_dev); outputs equal the headline path's within 1e-4"}
+
     if ctx.rank == 0:
         total_sweeps = a.steps * a.batch * ctx.world_size
         bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
@@ -161,6 +181,8 @@ def main():
             "voxelizer_only": {"sweeps_per_s": a.batch / vox_dt, "us_per_step": vox_dt * 1e6,
                                "pipeline_GBps": bytes_per_launch / vox_dt / 1e9},
         }
+        if fused is not None:
+            out["fused_feature_net"] = fused
         if not a.no_cpu_baseline and ctx.world_size == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

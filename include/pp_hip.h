@@ -85,6 +85,23 @@ int pp_voxelize_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                     int64_t *indices_dev, int32_t *num_cells_dev);
 
 /*
+ * Device-resident voxelizer with the feature net fused in (inference only;
+ * SURVEY 8f rank 1): replaces the voxel stage above AND PPFeatureNet.forward
+ * (model/model.py:31-40: conv1x1 9->64, ReLU, then BatchNorm2d in eval mode,
+ * max over the N slots, zero-padded slots included).  The dense [9,P,N] tensor
+ * is never built.
+ *   pfn_params_dev [64][12] f32 per output channel: conv weight w[0..8], conv
+ *                  bias, BN scale gamma/sqrt(var+eps), BN shift beta-mean*scale
+ *   features_dev   [batch][64][P] f32  == PPFeatureNet's output
+ *   indices_dev, num_cells_dev, points_dev, n_points: as pp_voxelize_dev
+ */
+int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
+                        int64_t points_stride, const int32_t *n_points, int batch,
+                        const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                        int channels, float *features_dev, int64_t *indices_dev,
+                        int32_t *num_cells_dev);
+
+/*
  * Host drop-in for create_pillars (pillars.cpp:236-249, exported :433).
  * points [n,>=4], tensor [P',N',>=9], indices [P',>=3]: f64 host arrays with
  * arbitrary BYTE strides, mutated in place; nothing is zeroed (pillars.cpp never

@@ -1,0 +1,93 @@
+"""GPU parity of the fused voxelizer + feature net against
+PPFeatureNet (model/model.py:31-40) evaluated by PyTorch on the dense tensor.
+
+Bar: both are f32 evaluations of the same function (the fused kernel sums the
+9-term dot product in one fixed fmaf order and applies eval-mode BatchNorm as
+s*r+t; MIOpen uses its own order), so each is compared with an f64 evaluation of
+PPFeatureNet: the fused kernel's error must not exceed twice PyTorch-f32's own
+(+1e-6), and the two f32 results must agree within 1e-4 absolute (inputs reach
+|xp|,|yp| ~ 500, outputs ~ 60)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL_ABS = 1e-4
+
+
+def _net(gpu, seed=0):
+    import torch
+    import pp_amd.model as M
+    torch.manual_seed(seed)
+    fn = M.PPFeatureNet(9, 64).to(gpu)
+    with torch.no_grad():      # non-trivial BN statistics, both signs of the BN scale
+        fn.bn1.running_mean.normal_(0, 0.5)
+        fn.bn1.running_var.uniform_(0.3, 2.0)
+        fn.bn1.weight.normal_(0, 1.0)
+        fn.bn1.bias.normal_(0, 0.3)
+        fn.conv1.weight.mul_(0.2)
+    return fn.eval()
+
+
+def _compare(gpu, cfg_args, pts_list, n_points=None, order=0):
+    import torch
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    half, step, P, N = cfg_args
+    vox = PillarVoxelizer(VoxelConfig.square(half, step, P, N, order=order), device=gpu)
+    fn = _net(gpu)
+    pts = torch.from_numpy(np.stack(pts_list)).to(gpu)
+    dense, idx = vox(pts, n_points=n_points)
+    import pp_amd.model as M
+    fn64 = M.PPFeatureNet(9, 64).to(gpu).double()
+    fn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in fn.state_dict().items()})
+    fn64.eval()
+    with torch.no_grad():
+        ref = fn(dense)                                    # [B,64,P], PyTorch-ROCm f32
+        ref64 = fn64(dense.double())
+    feats, idx2, cnt = vox.pfn(pts, fn.fused_params(), n_points=n_points, return_counts=True)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, idx2)
+    assert (fn.bn1.weight < 0).any() and (fn.bn1.weight > 0).any()
+    err_torch = (ref.double() - ref64).abs().max().item()
+    err_fused = (feats.double() - ref64).abs().max().item()
+    assert err_fused <= 2 * err_torch + 1e-6, (err_fused, err_torch)
+    assert (feats - ref).abs().max().item() <= TOL_ABS
+    return feats, ref
+
+
+def test_fused_pfn_matches_torch_feature_net(gpu):
+    from pp_amd import synth
+    _compare(gpu, (20.0, 0.2, 8000, 32), [synth.lidar_like(20000, 20.0, s) for s in (0, 1)])
+
+
+def test_fused_pfn_overflow_empty_rows_and_ragged_batch(gpu):
+    from pp_amd import synth
+    clouds = [synth.lidar_like(30000, 30.0, 5 + s) for s in range(3)]
+    feats, ref = _compare(gpu, (30.0, 0.2, 5000, 16), clouds, n_points=[30000, 1200, 0])
+    # sweep 2 is empty: every row equals BN(ReLU(bias)) -- the zero-padded value
+    assert (feats[2] == feats[2][:, :1]).all()
+
+
+def test_fused_pfn_dense_cells_ncap_and_big_pillars(gpu):
+    """BASELINE config 1 grid: up to 381 points per cell, N-cap at 100 (no padding in
+    those pillars), the ballot-rescan path, and P not a multiple of 4."""
+    from pp_amd import synth
+    _compare(gpu, (50.0, 1.0, 5763, 100), [synth.lidar_like(60000, 50.0, 0)])
+    _compare(gpu, (50.0, 1.0, 3001, 8), [synth.lidar_like(60000, 50.0, 1)], order=1)
+
+
+def test_fused_pipeline_equals_dense_pipeline(gpu):
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    pipe = PillarPipeline(VoxelConfig.square(16.0, 0.2, 4000, 32), feature_channels=64, device=gpu, seed=0)
+    pipe.model.eval()
+    pts = torch.from_numpy(np.stack([synth.lidar_like(15000, 16.0, s) for s in (3, 4)])).to(gpu)
+    c1, r1 = pipe.forward(pts)
+    c2, r2 = pipe.forward_fused(pts)
+    torch.cuda.synchronize()
+    assert (c1 - c2).abs().max().item() <= 1e-4 * max(1.0, c1.abs().max().item())
+    assert (r1 - r2).abs().max().item() <= 1e-4 * max(1.0, r1.abs().max().item())
+    pipe.model.train()
+    with pytest.raises(RuntimeError):
+        pipe.forward_fused(pts)
