@@ -28,6 +28,8 @@
 
 #include "pp_common.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -1153,29 +1155,33 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.pfn_w = pfn_w;
   a.pfn_out = pfn_out;
   const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
-  int slot = -1;
+  // When the timing ring is armed the emit launch carries its own start/stop events
+  // (hipExtLaunchKernelGGL binds them to the dispatch packet, so the pair brackets the
+  // kernel alone, like a profiler's kernel trace, not the gaps around it).
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (timed && ctx->ev_slots > 0) {
-    slot = ctx->ev_next;
-    PP_HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+    ev0 = ctx->ev_start[ctx->ev_next];
+    ev1 = ctx->ev_stop[ctx->ev_next];
+    ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
+    ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
   }
   switch (mode) {
     case kModeDenseVec4:
-      hipLaunchKernelGGL((k_emit<TIn, kModeDenseVec4>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseVec4>), grid_emit, dim3(kEmitThreads), 0, stream,
+                            ev0, ev1, 0, a);
       break;
     case kModeDenseScalar:
-      hipLaunchKernelGGL((k_emit<TIn, kModeDenseScalar>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseScalar>), grid_emit, dim3(kEmitThreads), 0, stream,
+                            ev0, ev1, 0, a);
       break;
     case kModePfn:
-      hipLaunchKernelGGL((k_emit<TIn, kModePfn>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      hipExtLaunchKernelGGL((k_emit<TIn, kModePfn>), grid_emit, dim3(kEmitThreads), 0, stream, ev0,
+                            ev1, 0, a);
       break;
     default:
-      hipLaunchKernelGGL((k_emit<TIn, kModeCompact>), grid_emit, dim3(kEmitThreads), 0, stream, a);
+      hipExtLaunchKernelGGL((k_emit<TIn, kModeCompact>), grid_emit, dim3(kEmitThreads), 0, stream,
+                            ev0, ev1, 0, a);
       break;
-  }
-  if (slot >= 0) {
-    PP_HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
-    ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
-    ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
   }
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;

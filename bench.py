@@ -75,17 +75,24 @@ def main():
                          "assignment, loss forward/backward and the loss-scalar all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-feature-net side measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the contract); gloo only to rehearse the multi-rank "
+                         "code path on a box with fewer GPUs than ranks (all ranks share device 0)")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    ctx = shard.init_from_env("nccl")
+    ctx = shard.init_from_env(a.backend)
     if ctx.world_size != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world_size}: launch with "
                          f"torch.distributed.run --nproc-per-node {a.gpus}")
-    torch.cuda.set_device(ctx.local_rank)
-    dev = torch.device("cuda", ctx.local_rank)
-    torch.backends.cudnn.benchmark = True  # let MIOpen pick its fastest f32 algorithms
+    local_dev = ctx.local_rank if a.backend == "nccl" else ctx.local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    # fwd: let MIOpen search its fastest f32 forward algorithms (seconds, in the warm-up).
+    # train: immediate mode -- the exhaustive search over backward-data / backward-weight
+    # solvers takes minutes and includes naive 90 ms kernels.
+    torch.backends.cudnn.benchmark = (a.mode == "fwd")
 
     cfg = VoxelConfig.square(HALF, STEP, P, N)
     pipe = PillarPipeline(cfg, device=dev, seed=0, with_targets=(a.mode == "train"))
