@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBinThreads) void k_fill(
 // k_emit                                                                      //
 // ------------------------------------------------------------------------- //
 template <typename TIn>
-struct WaveLds {
+struct alignas(16) WaveLds {
   int idx[CAPW];                               // point indices as stored by k_fill (arrival order)
   TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar
   union {
@@ -503,7 +503,7 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
                                            int kbeg, int kend, int lane, int idx0,
                                            typename Rec4<TIn>::type rec0, int idx1,
                                            typename Rec4<TIn>::type rec1, int segbeg[KW],
-                                           int cntk[KW], int T) {
+                                           int segpad[KW], int cntk[KW], int T) {
   const int N = a.N;
   if (lane < T) L.idx[lane] = idx0;
   if (lane + kWave < T) L.idx[lane + kWave] = idx1;
@@ -516,17 +516,18 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
       int k = 0;
 #pragma unroll
       for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
-      int sb = 0, sc = 0;
+      int sb = 0, sc = 0, sp = 0;
 #pragma unroll
       for (int kk = 0; kk < KW; ++kk) {
         sb = (k == kk) ? segbeg[kk] : sb;
         sc = (k == kk) ? cntk[kk] : sc;
+        sp = (k == kk) ? segpad[kk] : sp;
       }
       const int my = it == 0 ? idx0 : idx1;
       const typename Rec4<TIn>::type rec = it == 0 ? rec0 : rec1;
       int r = 0;
       for (int jj = sb; jj < sb + sc; ++jj) r += (L.idx[jj] < my) ? 1 : 0;
-      const int pos = sb + r;
+      const int pos = sp + r;  // sorted arrays use 4-aligned bucket starts (16-byte LDS reads later)
       L.px[pos] = rec.x;
       L.py[pos] = rec.y;
       L.pz[pos] = rec.z;
@@ -544,7 +545,7 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
     int sb = 0, sc = 0;
 #pragma unroll
     for (int kk = 0; kk < KW; ++kk) {
-      sb = (lane == kk) ? segbeg[kk] : sb;
+      sb = (lane == kk) ? segpad[kk] : sb;
       sc = (lane == kk) ? cntk[kk] : sc;
     }
     if (sc > 0) {
@@ -572,13 +573,17 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
     int k = 0;
 #pragma unroll
     for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
-    int sb = 0;
+    int sb = 0, sp = 0;
 #pragma unroll
-    for (int kk = 0; kk < KW; ++kk) sb = (k == kk) ? segbeg[kk] : sb;
+    for (int kk = 0; kk < KW; ++kk) {
+      sb = (k == kk) ? segbeg[kk] : sb;
+      sp = (k == kk) ? segpad[kk] : sp;
+    }
     const int n = j - sb;
+    const int q = sp + n;
     if (n < N) {
       double f[9];
-      point_features((double)L.px[j], (double)L.py[j], (double)L.pz[j], (double)L.pr[j],
+      point_features((double)L.px[q], (double)L.py[q], (double)L.pz[q], (double)L.pr[q],
                      L.cx[k], L.cy[k], L.mean[k], f);
       if (MODE == kModeCompact) {
         double *o = a.feat_out + ((int64_t)b * a.ncap + start0 + j) * 9;
@@ -590,7 +595,7 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
           outb[((int64_t)d * a.P + (p0 + k)) * N + n] = (float)f[d];
       } else {
 #pragma unroll
-        for (int d = 0; d < 9; ++d) L.u.feat[d][j] = (float)f[d];
+        for (int d = 0; d < 9; ++d) L.u.feat[d][q] = (float)f[d];
       }
     }
   }
@@ -609,24 +614,46 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
 // (big) pillar only its head groups are skipped; emit_big_pillar writes those.
 struct SlabGeom {
   unsigned rowf4, N4, magic_n4;
-  int nh[KW];       // head groups (ceil(live/4)) per pillar
-  unsigned pooled;  // bit k: pillar k's features are (will be) in L.u.feat
-  bool aligned;     // (P*N4) % 8 == 0: same line phase for every feature
-  unsigned H4;      // groups >= H4 of every row were zero-filled speculatively
+  unsigned base0;      // first 16-byte group of the wave's slab in feature plane 0
+  unsigned pn4_bytes;  // byte distance between two feature planes
+  int nh[KW];          // head groups (ceil(live/4)) per pillar
+  unsigned pooled;     // bit k: pillar k's features are (will be) in L.u.feat
+  bool aligned;        // one line mask serves all nine planes
+  u64 late_lines;      // bit l: line (base0>>3)+l holds a head group of a pooled pillar
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned d, unsigned magic) {
   return d == 1u ? n : __umulhi(n, magic);  // magic = floor((2^32-1)/d)+1, exact for n*d < 2^32
 }
 
-template <bool LATE, typename TIn>
+__device__ __forceinline__ u64 slab_late_lines(const SlabGeom &sg, unsigned pooled) {
+  u64 m = 0;
+  const unsigned line0 = sg.base0 >> 3;
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) {
+    if (((pooled >> kk) & 1u) && sg.nh[kk] > 0) {
+      const unsigned lo = ((sg.base0 + (unsigned)kk * sg.N4) >> 3) - line0;
+      const unsigned hi = ((sg.base0 + (unsigned)kk * sg.N4 + (unsigned)sg.nh[kk] - 1u) >> 3) - line0;
+      const unsigned w = hi - lo + 1u;
+      m |= (w >= 64u ? ~0ull : ((1ull << w) - 1ull)) << lo;
+    }
+  }
+  return m;
+}
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// Stores go through a buffer descriptor (wave-uniform base of the sweep's output,
+// per-lane 32-bit byte offset, the feature plane as an SGPR offset): nine
+// back-to-back buffer_store_dwordx4 per decision with no 64-bit address math.
+enum { kPassEarly = 0, kPassLate = 1, kPassAll = 2 };
+
+template <int PASS, typename TIn>
 __device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom &sg,
-                                           float4 *__restrict__ out4, int64_t P, int p0,
-                                           int lane, const int segbeg[KW]) {
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t PN4 = P * (int64_t)sg.N4;
-  const unsigned base0 = (unsigned)((int64_t)p0 * sg.N4);
-  float4 *o0 = out4 + (int64_t)p0 * sg.N4;
+                                           __amdgpu_buffer_rsrc_t rs, int lane,
+                                           const int segbeg[KW]) {
+  const v4i_t z4 = {0, 0, 0, 0};
+  const unsigned line0 = sg.base0 >> 3;
   for (unsigned rem = lane; rem < sg.rowf4; rem += kWave) {
     const unsigned k = fastdiv(rem, sg.N4, sg.magic_n4);
     const unsigned n4 = rem - k * sg.N4;
@@ -639,69 +666,39 @@ __device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom
       pooled_k = (k == (unsigned)kk) ? (((sg.pooled >> kk) & 1u) != 0) : pooled_k;
     }
     const bool head = (int)n4 < nhk;
-    bool late = head && pooled_k;
-    if (sg.aligned) {
-      const unsigned line = (base0 + rem) >> 3;
-#pragma unroll
-      for (int kk = 0; kk < KW; ++kk) {
-        const unsigned lo = (base0 + (unsigned)kk * sg.N4) >> 3;
-        const unsigned hi = (base0 + (unsigned)kk * sg.N4 + (unsigned)max(sg.nh[kk], 1) - 1u) >> 3;
-        late = late || (((sg.pooled >> kk) & 1u) && sg.nh[kk] > 0 && line >= lo && line <= hi);
-      }
+    const bool late = sg.aligned ? (((sg.late_lines >> (((sg.base0 + rem) >> 3) - line0)) & 1ull) != 0)
+                                 : (head && pooled_k);
+    const unsigned voff = (sg.base0 + rem) * 16u;
+    bool write_zero, write_head;
+    if (PASS == kPassEarly) {
+      write_zero = !late && !head;
+      write_head = false;
+    } else if (PASS == kPassLate) {
+      write_zero = late && !head;
+      write_head = late && head && pooled_k;
+    } else {  // single pass: the features of every pooled pillar are already in LDS
+      write_zero = !head;
+      write_head = head && pooled_k;
     }
-    if (!LATE) {
-      if (!late && !head && n4 < sg.H4) {
+    if (write_head || write_zero) {
+      v4i_t v[PP_NUM_FEATURES];
 #pragma unroll
-        for (int d = 0; d < PP_NUM_FEATURES; ++d) o0[d * PN4 + rem] = z4;
-      }
-    } else if (late && (head ? pooled_k : n4 < sg.H4)) {
-      if (head) {
-        const int lv = L.live[k];
-        const int j0 = sb + 4 * (int)n4;
-        const int j1 = min(j0 + 1, CAPW - 1), j2 = min(j0 + 2, CAPW - 1), j3 = min(j0 + 3, CAPW - 1);
-        const bool h1 = 4 * (int)n4 + 1 < lv, h2 = 4 * (int)n4 + 2 < lv, h3 = 4 * (int)n4 + 3 < lv;
+      for (int d = 0; d < PP_NUM_FEATURES; ++d) v[d] = z4;
+      if (write_head) {
+        const int lv = L.live[k] - 4 * (int)n4;  // live entries in this 16-byte group (>= 1)
+        const int j0 = sb + 4 * (int)n4;         // 4-aligned: buckets start on 16-byte LDS boundaries
 #pragma unroll
         for (int d = 0; d < PP_NUM_FEATURES; ++d) {
-          const float *fr = L.u.feat[d];
-          float4 v;
-          v.x = fr[j0];
-          v.y = h1 ? fr[j1] : 0.0f;
-          v.z = h2 ? fr[j2] : 0.0f;
-          v.w = h3 ? fr[j3] : 0.0f;
-          o0[d * PN4 + rem] = v;
+          const v4i_t t = *reinterpret_cast<const v4i_t *>(&L.u.feat[d][j0]);
+          v[d].x = t.x;
+          v[d].y = lv > 1 ? t.y : 0;
+          v[d].z = lv > 2 ? t.z : 0;
+          v[d].w = lv > 3 ? t.w : 0;
         }
-      } else {
-#pragma unroll
-        for (int d = 0; d < PP_NUM_FEATURES; ++d) o0[d * PN4 + rem] = z4;
       }
-    }
-  }
-}
-
-// Speculative zero fill: the groups n4 >= H4 of every pillar row hold live data
-// only for pillars with more than 4*H4 points, so they are zero-filled at kernel
-// entry, before ANY load has returned -- two thirds of the kernel's bytes at
-// N = 100.  A pillar that does reach into that region overwrites it later; the
-// overwrite is ordered behind these stores because it depends on loads that were
-// issued after them (vmcnt retires in issue order) and on an explicit wait.
-#ifndef PP_SPEC_H4
-#define PP_SPEC_H4 100000  /* measured: early store bursts delay the loads (profiles/r01/NOTES.md) */
-#endif
-constexpr unsigned kSpecH4 = PP_SPEC_H4;
-
-__device__ __forceinline__ void spec_zero_fill(float4 *__restrict__ out4, int64_t P, int p0,
-                                               unsigned rowf4, unsigned N4, unsigned H4,
-                                               unsigned magic_n4, int lane) {
-  if (H4 >= N4) return;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t PN4 = P * (int64_t)N4;
-  float4 *o0 = out4 + (int64_t)p0 * N4;
-  for (unsigned rem = lane; rem < rowf4; rem += kWave) {
-    const unsigned k = fastdiv(rem, N4, magic_n4);
-    const unsigned n4 = rem - k * N4;
-    if (n4 >= H4) {
 #pragma unroll
-      for (int d = 0; d < PP_NUM_FEATURES; ++d) o0[d * PN4 + rem] = z4;
+      for (int d = 0; d < PP_NUM_FEATURES; ++d)
+        __builtin_amdgcn_raw_buffer_store_b128(v[d], rs, voff, d * sg.pn4_bytes, 0);
     }
   }
 }
@@ -724,7 +721,9 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       c4[i] = make_int4(0, 0, 0, 0);
   }
   WaveLds<TIn> &L = lds[w];
-  const int p0 = (blockIdx.x * kEmitWaves + w) * KW;
+  // wave-uniform by construction; readfirstlane lets the compiler keep everything
+  // derived from it (slab geometry, line masks, buffer offsets) in SGPRs
+  const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kEmitWaves + w) * KW);
   if (p0 >= P) return;
   const int kw_eff = min(KW, P - p0);
   // (1) pillar descriptors: the loads go out first, the speculative fill below
@@ -733,14 +732,17 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   int4 m = make_int4(-1, 0, 0, 0);
   if (lane < KW && p0 + lane < P) m = a.pillar_meta[(int64_t)b * P + p0 + lane];
   SlabGeom sg;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.out + (int64_t)b * 9 * P * N), 0,
+      MODE == kModeDenseVec4 ? (int)(36u * (unsigned)P * (unsigned)N) : 0, 0x00020000);
   if (MODE == kModeDenseVec4) {
     sg.N4 = (unsigned)(N >> 2);
     sg.rowf4 = (unsigned)kw_eff * sg.N4;
     sg.magic_n4 = 0xFFFFFFFFu / sg.N4 + 1u;
-    sg.aligned = (((int64_t)P * sg.N4) & 7) == 0;
-    sg.H4 = min(kSpecH4, sg.N4);
-    spec_zero_fill(reinterpret_cast<float4 *>(a.out + (int64_t)b * 9 * P * N), P, p0, sg.rowf4,
-                   sg.N4, sg.H4, sg.magic_n4, lane);
+    sg.base0 = (unsigned)p0 * sg.N4;
+    sg.pn4_bytes = (unsigned)P * sg.N4 * 16u;
+    sg.aligned = ((((int64_t)P * sg.N4) & 7) == 0) && (KW * sg.N4 / 8 + 2 <= 64);
+    sg.late_lines = 0;
   }
   const int npil = min(tot.x, P);
   if (lane < KW) {
@@ -755,15 +757,17 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     L.cy[lane] = cy;
   }
   wave_sync();
-  int cnts[KW], segbeg[KW];
-  int T = 0;
+  int cnts[KW], segbeg[KW], segpad[KW];
+  int T = 0, Tpad = 0;
 #pragma unroll
   for (int k = 0; k < KW; ++k) {
     cnts[k] = __builtin_amdgcn_readfirstlane(L.cnt[k]);
-    segbeg[k] = T;
+    segbeg[k] = T;       // position in the CSR range / in L.idx
+    segpad[k] = Tpad;    // position in the sorted LDS arrays: 4-aligned bucket starts
     T += cnts[k];
+    Tpad += (cnts[k] + 3) & ~3;
   }
-  const bool pooled = (T <= CAPW);
+  const bool pooled = (Tpad <= CAPW);
   // (2) prefetch the pooled bucket (coalesced: consecutive pillars own consecutive
   //     CSR ranges); consumed after the early zero fill has been issued
   int idx0 = 0, idx1 = 0;
@@ -809,9 +813,14 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
         // pooled together, or alone in its own pass when the pool overflowed
         if (cnts[k] > 0 && (pooled || cnts[k] <= CAPW)) sg.pooled |= 1u << k;
       }
-#ifndef PP_EXP_NO_EARLY
-      store_slab<false, TIn>(L, sg, reinterpret_cast<float4 *>(outb), P, p0, lane, segbeg);
-#endif
+      // Everything fits the LDS pool (the normal case): ONE store pass after the point
+      // phase writes every line whole.  (Measured: a separate zero pass before the
+      // bucket data arrives plus a late pass for the live lines costs 10 us of 34 at
+      // 4 sweeps per launch -- the second pass's issue slots, not its bytes.)
+      if (!pooled || T == 0) {
+        sg.late_lines = slab_late_lines(sg, sg.pooled);
+        store_slab<kPassEarly, TIn>(L, sg, rs, lane, segbeg);
+      }
     } else {
       const int rowf = kw_eff * N;
       const int total = 9 * rowf;
@@ -877,27 +886,17 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
         if (k < kw_eff) o[k] = yv[k];
     }
   };
-#ifdef PP_EXP_NO_POINTS
-  return;
-#endif
   // (4) the points
   if (T == 0) {
     if constexpr (MODE == kModePfn) pfn_finish();
     return;
   }
-  if (MODE == kModeDenseVec4) {
-    bool deep = false;  // some pillar's live data reaches the speculatively zeroed groups
-#pragma unroll
-    for (int k = 0; k < KW; ++k) deep = deep || (sg.nh[k] > (int)sg.H4);
-    if (deep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
   if (pooled) {
-    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx0, rec0, idx1, rec1, segbeg, cnts, T);
-    if (MODE == kModeDenseVec4)
-      store_slab<true, TIn>(L, sg, reinterpret_cast<float4 *>(outb), P, p0, lane, segbeg);
+    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx0, rec0, idx1, rec1, segbeg, segpad, cnts, T);
+    if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn>(L, sg, rs, lane, segpad);
     if constexpr (MODE == kModePfn) {
 #pragma unroll
-      for (int k = 0; k < KW; ++k) pfn_fold(k, segbeg[k], min(cnts[k], N));
+      for (int k = 0; k < KW; ++k) pfn_fold(k, segpad[k], min(cnts[k], N));
     }
   } else {
     // the pool overflowed: one pillar at a time
@@ -923,7 +922,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
           idx1 = sidx[lane + kWave];
           rec1 = srec[lane + kWave];
         }
-        emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane, idx0, rec0, idx1, rec1, sb1, ck1, c);
+        emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane, idx0, rec0, idx1, rec1, sb1, sb1, ck1, c);
         if constexpr (MODE == kModePfn) {
           pfn_fold(k, 0, min(c, N));
           wave_sync();
@@ -934,7 +933,8 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
           // (both passes write identical zeros outside their own head groups)
           SlabGeom s1 = sg;
           s1.pooled = 1u << k;
-          store_slab<true, TIn>(L, s1, reinterpret_cast<float4 *>(outb), P, p0, lane, sb1);
+          s1.late_lines = slab_late_lines(sg, 1u << k);
+          store_slab<kPassLate, TIn>(L, s1, rs, lane, sb1);
         }
       } else {
         if constexpr (MODE == kModePfn) {
@@ -1227,8 +1227,8 @@ extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points
     return PP_ERR_VALUE;
   }
   const int P = prm->max_pillars, N = prm->max_points_per_pillar;
-  if (P < 1 || N < 1 || N > 65536 || (long long)P * N > (1ll << 31) / 16) {
-    set_error("need 1 <= max_pillars, 1 <= max_points_per_pillar <= 65536 and P*N < 2^27 "
+  if (P < 1 || N < 1 || N > 65536 || (long long)P * N > 100000000ll) {
+    set_error("need 1 <= max_pillars, 1 <= max_points_per_pillar <= 65536 and P*N <= 1e8 "
               "(got P=%d N=%d)", P, N);
     return PP_ERR_VALUE;
   }
