@@ -66,6 +66,7 @@ struct pp_ctx {
   pp::PinBuf pin_in, pin_out, pin_meta;
   // IoU / target scratch
   pp::DevBuf iou_ws;
+  unsigned long long tgt_key = 0;  // shape the target scratch was last armed for
   // emit-kernel timing ring (bench.py)
   std::vector<hipEvent_t> ev_start, ev_stop;
   int ev_slots = 0;

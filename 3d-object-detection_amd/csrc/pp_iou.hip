@@ -20,7 +20,7 @@
 
 namespace pp {
 
-constexpr int kIouThreads = 256;
+constexpr int kIouThreads = 128;  // 16 LDS vertex slots x 16 B per thread = 32 KB per workgroup
 using u64 = unsigned long long;
 
 __device__ __forceinline__ double shoelace_dev(const double *q, int n) {
@@ -35,38 +35,54 @@ __device__ __forceinline__ double shoelace_dev(const double *q, int n) {
 // pillars.cpp:132-172 for one pair.  a: anchor corners, declared counter-
 // clockwise; g: ground-truth corners, declared clockwise.  *bad is set when a
 // declared-orientation area is negative (the reference's "IOU < 0" exit).
-__device__ double iou_pair_dev(const double a[8], const double g[8], bool *bad) {
+// The two ping-pong vertex lists (at most 8 vertices each) live in LDS, slot-major
+// ([16 slots][block threads], 16 B per vertex): lanes of a wave touch consecutive
+// 16-byte words, and a dynamically indexed private array would go to scratch
+// (global memory) -- the clip is a chain of dependent reads and writes.
+struct PolyLds {
+  double2 *base;  // &lds[threadIdx.x]
+  int stride;     // block threads
+  __device__ __forceinline__ double2 &at(int list, int v) const {
+    return base[(list * 8 + v) * stride];
+  }
+};
+
+__device__ double iou_pair_dev(const double a[8], const double g[8], bool *bad, const PolyLds &pl) {
   const double area_a = shoelace_dev(a, 4);
   const double area_g = -shoelace_dev(g, 4);
   if (area_a < 0.0 || area_g < 0.0) {
     *bad = true;
     return -1.0;
   }
-  double poly[2][16];
   int n = 4, cur = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) poly[0][k] = a[k];
+  for (int k = 0; k < 4; ++k) pl.at(0, k) = make_double2(a[2 * k], a[2 * k + 1]);
   for (int e = 0; e < 4 && n > 0; ++e) {
     const int ia = (4 - e) & 3, ib = (3 - e) & 3;
-    const double ax = g[2 * ia], ay = g[2 * ia + 1];
-    const double ex = g[2 * ib] - ax, ey = g[2 * ib + 1] - ay;
-    const double *in = poly[cur];
-    double *out = poly[cur ^ 1];
+    double ax = 0, ay = 0, bx = 0, by = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // static indexing keeps g[] in registers
+      ax = (k == ia) ? g[2 * k] : ax;
+      ay = (k == ia) ? g[2 * k + 1] : ay;
+      bx = (k == ib) ? g[2 * k] : bx;
+      by = (k == ib) ? g[2 * k + 1] : by;
+    }
+    const double ex = bx - ax, ey = by - ay;
     int m = 0;
-    double px = in[2 * (n - 1)], py = in[2 * (n - 1) + 1];
+    const double2 last = pl.at(cur, n - 1);
+    double px = last.x, py = last.y;
     double dp = ex * (py - ay) - ey * (px - ax);
     for (int i = 0; i < n; ++i) {
-      const double cx = in[2 * i], cy = in[2 * i + 1];
+      const double2 c = pl.at(cur, i);
+      const double cx = c.x, cy = c.y;
       const double dc = ex * (cy - ay) - ey * (cx - ax);
       if ((dc >= 0.0) != (dp >= 0.0)) {
         const double t = dp / (dp - dc);
-        out[2 * m] = px + t * (cx - px);
-        out[2 * m + 1] = py + t * (cy - py);
+        pl.at(cur ^ 1, m) = make_double2(px + t * (cx - px), py + t * (cy - py));
         ++m;
       }
       if (dc >= 0.0) {
-        out[2 * m] = cx;
-        out[2 * m + 1] = cy;
+        pl.at(cur ^ 1, m) = make_double2(cx, cy);
         ++m;
       }
       px = cx;
@@ -77,7 +93,14 @@ __device__ double iou_pair_dev(const double a[8], const double g[8], bool *bad) 
     cur ^= 1;
   }
   if (n < 3) return 0.0;
-  const double inter = shoelace_dev(poly[cur], n);
+  // shoelace over the clipped ring, same operation order as shoelace_dev
+  double s = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const int j = (k + 1 == n) ? 0 : k + 1;
+    const double2 vk = pl.at(cur, k), vj = pl.at(cur, j);
+    s = s + (vk.x * vj.y - vj.x * vk.y);
+  }
+  const double inter = 0.5 * s;
   if (!(inter > 0.0)) return 0.0;
   return inter / (area_a + area_g - inter);
 }
@@ -94,6 +117,8 @@ __global__ __launch_bounds__(kIouThreads) void k_make_ious(
     const double *__restrict__ a_corners, const double *__restrict__ a_centers, int acols,
     int64_t A, const double *__restrict__ g_corners, const double *__restrict__ g_centers,
     int gcols, int G, double *__restrict__ ious, int *errflag) {
+  __shared__ double2 s_poly[16 * kIouThreads];
+  const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
   const int64_t total = A * G;
   for (int64_t e = (int64_t)blockIdx.x * kIouThreads + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * kIouThreads) {
@@ -110,7 +135,7 @@ __global__ __launch_bounds__(kIouThreads) void k_make_ious(
         g[k] = g_corners[(int64_t)j * 8 + k];
       }
       bool bad = false;
-      v = iou_pair_dev(a, g, &bad);
+      v = iou_pair_dev(a, g, &bad, pl);
       if (bad) atomicExch(errflag, 1);
     }
     ious[e] = v;
@@ -132,6 +157,10 @@ struct TargetArgs {
   u64 *col_max;  // [G] bit pattern of the column maximum IoU (0 = all zero)
   int *col_arg;  // [G] first anchor reaching the column maximum
   int *errflag;
+  // (anchor, gt, IoU bits) of every pair with IoU > 0, appended by k_targets_rows
+  int4 *cand;       // [cand_cap] {anchor, gt, iou lo, iou hi}
+  int cand_cap;
+  unsigned *cand_count;  // entries appended (may exceed cand_cap: then k_targets_cols re-scans)
   // outputs
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
@@ -175,21 +204,25 @@ __device__ void make_target_dev(const TargetArgs &t, int64_t i, int j, float out
   out[8] = (float)ort;
 }
 
-__device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad) {
+__device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad,
+                                           const PolyLds &pl) {
   double a[8], g[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     a[k] = t.a_corners[i * 8 + k];
     g[k] = t.g_corners[(int64_t)j * 8 + k];
   }
-  return iou_pair_dev(a, g, bad);
+  return iou_pair_dev(a, g, bad, pl);
 }
 
 // T1: one lane per anchor.  Row maximum / first argmax over the ground truths
 // (box_utils.py:193-196), positive rows of both targets (:211, :219-221),
-// zero rows otherwise, and the column maxima via 64-bit atomicMax on the f64
-// bit pattern (IoU >= 0, so the patterns order like the values).
+// zero rows otherwise, the column maxima via 64-bit atomicMax on the f64 bit
+// pattern (IoU >= 0, so the patterns order like the values), and the list of
+// pairs with IoU > 0 for the column-argmax pass.
 __global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
+  __shared__ double2 s_poly[16 * kIouThreads];
+  const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
   const int64_t i = (int64_t)blockIdx.x * kIouThreads + threadIdx.x;
   if (i >= t.A) return;
   const double acx = t.a_centers[i * 3], acy = t.a_centers[i * 3 + 1];
@@ -199,12 +232,18 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
   for (int j = 0; j < t.G; ++j) {
     const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
     if (gate_far(acx, acy, gcx, gcy)) continue;
-    const double v = pair_iou(t, i, j, &bad);
+    const double v = pair_iou(t, i, j, &bad, pl);
     if (v > best) {  // strict: first maximum wins, like np.argmax
       best = v;
       best_j = j;
     }
-    if (v > 0.0) atomicMax(&t.col_max[j], (u64)__double_as_longlong(v));
+    if (v > 0.0) {
+      const u64 bits = (u64)__double_as_longlong(v);
+      atomicMax(&t.col_max[j], bits);
+      const unsigned pos = atomicAdd(t.cand_count, 1u);
+      if (pos < (unsigned)t.cand_cap)
+        t.cand[pos] = make_int4((int)i, j, (int)(bits & 0xFFFFFFFFull), (int)(bits >> 32));
+    }
   }
   if (bad) atomicExch(t.errflag, 1);
   float *cls = t.cls_targets + i * t.num_classes;
@@ -219,17 +258,30 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
 }
 
 // T2: first anchor index that reaches each column maximum (np.argmax over the
-// transposed matrix, box_utils.py:199-200).  Recomputes the (deterministic)
-// IoU of the gated pairs instead of storing candidates.
+// transposed matrix, box_utils.py:199-200): one lane per listed pair.  If the
+// list overflowed (more pairs with IoU > 0 than anchors: never on real scenes),
+// every lane re-scans its anchor instead -- the IoU is deterministic, so the
+// recomputed bits are identical.
 __global__ __launch_bounds__(kIouThreads) void k_targets_cols(TargetArgs t) {
+  __shared__ double2 s_poly[16 * kIouThreads];
   const int64_t i = (int64_t)blockIdx.x * kIouThreads + threadIdx.x;
+  const unsigned count = *t.cand_count;
+  if (count <= (unsigned)t.cand_cap) {
+    if (i < count) {
+      const int4 c = t.cand[i];
+      const u64 bits = ((u64)(unsigned)c.w << 32) | (unsigned)c.z;
+      if (bits == t.col_max[c.y]) atomicMin(&t.col_arg[c.y], c.x);
+    }
+    return;
+  }
   if (i >= t.A) return;
+  const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
   const double acx = t.a_centers[i * 3], acy = t.a_centers[i * 3 + 1];
   bool bad = false;
   for (int j = 0; j < t.G; ++j) {
     const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
     if (gate_far(acx, acy, gcx, gcy)) continue;
-    const double v = pair_iou(t, i, j, &bad);
+    const double v = pair_iou(t, i, j, &bad, pl);
     if (v > 0.0 && (u64)__double_as_longlong(v) == t.col_max[j]) atomicMin(&t.col_arg[j], (int)i);
   }
 }
@@ -268,15 +320,26 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_forced(TargetArgs t) {
       for (int d = 0; d < 9; ++d) reg[d] = r[d];
     }
   }
+  // re-arm the scratch words for the next call on this context
+  __syncthreads();
+  for (int j = threadIdx.x; j < G; j += kIouThreads) {
+    t.col_max[j] = 0ull;
+    t.col_arg[j] = INT_MAX;
+  }
+  if (threadIdx.x == 0) *t.cand_count = 0u;
 }
 
-__global__ void k_targets_init(u64 *col_max, int *col_arg, int G, int *errflag) {
+__global__ void k_targets_init(u64 *col_max, int *col_arg, int G, int *errflag,
+                               unsigned *cand_count) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < G) {
     col_max[j] = 0ull;
     col_arg[j] = INT_MAX;
   }
-  if (j == 0) *errflag = 0;
+  if (j == 0) {
+    *errflag = 0;
+    *cand_count = 0u;
+  }
 }
 
 namespace {
@@ -343,6 +406,8 @@ extern "C" int pp_iou_check(pp_ctx_t *ctx, void *stream_) {
                             static_cast<hipStream_t>(stream_)));
   PP_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
   if (flag) {
+    // the flag is sticky across launches until it has been reported once
+    PP_HIP_TRY(hipMemsetAsync(ctx->iou_ws.ptr, 0, 4, static_cast<hipStream_t>(stream_)));
     set_error("IOU < 0: a box has the wrong corner winding (pillars.cpp:166-169)");
     return PP_ERR_WINDING;
   }
@@ -443,8 +508,13 @@ extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard2 guard(ctx->device);
-  const size_t need = 4096 + (size_t)std::max<int64_t>(G, 1) * 16;
-  int rc = ctx->iou_ws.ensure(need);
+  // scratch: [0,4096) flags/counters | col_max[Gcap] | col_arg[Gcap] | cand[A]
+  const size_t gcap = (size_t)std::max<int64_t>(G, 1);
+  const size_t off_cmax = 4096, off_carg = off_cmax + gcap * 8;
+  const size_t off_cand = (off_carg + gcap * 4 + 255) / 256 * 256;
+  const size_t need = off_cand + (size_t)A * 16;
+  bool grew = false;
+  int rc = ctx->iou_ws.ensure(need, &grew);
   if (rc) return rc;
   char *ws = static_cast<char *>(ctx->iou_ws.ptr);
   TargetArgs t;
@@ -464,13 +534,22 @@ extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
   t.canvas_height = prm->canvas_height;
   t.num_classes = prm->num_classes;
   t.errflag = reinterpret_cast<int *>(ws);
-  t.col_max = reinterpret_cast<u64 *>(ws + 4096);
-  t.col_arg = reinterpret_cast<int *>(ws + 4096 + (size_t)std::max<int64_t>(G, 1) * 8);
+  t.cand_count = reinterpret_cast<unsigned *>(ws + 64);
+  t.col_max = reinterpret_cast<u64 *>(ws + off_cmax);
+  t.col_arg = reinterpret_cast<int *>(ws + off_carg);
+  t.cand = reinterpret_cast<int4 *>(ws + off_cand);
+  t.cand_cap = (int)A;
   t.cls_targets = cls_targets;
   t.reg_targets = reg_targets;
-  const unsigned gb = (unsigned)((std::max<int64_t>(G, 1) + 255) / 256);
-  hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_arg,
-                     (int)G, t.errflag);
+  // The scratch words are re-armed by k_targets_forced at the end of every call; only a
+  // fresh / regrown / re-shaped workspace (or a call without ground truths) needs the init.
+  const unsigned long long key = ((unsigned long long)A << 20) ^ (unsigned long long)gcap;
+  if (grew || ctx->tgt_key != key || G == 0) {
+    const unsigned gb = (unsigned)((gcap + 255) / 256);
+    hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_arg,
+                       (int)G, t.errflag, t.cand_count);
+    ctx->tgt_key = key;
+  }
   const unsigned ab = (unsigned)((A + kIouThreads - 1) / kIouThreads);
   hipLaunchKernelGGL(k_targets_rows, dim3(ab), dim3(kIouThreads), 0, stream, t);
   if (G > 0) {

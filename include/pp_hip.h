@@ -129,10 +129,10 @@ int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
                      const void *g_centers, const int64_t gn_strides[2],
                      void *ious, const int64_t io_strides[2]);
 
-/* Error flag of the most recent IoU / target-assignment launch on this
- * context: synchronises `stream`, returns PP_ERR_WINDING if a pair that passed
- * the centre gate had a wrongly wound box (the reference's "IOU < 0" exit,
- * pillars.cpp:166-169), else PP_OK.  pp_make_ious_f64 calls it itself. */
+/* Error flag of the IoU / target-assignment launches on this context since the
+ * last check: synchronises `stream`, returns PP_ERR_WINDING (and clears the flag)
+ * if a pair that passed the centre gate had a wrongly wound box (the reference's
+ * "IOU < 0" exit, pillars.cpp:166-169), else PP_OK.  pp_make_ious_f64 calls it itself. */
 int pp_iou_check(pp_ctx_t *ctx, void *stream);
 
 /* Device-resident make_ious: contiguous f64 device arrays, ious_dev [A][G]. */
