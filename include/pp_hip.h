@@ -171,6 +171,22 @@ int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream, int64_t A,
                           const pp_target_params_t *prm, float *cls_targets,
                           float *reg_targets);
 
+/*
+ * Lidar sweep ingest pre-pass: replaces, per sweep, the point
+ * preparation of PPDataset.__getitem__ (data/dataset.py:65-82) --
+ * LidarPointCloud.from_file rows (first four f32 columns of `raw_cols`),
+ * .transform(transmat) in f64 stored as f32, .remove_close(min_dist) and the
+ * hstack aggregation (write sweep s at points_out_dev + 4*offset_s).
+ *   raw_dev        [n_points][raw_cols] f32 (the .bin file's rows), device memory
+ *   transform      row-major 4x4 f64 HOST matrix (ref_car_from_global . global_from_car
+ *                  . car_from_sensor, dataset.py:76)
+ *   points_out_dev [n_points][4] f32; a removed point keeps its row with x = NaN,
+ *                  which pp_voxelize_dev drops, so input order is preserved.
+ */
+int pp_ingest_dev(pp_ctx_t *ctx, void *stream, const float *raw_dev, int64_t n_points,
+                  int raw_cols, const double *transform_rowmajor4x4, double min_dist,
+                  float *points_out_dev);
+
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
  * stream around the k_emit launch.  pp_ctx_read_emit_ms synchronises on the

@@ -311,3 +311,26 @@ def create_target(anchor_corners, gt_corners, anchor_centers, gt_centers_img,
                                            anchor_yaw[anch], gt_centers_canvas[g],
                                            gt_wlh[g], gt_yaw[g], canvas_height)
     return cls_targets, reg_targets, ious
+
+
+# --------------------------------------------------------------------------- #
+# lidar ingest: data/dataset.py:51-88 (lyft_dataset_sdk LidarPointCloud, RECALLED)#
+# --------------------------------------------------------------------------- #
+
+def lidar_ingest(sweeps, min_dist=0.001):
+    """np restatement of the sweep loop of PPDataset.__getitem__ (dataset.py:54-88):
+    for each (raw[n,C] f32, transmat 4x4 f64): from_file keeps the first four
+    columns as a float32 [4,n] array; transform() computes
+    transmat.dot(vstack(points[:3], ones)) in f64 and stores it back as f32;
+    remove_close() drops points with |x| < r and |y| < r; sweeps are hstacked.
+    Returns the [n_kept, 4] f64 array create_pillars receives (dataset.py:88)."""
+    agg = np.zeros((4, 0))
+    for raw, mat in sweeps:
+        pts = np.asarray(raw, np.float32)[:, :4].T.copy()                    # [4,n] f32
+        mat = np.asarray(mat, np.float64).reshape(4, 4)
+        pts[:3, :] = mat.dot(np.vstack((pts[:3, :], np.ones(pts.shape[1]))))[:3, :]
+        x_filt = np.abs(pts[0, :]) < min_dist
+        y_filt = np.abs(pts[1, :]) < min_dist
+        pts = pts[:, np.logical_not(np.logical_and(x_filt, y_filt))]
+        agg = np.hstack((agg, pts))
+    return agg.transpose([1, 0])

@@ -95,3 +95,21 @@ def test_anchor_grid_layout(oracle):
     assert abs(area(corners[0]) - 250) < 1e-9
     c_img, k_img = O.boxes_to_image_space([[5., 7, 1]], [[2., 4, 1]], [0.3], 20)
     assert area(k_img[0]) < 0 and c_img[0, 1] == 12.0              # clockwise after the y flip
+
+
+def test_lidar_ingest_restatement(oracle):
+    """dataset.py:65-88 via the (recalled) LidarPointCloud semantics: first four f32
+    columns, f64 rigid transform stored as f32, remove_close needs BOTH |x| and |y|
+    inside the radius, sweeps are concatenated in order."""
+    raw = np.array([[1, 2, 3, 9, 7], [0.0005, -0.0005, 5, 8, 7], [0.0005, 2, 0, 6, 7], [0.5, 0.25, -1, 4, 7]],
+                   np.float32)
+    out = oracle.lidar_ingest([(raw, np.eye(4))])
+    assert out.shape == (3, 4) and out[:, 3].tolist() == [9, 6, 4]        # row 1 removed only
+    shift = np.eye(4)
+    shift[:3, 3] = [10, 20, 30]
+    rot = np.eye(4)
+    rot[:2, :2] = [[0, -1], [1, 0]]
+    out2 = oracle.lidar_ingest([(raw, shift), (raw[:1], rot)])
+    assert out2.shape == (5, 4)
+    assert out2[0].tolist() == [11, 22, 33, 9] and out2[4].tolist() == [-2, 1, 3, 9]
+    assert out2.dtype == np.float64 and np.array_equal(out2, out2.astype(np.float32))
