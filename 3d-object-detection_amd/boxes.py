@@ -84,8 +84,14 @@ def make_anchors(cfg: AnchorConfig):
     wlh = dims[d]
     yaw = np.deg2rad(np.asarray(cfg.yaws_deg, np.float64))[d]
     corners = bottom_corners_xy(centers, wlh, yaw)
+    # box_utils.py:152-155: (x1,y1,x2,y2) rows of anchor_xy.pkl -- corners 1,3 for the
+    # rotated anchors (yaw > 0), corners 2,0 for the others
+    rot = (np.asarray(cfg.yaws_deg, np.float64)[d] > 0)[:, None]
+    xy = np.where(rot, np.concatenate([corners[:, 1], corners[:, 3]], 1),
+                  np.concatenate([corners[:, 2], corners[:, 0]], 1))
     return {"corners": np.ascontiguousarray(corners), "centers": np.ascontiguousarray(centers),
-            "wlh": np.ascontiguousarray(wlh), "yaw": np.ascontiguousarray(yaw)}
+            "wlh": np.ascontiguousarray(wlh), "yaw": np.ascontiguousarray(yaw),
+            "xy": np.ascontiguousarray(xy)}
 
 
 def boxes_to_image_space(centers, wlh, yaw, canvas_height):

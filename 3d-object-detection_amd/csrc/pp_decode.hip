@@ -1,0 +1,283 @@
+// pp_decode.hip -- inference post-processing on the device.
+//
+// Replaces the per-sample tail of evaluate() / evaluate_single()
+// (/root/reference evaluate.py:231-245 and :146-158): sigmoid over the class
+// logits, tanh on regression element 6, max/argmax over classes, score threshold
+// (cfg.DATA.VAL_POS_THRESH), axis-aligned greedy NMS over the ANCHOR rectangles
+// (box_nms, evaluate.py:127-139, torchvision.ops.nms), the first 100 survivors,
+// make_pred_boxes (:33-89) and move_box_to_car_space (:91-125).
+//
+// torchvision is absent from the image; torchvision.ops.nms is restated from its
+// published CPU kernel: boxes in decreasing score order, a box is dropped when its
+// IoU with an already kept box exceeds the threshold, areas/intersections in f32.
+//
+// Kernels: k_score (one lane per anchor -> 44-bit sort key or sentinel), rocPRIM
+// device radix sort of the keys (library utility; keys are unique, so the order is
+// deterministic), k_nms (one workgroup, 256-candidate chunks: kept-list test, then
+// an in-chunk suppression matrix resolved serially), k_decode (one lane per kept box).
+
+#include <cstring>
+
+#include "pp_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace pp {
+
+using u64 = unsigned long long;
+constexpr u64 kSentinel = ~0ull;
+constexpr int kNmsThreads = 256;
+constexpr int kMaxOut = 1024;
+
+struct DecodeArgs {
+  const float *cls;  // [Ac*C][H][W]
+  const float *reg;  // [Ac*8][H][W]
+  const double *a_centers, *a_wlh, *a_yaw, *a_xy;
+  int A, Ac, C, HW;
+  float pos_thresh, nms_thresh;
+  int max_out;
+  double canvas_height, x_step, y_step, x_min, y_min;
+  u64 *keys;
+  int *kept;      // [max_out] anchor ids in keep order
+  int *count;     // number kept
+  double *boxes;  // [max_out][9] x,y,z,w,l,h,yaw,score,class
+};
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// scores,classes = torch.max(torch.sigmoid(cls), dim=-1)   (evaluate.py:231-235)
+__device__ __forceinline__ void anchor_score(const DecodeArgs &d, int a, float &score, int &klass) {
+  const int cell = a / d.Ac, k = a - cell * d.Ac;
+  const float *p = d.cls + (int64_t)(k * d.C) * d.HW + cell;
+  score = -1.0f;
+  klass = 0;
+  for (int c = 0; c < d.C; ++c) {
+    const float s = sigmoidf_ref(p[(int64_t)c * d.HW]);
+    if (s > score) {  // first maximum wins
+      score = s;
+      klass = c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_score(DecodeArgs d) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= d.A) return;
+  float s;
+  int c;
+  anchor_score(d, a, s, c);
+  u64 key = kSentinel;
+  if (s > d.pos_thresh) {  // evaluate.py:237 (strict >)
+    // decreasing score, then increasing anchor id; s in (0,1] so its bit pattern orders like s
+    const unsigned sb = (unsigned)__float_as_int(s);
+    key = ((u64)(0x3F800000u - sb) << 20) | (u64)a;
+  }
+  d.keys[a] = key;
+}
+
+struct NmsBox {
+  float x1, y1, x2, y2, area;
+};
+
+// box_nms, evaluate.py:127-139: anchor_xy as float32, rows 1 and 3 flipped with (H-1) - y
+__device__ __forceinline__ NmsBox load_box(const DecodeArgs &d, int a) {
+  NmsBox b;
+  const float h1 = (float)(d.canvas_height - 1);
+  b.x1 = (float)d.a_xy[(int64_t)a * 4 + 0];
+  b.y1 = h1 - (float)d.a_xy[(int64_t)a * 4 + 1];
+  b.x2 = (float)d.a_xy[(int64_t)a * 4 + 2];
+  b.y2 = h1 - (float)d.a_xy[(int64_t)a * 4 + 3];
+  b.area = (b.x2 - b.x1) * (b.y2 - b.y1);
+  return b;
+}
+
+// torchvision nms_kernel (CPU): ovr = inter / (iarea + areas[j] - inter), suppressed if ovr > thresh
+__device__ __forceinline__ bool suppresses(const NmsBox &i, const NmsBox &j, float thresh) {
+  const float xx1 = fmaxf(i.x1, j.x1), yy1 = fmaxf(i.y1, j.y1);
+  const float xx2 = fminf(i.x2, j.x2), yy2 = fminf(i.y2, j.y2);
+  const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (i.area + j.area - inter);
+  return ovr > thresh;
+}
+
+__global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
+  __shared__ NmsBox s_kept[kMaxOut];
+  __shared__ NmsBox s_chunk[kNmsThreads];
+  __shared__ u64 s_mask[kNmsThreads][kNmsThreads / 64];  // s_mask[i]: later chunk members i suppresses
+  __shared__ int s_alive[kNmsThreads];
+  __shared__ int s_id[kNmsThreads];
+  __shared__ int s_nkept, s_done;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    s_nkept = 0;
+    s_done = 0;
+  }
+  for (int i = t; i < d.max_out; i += kNmsThreads) d.kept[i] = -1;
+  __syncthreads();
+  for (int c0 = 0; c0 < d.A; c0 += kNmsThreads) {
+    const int nk = s_nkept;
+    const u64 key = (c0 + t < d.A) ? d.keys[c0 + t] : kSentinel;
+    const bool valid = key != kSentinel;
+    const int a = (int)(key & 0xFFFFFull);
+    NmsBox b = {0, 0, 0, 0, 0};
+    int alive = 0;
+    if (valid) {
+      b = load_box(d, a);
+      alive = 1;
+      for (int k = 0; k < nk && alive; ++k)
+        if (suppresses(s_kept[k], b, d.nms_thresh)) alive = 0;
+    }
+    s_chunk[t] = b;
+    s_alive[t] = alive;
+    s_id[t] = a;
+    __syncthreads();
+    // suppression matrix inside the chunk: bit j of s_mask[t] = (j > t and t suppresses j)
+    {
+      u64 m[kNmsThreads / 64] = {0, 0, 0, 0};
+      if (alive) {
+        for (int j = t + 1; j < kNmsThreads; ++j)
+          if (s_alive[j] && suppresses(b, s_chunk[j], d.nms_thresh)) m[j >> 6] |= 1ull << (j & 63);
+      }
+#pragma unroll
+      for (int w = 0; w < kNmsThreads / 64; ++w) s_mask[t][w] = m[w];
+    }
+    __syncthreads();
+    if (t == 0) {
+      u64 removed[kNmsThreads / 64] = {0, 0, 0, 0};
+      int n = s_nkept;
+      for (int i = 0; i < kNmsThreads && n < d.max_out; ++i) {
+        if (!s_alive[i] || ((removed[i >> 6] >> (i & 63)) & 1ull)) continue;
+        s_kept[n] = s_chunk[i];
+        d.kept[n] = s_id[i];
+        ++n;
+#pragma unroll
+        for (int w = 0; w < kNmsThreads / 64; ++w) removed[w] |= s_mask[i][w];
+      }
+      s_nkept = n;
+      // sorted keys: the first sentinel ends the candidates
+      s_done = (n >= d.max_out) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_done || !__syncthreads_or(valid && t == kNmsThreads - 1)) break;
+  }
+  if (t == 0) *d.count = s_nkept;
+}
+
+// make_pred_boxes (evaluate.py:33-89) + move_box_to_car_space (:91-125, image=True)
+__global__ void k_decode(DecodeArgs d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.max_out) return;
+  double *o = d.boxes + (int64_t)i * 9;
+  const int a = d.kept[i];
+  if (a < 0) {
+    for (int k = 0; k < 9; ++k) o[k] = 0.0;
+    return;
+  }
+  float score;
+  int klass;
+  anchor_score(d, a, score, klass);
+  const int cell = a / d.Ac, k = a - cell * d.Ac;
+  float off[8];
+  for (int r = 0; r < 8; ++r) off[r] = d.reg[(int64_t)(k * 8 + r) * d.HW + cell];
+  off[6] = tanhf(off[6]);  // evaluate.py:234
+  const double ax = d.a_centers[(int64_t)a * 3], ay = d.a_centers[(int64_t)a * 3 + 1],
+               az = d.a_centers[(int64_t)a * 3 + 2];
+  const double aw = d.a_wlh[(int64_t)a * 3], al = d.a_wlh[(int64_t)a * 3 + 1],
+               ah = d.a_wlh[(int64_t)a * 3 + 2];
+  const double diag = sqrt(aw * aw + al * al);
+  const double bx = ax + (double)off[0] * diag;
+  const double by = ay + (double)off[1] * diag;
+  const double bz = az + (double)off[2] * ah;
+  const double bw = (double)expf(off[3]) * aw;  // np.exp of a float32 scalar is float32
+  const double bl = (double)expf(off[4]) * al;
+  const double bh = (double)expf(off[5]) * ah;
+  const double yaw = (double)asinf(off[6]) + d.a_yaw[a];
+  const double y = (d.canvas_height - 1) - by;
+  o[0] = bx * d.x_step + d.x_min;
+  o[1] = y * d.y_step + d.y_min;
+  o[2] = bz;
+  o[3] = bw * d.y_step;
+  o[4] = bl * d.x_step;
+  o[5] = bh;
+  o[6] = yaw;
+  o[7] = (double)score;
+  o[8] = (double)klass;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev, const float *reg_dev,
+                             const double *a_centers, const double *a_wlh, const double *a_yaw,
+                             const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
+                             int32_t *kept_out, int32_t *count_out) {
+  if (!ctx || !cls_dev || !reg_dev || !a_centers || !a_wlh || !a_yaw || !a_xy || !prm || !boxes_out ||
+      !kept_out || !count_out) {
+    set_error("pp_decode_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  const int64_t A = (int64_t)prm->fm_height * prm->fm_width * prm->anchors_per_cell;
+  if (prm->fm_height < 1 || prm->fm_width < 1 || prm->anchors_per_cell < 1 || prm->num_classes < 1 ||
+      A >= (1 << 20) || prm->max_out < 1 || prm->max_out > kMaxOut) {
+    set_error("pp_decode_dev: need 1 <= anchors < 2^20 and 1 <= max_out <= %d", kMaxOut);
+    return PP_ERR_VALUE;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+  struct Restore {
+    int prev, dev;
+    ~Restore() {
+      if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+  } restore{prev, ctx->device};
+  size_t tmp_bytes = 0;
+  u64 *null_keys = nullptr;
+  if (rocprim::radix_sort_keys(nullptr, tmp_bytes, null_keys, null_keys, (size_t)A, 0, 44, stream) !=
+      hipSuccess) {
+    set_error("rocprim::radix_sort_keys size query failed");
+    return PP_ERR_HIP;
+  }
+  const size_t keys_bytes = ((size_t)A * 8 + 255) / 256 * 256;
+  int rc = ctx->decode_ws.ensure(2 * keys_bytes + tmp_bytes + 256);
+  if (rc) return rc;
+  char *ws = static_cast<char *>(ctx->decode_ws.ptr);
+  DecodeArgs d;
+  d.cls = cls_dev;
+  d.reg = reg_dev;
+  d.a_centers = a_centers;
+  d.a_wlh = a_wlh;
+  d.a_yaw = a_yaw;
+  d.a_xy = a_xy;
+  d.A = (int)A;
+  d.Ac = prm->anchors_per_cell;
+  d.C = prm->num_classes;
+  d.HW = prm->fm_height * prm->fm_width;
+  d.pos_thresh = (float)prm->pos_thresh;
+  d.nms_thresh = (float)prm->nms_thresh;
+  d.max_out = prm->max_out;
+  d.canvas_height = prm->canvas_height;
+  d.x_step = prm->x_step;
+  d.y_step = prm->y_step;
+  d.x_min = prm->x_min;
+  d.y_min = prm->y_min;
+  d.keys = reinterpret_cast<u64 *>(ws);
+  u64 *sorted = reinterpret_cast<u64 *>(ws + keys_bytes);
+  d.kept = kept_out;
+  d.count = count_out;
+  d.boxes = boxes_out;
+  hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, stream, d);
+  if (rocprim::radix_sort_keys(ws + 2 * keys_bytes, tmp_bytes, d.keys, sorted, (size_t)A, 0, 44,
+                               stream) != hipSuccess) {
+    set_error("rocprim::radix_sort_keys failed");
+    return PP_ERR_HIP;
+  }
+  d.keys = sorted;
+  hipLaunchKernelGGL(k_nms, dim3(1), dim3(kNmsThreads), 0, stream, d);
+  hipLaunchKernelGGL(k_decode, dim3((unsigned)((d.max_out + 127) / 128)), dim3(128), 0, stream, d);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}

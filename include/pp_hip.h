@@ -187,6 +187,32 @@ int pp_ingest_dev(pp_ctx_t *ctx, void *stream, const float *raw_dev, int64_t n_p
                   int raw_cols, const double *transform_rowmajor4x4, double min_dist,
                   float *points_out_dev);
 
+/*
+ * Inference post-processing on the device: replaces the
+ * per-sample tail of evaluate() (evaluate.py:231-245): sigmoid / tanh / class max /
+ * score threshold / box_nms (:127-139, torchvision.ops.nms over the ANCHOR
+ * rectangles) / first max_out survivors / make_pred_boxes (:33-89) /
+ * move_box_to_car_space (:91-125).
+ *   cls_dev [Ac*C][H][W] f32, reg_dev [Ac*8][H][W] f32: one sample of PPModel's output
+ *   a_centers [A,3] a_wlh [A,3] a_yaw [A] a_xy [A,4]: anchors, f64 device arrays
+ *       (box_utils.py:111-159; a_xy = the (x1,y1,x2,y2) rows of anchor_xy.pkl)
+ *   boxes_out [max_out][9] f64: car-space x,y,z,w,l,h,yaw,score,class (zeros beyond count)
+ *   kept_out  [max_out] int32 anchor ids in keep order (-1 beyond count); count_out [1]
+ */
+typedef struct pp_decode_params {
+  int32_t fm_height, fm_width, anchors_per_cell, num_classes;
+  double pos_thresh;    /* cfg.DATA.VAL_POS_THRESH, config.py:153 */
+  double nms_thresh;    /* cfg.DATA.VAL_NMS_THRESH, config.py:154 */
+  int32_t max_out;      /* 100, evaluate.py:241 */
+  int32_t reserved;
+  double canvas_height, x_step, y_step, x_min, y_min; /* config.py:46-53,60 */
+} pp_decode_params_t;
+
+int pp_decode_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, const float *reg_dev,
+                  const double *a_centers, const double *a_wlh, const double *a_yaw,
+                  const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
+                  int32_t *kept_out, int32_t *count_out);
+
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
  * stream around the k_emit launch.  pp_ctx_read_emit_ms synchronises on the

@@ -334,3 +334,73 @@ def lidar_ingest(sweeps, min_dist=0.001):
         pts = pts[:, np.logical_not(np.logical_and(x_filt, y_filt))]
         agg = np.hstack((agg, pts))
     return agg.transpose([1, 0])
+
+
+# --------------------------------------------------------------------------- #
+# inference post-processing: evaluate.py:33-139, 231-245                       #
+# --------------------------------------------------------------------------- #
+
+def anchor_xy(corners, yaws_deg_per_anchor):
+    """utils/box_utils.py:152-155: the (x1,y1,x2,y2) rows of anchor_xy.pkl."""
+    rot = (np.asarray(yaws_deg_per_anchor) > 0)[:, None]
+    return np.where(rot, np.concatenate([corners[:, 1], corners[:, 3]], 1),
+                    np.concatenate([corners[:, 2], corners[:, 0]], 1))
+
+
+def nms(boxes, scores, thresh):
+    """torchvision.ops.nms (absent third party; published CPU kernel restated):
+    f32 boxes (x1,y1,x2,y2), decreasing score order, drop when IoU > thresh.
+    Ties in score are broken by the lower index (stable sort)."""
+    boxes = np.asarray(boxes, np.float32)
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    areas = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    suppressed = np.zeros(len(boxes), bool)
+    keep = []
+    for _i, i in enumerate(order):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        rest = order[_i + 1:]
+        xx1 = np.maximum(boxes[i, 0], boxes[rest, 0])
+        yy1 = np.maximum(boxes[i, 1], boxes[rest, 1])
+        xx2 = np.minimum(boxes[i, 2], boxes[rest, 2])
+        yy2 = np.minimum(boxes[i, 3], boxes[rest, 3])
+        w = np.maximum(np.float32(0), xx2 - xx1)
+        h = np.maximum(np.float32(0), yy2 - yy1)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        suppressed[rest[ovr > np.float32(thresh)]] = True
+    return np.array(keep, np.int64)
+
+
+def postprocess(cls_tensor, reg_tensor, a_centers, a_wlh, a_yaw, a_xy, canvas_height, x_step, y_step,
+                x_min, y_min, pos_thresh=0.5, nms_thresh=0.1, max_out=100, num_classes=9, reg_dims=8):
+    """evaluate.py:231-245 + make_pred_boxes (:33-89) + move_box_to_car_space (:91-125) for one
+    sample; cls_tensor [Ac*9,H,W], reg_tensor [Ac*8,H,W] float32.  Returns (boxes[K,9] f64 rows
+    x,y,z,w,l,h,yaw,score,class in car space, kept anchor ids[K])."""
+    cls = np.asarray(cls_tensor, np.float32).transpose(1, 2, 0).reshape(-1, num_classes)
+    reg = np.asarray(reg_tensor, np.float32).transpose(1, 2, 0).reshape(-1, reg_dims).copy()
+    cls = (np.float32(1) / (np.float32(1) + np.exp(-cls))).astype(np.float32)      # torch.sigmoid
+    reg[:, 6] = np.tanh(reg[:, 6])
+    scores, classes = cls.max(-1), cls.argmax(-1)
+    pos = np.where(scores > np.float32(pos_thresh))[0]
+    nb = np.asarray(a_xy, np.float64).astype(np.float32)[pos]                       # box_nms :134
+    nb[:, 1] = np.float32(canvas_height - 1) - nb[:, 1]
+    nb[:, 3] = np.float32(canvas_height - 1) - nb[:, 3]
+    keep = nms(nb, scores[pos], nms_thresh)
+    final = pos[keep[:max_out]]
+    out = np.zeros((len(final), 9))
+    for r, i in enumerate(final):                                                   # make_pred_boxes
+        off = reg[i]
+        diag = np.sqrt(a_wlh[i, 0] ** 2 + a_wlh[i, 1] ** 2)
+        bx = a_centers[i, 0] + off[0] * diag
+        by = a_centers[i, 1] + off[1] * diag
+        bz = a_centers[i, 2] + off[2] * a_wlh[i, 2]
+        bw = np.exp(off[3]) * a_wlh[i, 0]
+        bl = np.exp(off[4]) * a_wlh[i, 1]
+        bh = np.exp(off[5]) * a_wlh[i, 2]
+        yaw = np.arcsin(off[6]) + a_yaw[i]
+        y = (canvas_height - 1) - by                                                # move_box_to_car_space
+        out[r] = [bx * x_step + x_min, y * y_step + y_min, bz, bw * y_step, bl * x_step, bh, yaw,
+                  scores[i], classes[i]]
+    return out, final

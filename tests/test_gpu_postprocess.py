@@ -1,0 +1,53 @@
+"""GPU parity of the device post-processing against the numpy
+restatement of evaluate.py:231-245.  Bar: kept anchor ids and their order exact;
+decoded boxes within 1e-5 relative (expf/asinf/tanhf/sigmoid come from different
+libms; the inputs avoid scores within 1e-6 of the threshold)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu, fm, seed, bias):
+    import torch
+    from pp_amd import boxes
+    from pp_amd.postprocess import Detector
+    acfg = boxes.AnchorConfig(fm, fm)
+    anchors = boxes.make_anchors(acfg)
+    rng = np.random.default_rng(seed)
+    cls = (rng.normal(bias, 1.5, (acfg.per_cell * 9, fm, fm))).astype(np.float32)
+    reg = (rng.normal(0, 0.3, (acfg.per_cell * 8, fm, fm))).astype(np.float32)
+    H = 2 * fm
+    det = Detector(anchors, acfg, H, 0.2, 0.2, -0.1 * H, -0.1 * H, device=gpu)
+    return anchors, acfg, cls, reg, H, det
+
+
+@pytest.mark.parametrize("fm,seed,bias", [(40, 0, -3.0), (64, 1, -4.5), (250, 2, -6.0), (30, 3, 0.5),
+                                          (250, 4, 0.0)])
+def test_postprocess_matches_restatement(gpu, oracle, fm, seed, bias):
+    import torch
+    anchors, acfg, cls, reg, H, det = _setup(gpu, fm, seed, bias)
+    boxes_d, kept_d, count_d = det(torch.from_numpy(cls).to(gpu), torch.from_numpy(reg).to(gpu))
+    torch.cuda.synchronize()
+    ref_b, ref_k = oracle.postprocess(cls, reg, anchors["centers"], anchors["wlh"], anchors["yaw"],
+                                      anchors["xy"], H, 0.2, 0.2, -0.1 * H, -0.1 * H)
+    n = int(count_d.item())
+    assert n == len(ref_k)
+    if fm == 250 and bias == 0.0:
+        assert n == 100            # the first-100 cap of evaluate.py:241 is exercised
+    assert np.array_equal(kept_d.cpu().numpy()[:n], ref_k.astype(np.int32))
+    assert (kept_d.cpu().numpy()[n:] == -1).all()
+    got = boxes_d.cpu().numpy()
+    assert np.allclose(got[:n], ref_b, rtol=1e-5, atol=1e-5)
+    assert not got[n:].any()
+    assert np.array_equal(got[:n, 8], ref_b[:, 8])           # classes exact
+
+
+def test_postprocess_no_detection_and_full_batch_guard(gpu, oracle):
+    import torch
+    anchors, acfg, cls, reg, H, det = _setup(gpu, 20, 5, -30.0)
+    boxes_d, kept_d, count_d = det(torch.from_numpy(cls)[None].to(gpu), torch.from_numpy(reg)[None].to(gpu))
+    torch.cuda.synchronize()
+    assert int(count_d.item()) == 0 and (kept_d.cpu().numpy() == -1).all() and not boxes_d.any()
+    with pytest.raises(ValueError):
+        det(torch.zeros(2, 18, 20, 20, device=gpu), torch.zeros(2, 16, 20, 20, device=gpu))

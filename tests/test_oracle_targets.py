@@ -113,3 +113,28 @@ def test_lidar_ingest_restatement(oracle):
     assert out2.shape == (5, 4)
     assert out2[0].tolist() == [11, 22, 33, 9] and out2[4].tolist() == [-2, 1, 3, 9]
     assert out2.dtype == np.float64 and np.array_equal(out2, out2.astype(np.float32))
+
+
+def test_nms_and_postprocess_restatement(oracle):
+    """torchvision.ops.nms semantics (greedy, IoU > thresh suppresses, score order)
+    and the decode formulae of make_pred_boxes / move_box_to_car_space."""
+    O = oracle
+    b = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.5]], np.float32)
+    keep = O.nms(b, np.array([0.9, 0.8, 0.7, 0.95], np.float32), 0.5)
+    assert keep.tolist() == [3, 2]              # box 3 wins, suppresses 0 (IoU .95) and 1 (.66); 2 is far
+    assert O.nms(b, np.array([0.9, 0.8, 0.7, 0.95], np.float32), 0.99).tolist() == [3, 0, 1, 2]
+    # one anchor, hand-computed decode
+    a_c, a_wlh, a_yaw = np.array([[30.0, 40.0, 0.75]]), np.array([[10.0, 25.0, 1.75]]), np.array([0.0])
+    corners = O.box_bottom_corners_xy(a_c, a_wlh, a_yaw)
+    xy = O.anchor_xy(corners, [0])
+    assert xy[0].tolist() == [17.5, 45.0, 42.5, 35.0]            # corners 2 and 0 (box_utils.py:155)
+    cls = np.full((9, 1, 1), -5.0, np.float32)
+    cls[4] = 2.0
+    reg = np.zeros((8, 1, 1), np.float32)
+    reg[[0, 3, 6], 0, 0] = [0.1, np.log(2.0), 0.5]
+    out, kept = O.postprocess(cls, reg, a_c, a_wlh, a_yaw, xy, 100, 0.2, 0.2, -10, -10)
+    diag = np.sqrt(10.0 ** 2 + 25.0 ** 2)
+    assert kept.tolist() == [0] and out[0, 8] == 4 and abs(out[0, 7] - 1 / (1 + np.exp(-2.0))) < 1e-6
+    assert abs(out[0, 0] - ((30 + np.float32(0.1) * diag) * 0.2 - 10)) < 1e-9
+    assert abs(out[0, 1] - ((99 - 40.0) * 0.2 - 10)) < 1e-9
+    assert abs(out[0, 3] - 2.0 * 10 * 0.2) < 1e-5 and abs(out[0, 6] - np.arcsin(np.tanh(np.float32(0.5)))) < 1e-6
