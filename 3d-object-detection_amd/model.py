@@ -23,12 +23,33 @@ class PPFeatureNet(nn.Module):
         super().__init__()
         self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=1)
         self.bn1 = nn.BatchNorm2d(out_channels)
+        #: inference only: evaluate the same function with two passes over the
+        #: [B,C,P,N] intermediate instead of eight (see forward_eval)
+        self.fast_eval = True
 
     def forward(self, x):                  # [B,D,P,N]
+        if not self.training and self.fast_eval:
+            return self.forward_eval(x)
         x = self.conv1(x)
         x = F.relu(x)
         x = self.bn1(x)
         return torch.max(x, dim=3)[0]      # [B,C,P]
+
+    def forward_eval(self, x):
+        """Same function as the reference sequence (model/model.py:36-39) in eval mode,
+        rearranged so that the 64x-inflated intermediate is written once and read once:
+        bias add and ReLU are monotone, so max_n relu(W x_n + b) = relu(max_n(W x_n) + b)
+        (min likewise), and eval-mode BatchNorm is the per-channel affine map s*r + t, so
+        max_n BN(r_n) = s*max_n(r_n) + t for s >= 0 and s*min_n(r_n) + t for s < 0."""
+        B, D, P, N = x.shape
+        C = self.conv1.out_channels
+        y = F.conv2d(x, self.conv1.weight, None)                          # bias folded in below
+        mn, mx = torch.aminmax(y, dim=3)                                  # [B,C,P] each
+        b = self.conv1.bias.reshape(1, C, 1)
+        scale = (self.bn1.weight * torch.rsqrt(self.bn1.running_var + self.bn1.eps)).reshape(1, C, 1)
+        shift = self.bn1.bias.reshape(1, C, 1) - self.bn1.running_mean.reshape(1, C, 1) * scale
+        r = torch.where(scale >= 0, F.relu(mx + b), F.relu(mn + b))
+        return r * scale + shift
 
     @torch.no_grad()
     def fused_params(self):

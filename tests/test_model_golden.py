@@ -84,3 +84,29 @@ def test_up3_output_padding():
     net = M.PPModel(9, 4, 18, 16, 100, 100)
     c, r = net(torch.zeros(1, 9, 8, 4), torch.zeros(1, 8, 3, dtype=torch.int64))
     assert c.shape == (1, 18, 50, 50) and r.shape == (1, 16, 50, 50)
+
+
+def test_fast_eval_feature_net_equals_reference_sequence(gold):
+    """PPFeatureNet.forward_eval (two passes over the [B,C,P,N] intermediate) against the
+    reference op sequence conv -> ReLU -> BN -> max, incl. negative BatchNorm scales and
+    pillars without any zero-padded slot."""
+    import pp_amd.model as M
+    torch.manual_seed(3)
+    fn = M.PPFeatureNet(9, 64)
+    with torch.no_grad():
+        fn.bn1.weight.normal_(0, 1.0)
+        fn.bn1.bias.normal_(0, 0.5)
+        fn.bn1.running_mean.normal_(0, 0.5)
+        fn.bn1.running_var.uniform_(0.2, 3.0)
+    fn.eval()
+    x = torch.randn(2, 9, 50, 12) * 3
+    x[:, :, 10:, 6:] = 0
+    with torch.no_grad():
+        fast = fn(x)
+        fn.fast_eval = False
+        ref = fn(x)
+    assert (fn.bn1.weight < 0).any()
+    assert torch.allclose(fast, ref, atol=2e-6, rtol=1e-6)
+    fn.train()
+    fn.fast_eval = True
+    assert fn(x).shape == (2, 64, 50)          # training always takes the reference sequence
