@@ -1,0 +1,68 @@
+// pp_epilogue.hip -- fused conv epilogue for the inference backbone.
+//
+// Every block of the reference backbone is Conv2d -> ReLU -> BatchNorm2d
+// (/root/reference model/model.py:76-84, 105-109).  In eval mode PyTorch-ROCm runs
+// that as MIOpen conv + a bias kernel + a ReLU kernel + a BatchNorm kernel: three
+// extra read+write passes over every activation tensor.  This kernel does
+// y = max(x + b_c, 0) * s_c + t_c in place, in one pass (s = gamma/sqrt(var+eps),
+// t = beta - mean*s): HBM-bound, 8 bytes of traffic per element.
+
+#include "pp_common.h"
+
+namespace pp {
+
+__global__ __launch_bounds__(256) void k_bias_relu_bn(float *__restrict__ x, int C, int64_t hw,
+                                                      const float *__restrict__ prm) {
+  const int64_t plane = blockIdx.y;  // b*C + c
+  const int c = (int)(plane % C);
+  const float b = prm[c * 3 + 0], s = prm[c * 3 + 1], t = prm[c * 3 + 2];
+  float *p = x + plane * hw;
+  const int64_t n4 = hw >> 2;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  if (aligned) {
+    float4 *p4 = reinterpret_cast<float4 *>(p);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      float4 v = p4[i];
+      v.x = fmaxf(v.x + b, 0.0f) * s + t;
+      v.y = fmaxf(v.y + b, 0.0f) * s + t;
+      v.z = fmaxf(v.z + b, 0.0f) * s + t;
+      v.w = fmaxf(v.w + b, 0.0f) * s + t;
+      p4[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw;
+         i += (int64_t)gridDim.x * 256)
+      p[i] = fmaxf(p[i] + b, 0.0f) * s + t;
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
+      p[i] = fmaxf(p[i] + b, 0.0f) * s + t;
+  }
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream_, float *x_dev, int64_t batch,
+                                   int channels, int64_t hw, const float *params_dev) {
+  if (!ctx || !x_dev || !params_dev) {
+    set_error("pp_bias_relu_bn_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || channels < 1 || hw < 1 || batch * channels > 65535) {
+    set_error("pp_bias_relu_bn_dev: need batch*channels in [1,65535], hw >= 1");
+    return PP_ERR_VALUE;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+  const unsigned gx = (unsigned)std::min<int64_t>(((hw >> 2) + 255) / 256 + 1, 64);
+  hipLaunchKernelGGL(k_bias_relu_bn, dim3(gx, (unsigned)(batch * channels)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), x_dev, channels, hw, params_dev);
+  hipError_t e = hipGetLastError();
+  if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("k_bias_relu_bn launch failed: %s", hipGetErrorString(e));
+    return PP_ERR_HIP;
+  }
+  return PP_OK;
+}

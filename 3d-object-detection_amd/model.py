@@ -11,9 +11,54 @@ imported reference module).  Differences, none of them numerical:
   * the scatter never calls ``nonzero`` (a host sync, model/model.py:56): empty
     pillars are routed to a spill column that is sliced away.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
+
+
+class _Epilogue:
+    """Inference-only fused ``ReLU -> BatchNorm2d(eval)`` (+ conv bias) in place, one HIP
+    kernel (csrc/pp_epilogue.hip).  The per-channel table is rebuilt only when a
+    parameter / running statistic of the (conv, bn) pair changed."""
+
+    _ctx = {}
+
+    def __init__(self):
+        self._key = None
+        self._table = None
+
+    def table(self, bias, bn):
+        ts = (bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+        if key != self._key:
+            with torch.no_grad():
+                scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+                shift = bn.bias.double() - bn.running_mean.double() * scale
+                b = bias.double() if bias is not None else torch.zeros_like(scale)
+                self._table = torch.stack([b, scale, shift], 1).float().contiguous()
+            self._key = key
+        return self._table
+
+    def __call__(self, y, bias, bn):
+        dev = y.device
+        ctx = _Epilogue._ctx.get(dev.index)
+        if ctx is None:
+            ctx = _Epilogue._ctx[dev.index] = _lib.Context(dev.index)
+        tab = self.table(bias, bn)
+        B, C, H, W = y.shape
+        rc = _lib.lib().pp_bias_relu_bn_dev(
+            ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+            ctypes.c_void_p(y.data_ptr()), B, C, H * W, ctypes.c_void_p(tab.data_ptr()))
+        _lib.check(rc, "pp_bias_relu_bn_dev")
+        return y
+
+
+def _use_fused_epilogue(module, x):
+    return (not module.training) and module.fused_epilogue and x.is_cuda and x.dtype == torch.float32
 
 
 class PPFeatureNet(nn.Module):
@@ -92,9 +137,18 @@ class PPDownBlock(nn.Module):
             block += [nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1),
                       nn.ReLU(), nn.BatchNorm2d(out_channels)]
         self.block = nn.Sequential(*block)
+        #: inference only: conv without bias + one fused bias/ReLU/BatchNorm pass per layer
+        self.fused_epilogue = True
+        self._epi = [_Epilogue() for _ in range(num_layers)]
 
     def forward(self, x):
-        return self.block(x)
+        if not _use_fused_epilogue(self, x):
+            return self.block(x)
+        for i, epi in enumerate(self._epi):
+            conv, bn = self.block[3 * i], self.block[3 * i + 2]
+            x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+            x = epi(x if x.is_contiguous() else x.contiguous(), conv.bias, bn)
+        return x
 
 
 class PPUpBlock(nn.Module):
@@ -105,9 +159,15 @@ class PPUpBlock(nn.Module):
         self.conv2d_t = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=3, stride=stride,
                                            padding=padding, output_padding=output_padding)
         self.bn = nn.BatchNorm2d(out_channels)
+        self.fused_epilogue = True
+        self._epi = _Epilogue()
 
     def forward(self, x):
-        return self.bn(F.relu(self.conv2d_t(x)))
+        if not _use_fused_epilogue(self, x):
+            return self.bn(F.relu(self.conv2d_t(x)))
+        ct = self.conv2d_t
+        y = F.conv_transpose2d(x, ct.weight, None, ct.stride, ct.padding, ct.output_padding)
+        return self._epi(y if y.is_contiguous() else y.contiguous(), ct.bias, self.bn)
 
 
 def up3_output_padding(canvas):

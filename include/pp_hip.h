@@ -213,6 +213,15 @@ int pp_decode_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, const float
                   const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
                   int32_t *kept_out, int32_t *count_out);
 
+/*
+ * Fused conv epilogue for the inference backbone: y = max(x + b_c, 0) * s_c + t_c in
+ * place on a contiguous NCHW f32 tensor -- the ReLU -> BatchNorm2d(eval) tail (plus the
+ * conv bias) of every block of model/model.py:76-84,105-109 in one pass.
+ *   x_dev [batch][channels][hw] f32; params_dev [channels][3] f32 {bias, scale, shift}
+ */
+int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t batch, int channels,
+                        int64_t hw, const float *params_dev);
+
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
  * stream around the k_emit launch.  pp_ctx_read_emit_ms synchronises on the

@@ -71,3 +71,36 @@ def test_bench_contract_line(gpu):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 0 and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+
+
+def test_fused_epilogue_equals_relu_batchnorm(gpu):
+    """Backbone in eval mode: conv + fused bias/ReLU/BN kernel == Conv2d -> ReLU -> BatchNorm2d."""
+    import torch
+    import pp_amd.model as M
+    torch.manual_seed(5)
+    bb = M.PPBackbone(16, up3_op=M.up3_output_padding(96)).to(gpu)
+    with torch.no_grad():
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.4, 2.0)
+                m.weight.normal_(0, 1.0)
+                m.bias.normal_(0, 0.2)
+    bb.eval()
+    x = torch.randn(2, 16, 96, 96, device=gpu)
+    with torch.no_grad():
+        y1 = bb(x)
+        for m in bb.modules():
+            if hasattr(m, "fused_epilogue"):
+                m.fused_epilogue = False
+        y0 = bb(x)
+    assert y1.shape == y0.shape == (2, 96, 48, 48)
+    assert (y1 - y0).abs().max().item() <= 2e-4 * max(1.0, y0.abs().max().item())
+    # odd spatial size: scalar tail / unaligned planes
+    d = M.PPDownBlock(2, 3, 5).to(gpu).eval()
+    xx = torch.randn(1, 3, 37, 41, device=gpu)
+    with torch.no_grad():
+        a = d(xx)
+        d.fused_epilogue = False
+        b = d(xx)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
