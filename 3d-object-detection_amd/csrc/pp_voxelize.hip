@@ -161,11 +161,6 @@ __device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
   int hi = __shfl_up((int)(v >> 32), d, kWave);
   return ((u64)(unsigned)hi << 32) | (unsigned)lo;
 }
-__device__ __forceinline__ u64 shfl64(u64 v, int src) {
-  int lo = __shfl((int)(v & 0xFFFFFFFFull), src, kWave);
-  int hi = __shfl((int)(v >> 32), src, kWave);
-  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
-}
 __device__ __forceinline__ u64 wave_sum64(u64 v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -726,8 +721,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kEmitWaves + w) * KW);
   if (p0 >= P) return;
   const int kw_eff = min(KW, P - p0);
-  // (1) pillar descriptors: the loads go out first, the speculative fill below
-  //     overlaps their latency
+  // (1) pillar descriptors (one lane per pillar)
   const int2 tot = a.totals[b];
   int4 m = make_int4(-1, 0, 0, 0);
   if (lane < KW && p0 + lane < P) m = a.pillar_meta[(int64_t)b * P + p0 + lane];
@@ -768,8 +762,8 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     Tpad += (cnts[k] + 3) & ~3;
   }
   const bool pooled = (Tpad <= CAPW);
-  // (2) prefetch the pooled bucket (coalesced: consecutive pillars own consecutive
-  //     CSR ranges); consumed after the early zero fill has been issued
+  // (2) the wave's pooled bucket in one coalesced read: consecutive pillars own
+  //     consecutive CSR ranges
   int idx0 = 0, idx1 = 0;
   Rec rec0, rec1;
   rec0.x = rec0.y = rec0.z = rec0.w = 0;
@@ -1183,7 +1177,15 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                             ev0, ev1, 0, a);
       break;
   }
-  PP_HIP_TRY(hipGetLastError());
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      // the self-cleaning invariant (counts, scan words zero) can no longer be assumed
+      std::memset(ctx->vox_layout_key, 0, sizeof ctx->vox_layout_key);
+      set_error("voxelizer launch failed: %s", hipGetErrorString(e));
+      return PP_ERR_HIP;
+    }
+  }
   return PP_OK;
 }
 

@@ -198,3 +198,34 @@ def test_full_size_configs(gpu, oracle, cfg):
     assert np.array_equal(live[:nrow], np.minimum(cc[:nrow, 2], N))
     ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, cfg["half"], cfg["step"])
     assert _check_exact(pil, idx, ref_p, ref_i)
+
+
+def test_hip_graph_capture_and_replay(gpu, oracle):
+    """The device entry point allocates and synchronises nothing once its workspace is
+    reserved, so the four launches can be captured into a HIP graph and replayed; the
+    self-cleaning workspace makes every replay independent of the previous one."""
+    import torch
+    from pp_amd import synth
+    P, N = 3000, 16
+    vox = _vox(gpu, 12.0, 0.2, P, N)
+    a = torch.from_numpy(synth.lidar_like(9000, 12.0, 40)).to(gpu)
+    b = torch.from_numpy(synth.lidar_like(9000, 12.0, 41)).to(gpu)
+    static_in = a.clone().unsqueeze(0)
+    out = (torch.empty((1, 9, P, N), dtype=torch.float32, device=gpu),
+           torch.empty((1, P, 3), dtype=torch.int64, device=gpu))
+    vox.reserve(1, 9000)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        vox(static_in, out=out)                      # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        vox(static_in, out=out)
+    for cloud in (b, a, b):
+        static_in.copy_(cloud.unsqueeze(0))
+        g.replay()
+        torch.cuda.synchronize()
+        ref_p, ref_i, _ = oracle_stage(oracle, cloud.cpu().numpy(), P, N, 12.0, 0.2)
+        assert np.array_equal(out[1][0].cpu().numpy(), ref_i)
+        assert np.array_equal(out[0][0].cpu().numpy(), ref_p)
