@@ -120,7 +120,7 @@ def lib():
         L.pp_ingest_dev.argtypes = [vp, vp, vp, i64, c_int, ctypes.POINTER(ctypes.c_double),
                                     ctypes.c_double, vp]
         L.pp_decode_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(DecodeParams), vp, vp, vp]
-        L.pp_bias_relu_bn_dev.argtypes = [vp, vp, vp, i64, c_int, i64, vp]
+        L.pp_bias_relu_bn_dev.argtypes = [vp, vp, vp, i64, c_int, i64, vp, vp, i64, i64]
         L.pp_ctx_set_timing.argtypes = [vp, c_int]
         L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
                                           ctypes.POINTER(c_int)]

@@ -11,30 +11,38 @@
 
 namespace pp {
 
-__global__ __launch_bounds__(256) void k_bias_relu_bn(float *__restrict__ x, int C, int64_t hw,
+// x: [B][C][hw] contiguous.  y: plane (b,c) lives at y + (b*y_batch_stride + c)*hw, which
+// is x itself for the in-place form and a channel slice of a wider tensor otherwise (the
+// up blocks write straight into the concatenated [B,6C,h,w] output, model/model.py:140).
+__global__ __launch_bounds__(256) void k_bias_relu_bn(const float *__restrict__ x,
+                                                      float *__restrict__ y, int C, int64_t hw,
+                                                      int64_t y_batch_stride,
                                                       const float *__restrict__ prm) {
   const int64_t plane = blockIdx.y;  // b*C + c
-  const int c = (int)(plane % C);
+  const int64_t bi = plane / C;
+  const int c = (int)(plane - bi * C);
   const float b = prm[c * 3 + 0], s = prm[c * 3 + 1], t = prm[c * 3 + 2];
-  float *p = x + plane * hw;
+  const float *p = x + plane * hw;
+  float *q = y + (bi * y_batch_stride + c) * hw;
   const int64_t n4 = hw >> 2;
-  const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  const bool aligned = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0);
   if (aligned) {
-    float4 *p4 = reinterpret_cast<float4 *>(p);
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+    float4 *q4 = reinterpret_cast<float4 *>(q);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
       float4 v = p4[i];
       v.x = fmaxf(v.x + b, 0.0f) * s + t;
       v.y = fmaxf(v.y + b, 0.0f) * s + t;
       v.z = fmaxf(v.z + b, 0.0f) * s + t;
       v.w = fmaxf(v.w + b, 0.0f) * s + t;
-      p4[i] = v;
+      q4[i] = v;
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw;
          i += (int64_t)gridDim.x * 256)
-      p[i] = fmaxf(p[i] + b, 0.0f) * s + t;
+      q[i] = fmaxf(p[i] + b, 0.0f) * s + t;
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
-      p[i] = fmaxf(p[i] + b, 0.0f) * s + t;
+      q[i] = fmaxf(p[i] + b, 0.0f) * s + t;
   }
 }
 
@@ -43,7 +51,19 @@ __global__ __launch_bounds__(256) void k_bias_relu_bn(float *__restrict__ x, int
 using namespace pp;
 
 extern "C" int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream_, float *x_dev, int64_t batch,
-                                   int channels, int64_t hw, const float *params_dev) {
+                                   int channels, int64_t hw, const float *params_dev,
+                                   float *y_dev, int64_t y_channels, int64_t y_channel_offset) {
+  if (!y_dev) {  // in place
+    y_dev = x_dev;
+    y_channels = channels;
+    y_channel_offset = 0;
+  }
+  if (y_channels < channels || y_channel_offset < 0 || y_channel_offset + channels > y_channels) {
+    set_error("pp_bias_relu_bn_dev: channel slice [%lld,%lld) outside [0,%lld)",
+              (long long)y_channel_offset, (long long)(y_channel_offset + channels),
+              (long long)y_channels);
+    return PP_ERR_VALUE;
+  }
   if (!ctx || !x_dev || !params_dev) {
     set_error("pp_bias_relu_bn_dev: NULL argument");
     return PP_ERR_VALUE;
@@ -57,7 +77,8 @@ extern "C" int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream_, float *x_dev, i
   if (prev != ctx->device) (void)hipSetDevice(ctx->device);
   const unsigned gx = (unsigned)std::min<int64_t>(((hw >> 2) + 255) / 256 + 1, 64);
   hipLaunchKernelGGL(k_bias_relu_bn, dim3(gx, (unsigned)(batch * channels)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), x_dev, channels, hw, params_dev);
+                     static_cast<hipStream_t>(stream_), x_dev, y_dev + y_channel_offset * hw, channels,
+                     hw, y_channels, params_dev);
   hipError_t e = hipGetLastError();
   if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
   if (e != hipSuccess) {

@@ -43,18 +43,24 @@ class _Epilogue:
             self._key = key
         return self._table
 
-    def __call__(self, y, bias, bn):
+    def __call__(self, y, bias, bn, out=None, channel_offset=0):
+        """In place on ``y`` [B,C,H,W], or into channels [channel_offset, +C) of ``out``."""
         dev = y.device
         ctx = _Epilogue._ctx.get(dev.index)
         if ctx is None:
             ctx = _Epilogue._ctx[dev.index] = _lib.Context(dev.index)
         tab = self.table(bias, bn)
         B, C, H, W = y.shape
+        if out is not None and (out.shape[0] != B or out.shape[2:] != y.shape[2:]
+                                or not out.is_contiguous() or out.dtype != y.dtype):
+            raise ValueError("epilogue destination does not match the source")
         rc = _lib.lib().pp_bias_relu_bn_dev(
             ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-            ctypes.c_void_p(y.data_ptr()), B, C, H * W, ctypes.c_void_p(tab.data_ptr()))
+            ctypes.c_void_p(y.data_ptr()), B, C, H * W, ctypes.c_void_p(tab.data_ptr()),
+            ctypes.c_void_p(out.data_ptr()) if out is not None else None,
+            out.shape[1] if out is not None else C, int(channel_offset))
         _lib.check(rc, "pp_bias_relu_bn_dev")
-        return y
+        return y if out is None else out
 
 
 def _use_fused_epilogue(module, x):
@@ -162,12 +168,13 @@ class PPUpBlock(nn.Module):
         self.fused_epilogue = True
         self._epi = _Epilogue()
 
-    def forward(self, x):
+    def forward(self, x, out=None, channel_offset=0):
         if not _use_fused_epilogue(self, x):
             return self.bn(F.relu(self.conv2d_t(x)))
         ct = self.conv2d_t
         y = F.conv_transpose2d(x, ct.weight, None, ct.stride, ct.padding, ct.output_padding)
-        return self._epi(y if y.is_contiguous() else y.contiguous(), ct.bias, self.bn)
+        return self._epi(y if y.is_contiguous() else y.contiguous(), ct.bias, self.bn, out,
+                         channel_offset)
 
 
 def up3_output_padding(canvas):
@@ -196,6 +203,18 @@ class PPBackbone(nn.Module):
         self.up3 = PPUpBlock(4 * c, 2 * c, 4, 1, up3_op)
 
     def forward(self, x):
+        if _use_fused_epilogue(self.up1, x):
+            # inference: the three up blocks write their channel slices of the concatenated
+            # output directly (no torch.cat copy)
+            c = self.up1.conv2d_t.out_channels
+            x = self.down1(x)
+            out = x.new_empty((x.shape[0], 3 * c, x.shape[2], x.shape[3]))
+            self.up1(x, out, 0)
+            x = self.down2(x)
+            self.up2(x, out, c)
+            x = self.down3(x)
+            self.up3(x, out, 2 * c)
+            return out
         x = self.down1(x)
         out1 = self.up1(x)
         x = self.down2(x)

@@ -218,9 +218,13 @@ int pp_decode_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, const float
  * place on a contiguous NCHW f32 tensor -- the ReLU -> BatchNorm2d(eval) tail (plus the
  * conv bias) of every block of model/model.py:76-84,105-109 in one pass.
  *   x_dev [batch][channels][hw] f32; params_dev [channels][3] f32 {bias, scale, shift}
+ *   y_dev NULL: in place.  Otherwise the result goes to channels
+ *   [y_channel_offset, y_channel_offset+channels) of y_dev [batch][y_channels][hw] -- the
+ *   up blocks write straight into the concatenated backbone output (model/model.py:140).
  */
 int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t batch, int channels,
-                        int64_t hw, const float *params_dev);
+                        int64_t hw, const float *params_dev, float *y_dev, int64_t y_channels,
+                        int64_t y_channel_offset);
 
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
