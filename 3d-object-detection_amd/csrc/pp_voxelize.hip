@@ -47,7 +47,11 @@ constexpr int kScanTile = kScanThreads * 4;  // cells per scan workgroup
 constexpr int kEmitWaves = 4;                // waves per emit workgroup
 constexpr int kEmitThreads = kEmitWaves * kWave;
 constexpr int KW = 4;      // pillars per emit wave
-constexpr int CAPW = 128;  // pooled bucket capacity (points) per emit wave
+#ifndef PP_CAPW
+#define PP_CAPW 128
+#endif
+constexpr int CAPW = PP_CAPW;  // pooled bucket capacity (points, 4-padded per pillar) per emit wave
+constexpr int kPre = CAPW / 64;  // bucket entries prefetched per lane
 constexpr unsigned kSpinLimit = 1u << 26;
 
 using u64 = unsigned long long;
@@ -301,15 +305,12 @@ __global__ __launch_bounds__(kBinThreads) void k_fill(
 // k_emit                                                                      //
 // ------------------------------------------------------------------------- //
 template <typename TIn>
-struct alignas(16) WaveLds {
-  int idx[CAPW];                               // point indices as stored by k_fill (arrival order)
+struct alignas(32) WaveLds {
+  int idx[CAPW];  // point indices as stored by k_fill (arrival order), 4-aligned buckets, INT_MAX pads
   TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar
   union {
-    struct {
-      double q[3][CAPW];   // v / (n+1)
-      double ratio[CAPW];  // n / (n+1)
-    } c;
-    float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense mode), aliases c
+    double4 cq[CAPW];  // chain operands of one point: {n/(n+1), x/(n+1), y/(n+1), z/(n+1)}
+    float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense / fused-net modes), aliases cq
   } u;
   double mean[KW][3];
   double cx[KW], cy[KW];  // canvas_x / canvas_y (pillars.cpp:278-280), once per pillar
@@ -410,10 +411,7 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
       L.px[rank] = x;
       L.py[rank] = y;
       L.pz[rank] = z;
-      L.u.c.ratio[rank] = n / den;
-      L.u.c.q[0][rank] = (double)x / den;
-      L.u.c.q[1][rank] = (double)y / den;
-      L.u.c.q[2][rank] = (double)z / den;
+      L.u.cq[rank] = make_double4(n / den, (double)x / den, (double)y / den, (double)z / den);
     }
     wave_sync();
     const int c = __popcll(mask);
@@ -423,10 +421,10 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
         m1 = (double)L.py[0];
         m2 = (double)L.pz[0];
       } else {
-        const double rt = L.u.c.ratio[t];
-        m0 = m0 * rt + L.u.c.q[0][t];
-        m1 = m1 * rt + L.u.c.q[1][t];
-        m2 = m2 * rt + L.u.c.q[2][t];
+        const double4 o = L.u.cq[t];
+        m0 = m0 * o.x + o.y;
+        m1 = m1 * o.x + o.z;
+        m2 = m2 * o.x + o.w;
       }
     }
     seen += c;
@@ -490,22 +488,47 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
 }
 
 // Pooled pillars [kbeg,kend) of this wave: entries j (pooled bucket position)
-// were prefetched by the caller into registers (idx0/rec0 for j = lane, idx1/rec1
-// for j = lane + 64) straight from the CSR arrays.  Leaves the f32 features of
+// were prefetched by the caller into registers (idx_r[it] / rec_r[it] for
+// j = lane + 64*it) straight from the CSR arrays.  Leaves the f32 features of
 // the live points in L.u.feat (dense vec4 mode) or stores them (other modes).
 template <typename TIn, int MODE>
 __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0,
-                                           int kbeg, int kend, int lane, int idx0,
-                                           typename Rec4<TIn>::type rec0, int idx1,
-                                           typename Rec4<TIn>::type rec1, int segbeg[KW],
+                                           int kbeg, int kend, int lane, const int idx_r[kPre],
+                                           const typename Rec4<TIn>::type rec_r[kPre],
+                                           int segbeg[KW],
                                            int segpad[KW], int cntk[KW], int T) {
   const int N = a.N;
-  if (lane < T) L.idx[lane] = idx0;
-  if (lane + kWave < T) L.idx[lane + kWave] = idx1;
+  // bucket entries go to 4-aligned bucket starts; the up-to-3 pad entries compare as
+  // "not smaller" in the rank search below
+  if (lane < KW) {
+    int sp = 0, sc = 0;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      sp = (lane == kk) ? segpad[kk] : sp;
+      sc = (lane == kk) ? cntk[kk] : sc;
+    }
+    for (int e = sc; e < ((sc + 3) & ~3); ++e) L.idx[sp + e] = INT_MAX;
+  }
+#pragma unroll
+  for (int it = 0; it < kPre; ++it) {
+    const int j = lane + it * kWave;
+    if (j < T) {
+      int k = 0;
+#pragma unroll
+      for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
+      int sb = 0, sp = 0;
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+        sb = (k == kk) ? segbeg[kk] : sb;
+        sp = (k == kk) ? segpad[kk] : sp;
+      }
+      L.idx[sp + (j - sb)] = idx_r[it];
+    }
+  }
   wave_sync();
   // restore input order: rank of every entry inside its bucket (counts are small)
 #pragma unroll
-  for (int it = 0; it < CAPW / kWave; ++it) {
+  for (int it = 0; it < kPre; ++it) {
     const int j = lane + it * kWave;
     if (j < T) {
       int k = 0;
@@ -518,20 +541,22 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
         sc = (k == kk) ? cntk[kk] : sc;
         sp = (k == kk) ? segpad[kk] : sp;
       }
-      const int my = it == 0 ? idx0 : idx1;
-      const typename Rec4<TIn>::type rec = it == 0 ? rec0 : rec1;
+      const int my = idx_r[it];
+      const typename Rec4<TIn>::type rec = rec_r[it];
       int r = 0;
-      for (int jj = sb; jj < sb + sc; ++jj) r += (L.idx[jj] < my) ? 1 : 0;
-      const int pos = sp + r;  // sorted arrays use 4-aligned bucket starts (16-byte LDS reads later)
+      for (int g4 = 0; g4 < ((sc + 3) >> 2); ++g4) {  // 16-byte LDS reads, four compares each
+        const int4 v = *reinterpret_cast<const int4 *>(&L.idx[sp + 4 * g4]);
+        r += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
+      }
+      const int pos = sp + r;  // sorted arrays use 4-aligned bucket starts too
       L.px[pos] = rec.x;
       L.py[pos] = rec.y;
       L.pz[pos] = rec.z;
       L.pr[pos] = rec.w;
       const double n = (double)r, den = n + 1;
-      L.u.c.ratio[pos] = n / den;             // pillars.cpp:322-326: n/(n+1)
-      L.u.c.q[0][pos] = (double)rec.x / den;  //                       v/(n+1)
-      L.u.c.q[1][pos] = (double)rec.y / den;
-      L.u.c.q[2][pos] = (double)rec.z / den;
+      // pillars.cpp:322-326: n/(n+1) and v/(n+1), true f64 divisions, lane-parallel
+      L.u.cq[pos] = make_double4(n / den, (double)rec.x / den, (double)rec.y / den,
+                                 (double)rec.z / den);
     }
   }
   wave_sync();
@@ -545,11 +570,30 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
     }
     if (sc > 0) {
       double m0 = (double)L.px[sb], m1 = (double)L.py[sb], m2 = (double)L.pz[sb];
-      for (int n = 1; n < sc; ++n) {
-        const double rt = L.u.c.ratio[sb + n];
-        m0 = m0 * rt + L.u.c.q[0][sb + n];
-        m1 = m1 * rt + L.u.c.q[1][sb + n];
-        m2 = m2 * rt + L.u.c.q[2][sb + n];
+      // the chain is serial in m, but its operands are not: fetch four points' operands
+      // ahead of the four dependent mul+add steps that consume them
+      int n = 1;
+      for (; n + 3 < sc; n += 4) {
+        const double4 o0 = L.u.cq[sb + n], o1 = L.u.cq[sb + n + 1], o2 = L.u.cq[sb + n + 2],
+                      o3 = L.u.cq[sb + n + 3];
+        m0 = m0 * o0.x + o0.y;
+        m1 = m1 * o0.x + o0.z;
+        m2 = m2 * o0.x + o0.w;
+        m0 = m0 * o1.x + o1.y;
+        m1 = m1 * o1.x + o1.z;
+        m2 = m2 * o1.x + o1.w;
+        m0 = m0 * o2.x + o2.y;
+        m1 = m1 * o2.x + o2.z;
+        m2 = m2 * o2.x + o2.w;
+        m0 = m0 * o3.x + o3.y;
+        m1 = m1 * o3.x + o3.z;
+        m2 = m2 * o3.x + o3.w;
+      }
+      for (; n < sc; ++n) {
+        const double4 o = L.u.cq[sb + n];
+        m0 = m0 * o.x + o.y;
+        m1 = m1 * o.x + o.z;
+        m2 = m2 * o.x + o.w;
       }
       L.mean[lane][0] = m0;
       L.mean[lane][1] = m1;
@@ -562,7 +606,7 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
   float *outb = a.out + (int64_t)b * 9 * a.P * N;
   const int start0 = L.start[kbeg];
 #pragma unroll
-  for (int it = 0; it < CAPW / kWave; ++it) {
+  for (int it = 0; it < kPre; ++it) {
     const int j = lane + it * kWave;
     if (j >= T) continue;
     int k = 0;
@@ -756,7 +800,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
 #pragma unroll
   for (int k = 0; k < KW; ++k) {
     cnts[k] = __builtin_amdgcn_readfirstlane(L.cnt[k]);
-    segbeg[k] = T;       // position in the CSR range / in L.idx
+    segbeg[k] = T;       // position in the CSR range
     segpad[k] = Tpad;    // position in the sorted LDS arrays: 4-aligned bucket starts
     T += cnts[k];
     Tpad += (cnts[k] + 3) & ~3;
@@ -764,22 +808,23 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const bool pooled = (Tpad <= CAPW);
   // (2) the wave's pooled bucket in one coalesced read: consecutive pillars own
   //     consecutive CSR ranges
-  int idx0 = 0, idx1 = 0;
-  Rec rec0, rec1;
-  rec0.x = rec0.y = rec0.z = rec0.w = 0;
-  rec1 = rec0;
+  int idx_r[kPre];
+  Rec rec_r[kPre];
+#pragma unroll
+  for (int it = 0; it < kPre; ++it) {
+    idx_r[it] = 0;
+    rec_r[it].x = rec_r[it].y = rec_r[it].z = rec_r[it].w = 0;
+  }
   if (pooled && T > 0) {
     const int start0 = __builtin_amdgcn_readfirstlane(L.start[0]);
     const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + start0;
     const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + start0;
-    if (lane < T) {
-      idx0 = sidx[lane];
-      rec0 = srec[lane];
-    }
-    if (lane + kWave < T) {
-      idx1 = sidx[lane + kWave];
-      rec1 = srec[lane + kWave];
-    }
+#pragma unroll
+    for (int it = 0; it < kPre; ++it)
+      if (lane + it * kWave < T) {
+        idx_r[it] = sidx[lane + it * kWave];
+        rec_r[it] = srec[lane + it * kWave];
+      }
   }
   // (3) scatter indices; dense modes: the zero padding that needs no point data
   float *outb = nullptr;
@@ -886,51 +931,23 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     return;
   }
   if (pooled) {
-    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx0, rec0, idx1, rec1, segbeg, segpad, cnts, T);
+    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx_r, rec_r, segbeg, segpad, cnts, T);
     if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn>(L, sg, rs, lane, segpad);
     if constexpr (MODE == kModePfn) {
 #pragma unroll
       for (int k = 0; k < KW; ++k) pfn_fold(k, segpad[k], min(cnts[k], N));
     }
   } else {
-    // the pool overflowed: one pillar at a time
+    // the pool overflowed: greedy runs of consecutive pillars that fit the pool,
+    // a pillar beyond the pool on its own through the ballot re-scan
+    int k = 0;
 #pragma unroll 1
-    for (int k = 0; k < KW; ++k) {
-      const int c = cnts[k];
-      if (c == 0) continue;
-      if (c <= CAPW) {
-        int sb1[KW], ck1[KW];
-#pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-          sb1[kk] = 0;
-          ck1[kk] = (kk == k) ? c : 0;
-        }
-        const int st = __builtin_amdgcn_readfirstlane(L.start[k]);
-        const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + st;
-        const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + st;
-        if (lane < c) {
-          idx0 = sidx[lane];
-          rec0 = srec[lane];
-        }
-        if (lane + kWave < c) {
-          idx1 = sidx[lane + kWave];
-          rec1 = srec[lane + kWave];
-        }
-        emit_group<TIn, MODE>(L, a, b, p0, k, k + 1, lane, idx0, rec0, idx1, rec1, sb1, sb1, ck1, c);
-        if constexpr (MODE == kModePfn) {
-          pfn_fold(k, 0, min(c, N));
-          wave_sync();
-        }
-        if (MODE == kModeDenseVec4) {
-          // late pass restricted to this pillar's lines: lines shared with another
-          // pooled pillar of this wave are completed by that pillar's own pass
-          // (both passes write identical zeros outside their own head groups)
-          SlabGeom s1 = sg;
-          s1.pooled = 1u << k;
-          s1.late_lines = slab_late_lines(sg, 1u << k);
-          store_slab<kPassLate, TIn>(L, s1, rs, lane, sb1);
-        }
-      } else {
+    while (k < KW) {
+      if (cnts[k] == 0) {
+        ++k;
+        continue;
+      }
+      if (cnts[k] > CAPW) {
         if constexpr (MODE == kModePfn) {
           float mx = -INFINITY, mn = INFINITY;
           emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane, &acc, &mx, &mn);
@@ -943,6 +960,60 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
         } else {
           emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane);
         }
+        wave_sync();
+        ++k;
+        continue;
+      }
+      const int kb = k;
+      int gpad = 0, graw = 0;
+      int sbg[KW], spg[KW], ckg[KW];
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+        sbg[kk] = 0;
+        spg[kk] = 0;
+        ckg[kk] = 0;
+      }
+      while (k < KW && cnts[k] <= CAPW && gpad + ((cnts[k] + 3) & ~3) <= CAPW) {
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk)
+          if (kk == k) {
+            sbg[kk] = graw;
+            spg[kk] = gpad;
+            ckg[kk] = cnts[kk];
+          }
+        graw += cnts[k];
+        gpad += (cnts[k] + 3) & ~3;
+        ++k;
+      }
+      unsigned gmask = 0;
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk)
+        if (ckg[kk] > 0) gmask |= 1u << kk;
+      const int st = __builtin_amdgcn_readfirstlane(L.start[kb]);  // kb is occupied
+      const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + st;
+      const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + st;
+#pragma unroll
+      for (int it = 0; it < kPre; ++it)
+        if (lane + it * kWave < graw) {
+          idx_r[it] = sidx[lane + it * kWave];
+          rec_r[it] = srec[lane + it * kWave];
+        }
+      emit_group<TIn, MODE>(L, a, b, p0, kb, k, lane, idx_r, rec_r, sbg, spg, ckg, graw);
+      if constexpr (MODE == kModePfn) {
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk)
+          if (ckg[kk] > 0) pfn_fold(kk, spg[kk], min(ckg[kk], N));
+        wave_sync();
+      }
+      if (MODE == kModeDenseVec4) {
+        // late pass restricted to this run's lines: a line shared with a pillar of
+        // another run is completed by that run's own pass (both write identical
+        // zeros outside their own head groups)
+        SlabGeom s1 = sg;
+        s1.pooled = gmask;
+        s1.late_lines = slab_late_lines(sg, gmask);
+        store_slab<kPassLate, TIn>(L, s1, rs, lane, spg);
+        wave_sync();
       }
     }
   }
