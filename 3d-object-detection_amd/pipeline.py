@@ -81,12 +81,21 @@ class PillarPipeline:
         """Call after changing the feature net's weights / BN statistics."""
         self._pfn_params = None
 
+    def upload_ground_truth(self, g):
+        """Host box arrays (centers / wlh / yaw / classes, canvas space) -> the device tuple
+        ``TargetAssigner.assign_device`` consumes (image-space corners are derived here,
+        utils/box_utils.py:19-32)."""
+        return self.assigner._gt_to_device(g["centers"], g["wlh"], g["yaw"], g["classes"])
+
     def train_forward_backward(self, points, gts, n_points=None):
         """train.py:139-147 without the optimizer: voxel stage, target stage, forward,
         loss, backward.  ``gts`` is a list (one per sweep) of dicts with
         centers / wlh / yaw / classes in canvas space."""
         pillars, indices = self.voxelize(points, n_points)
-        targets = [self.assigner.assign(g["centers"], g["wlh"], g["yaw"], g["classes"]) for g in gts]
+        # a ground-truth entry is either the dict of host arrays or the device tuple of
+        # upload_ground_truth() (what a prefetching loader hands over: no H2D copy, no sync)
+        targets = [self.assigner.assign_device(*g) if isinstance(g, tuple)
+                   else self.assigner.assign(g["centers"], g["wlh"], g["yaw"], g["classes"]) for g in gts]
         cls_t = torch.stack([t[0] for t in targets])
         reg_t = torch.stack([t[1] for t in targets])
         cls, reg = self.model(pillars, indices)

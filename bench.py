@@ -101,6 +101,8 @@ def main():
     clouds = np.stack([synth.lidar_like(N_POINTS, HALF, s) for s in sweep_ids])
     points = torch.from_numpy(clouds).to(dev)          # resident in HBM before timing
     gts = [synth.gt_boxes(40, cfg.canvas_height, s) for s in sweep_ids]
+    if a.mode == "train":   # boxes resident on the device like the points (a loader would prefetch them)
+        gts = [pipe.upload_ground_truth(g) for g in gts]
 
     def step():
         if a.mode == "fwd":
