@@ -220,23 +220,48 @@ __device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j
 // zero rows otherwise, the column maxima via 64-bit atomicMax on the f64 bit
 // pattern (IoU >= 0, so the patterns order like the values), and the list of
 // pairs with IoU > 0 for the column-argmax pass.
+//
+// Only ~0.16 % of the (anchor, gt) pairs pass the centre gate, but an anchor near
+// two or three boxes would clip them one after the other while the rest of its
+// wave idles.  The workgroup therefore queues its gated pairs in LDS (gate pass:
+// count, prefix sum, fill -- pairs of one anchor stay in ascending gt order) and
+// clips them one pair per lane, all lanes busy; each anchor then reduces its own
+// slice of the results.  A workgroup with more gated pairs than the queue holds
+// falls back to the serial loop.
+constexpr int kPairCap = 512;
+constexpr int kGtChunk = 256;  // ground-truth centres staged in LDS per pass (uniform global loads in
+                               // the gate loop are a 500-cycle round trip each: the loop is load-latency-bound)
+
 __global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
-  __shared__ double2 s_poly[16 * kIouThreads];
-  const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
-  const int64_t i = (int64_t)blockIdx.x * kIouThreads + threadIdx.x;
-  if (i >= t.A) return;
-  const double acx = t.a_centers[i * 3], acy = t.a_centers[i * 3 + 1];
+  // LDS budget decides how many workgroups are resident (the grid should fit in one
+  // round): vertex lists for ONE clipping wave (16 KB), centres, queue, results = 26 KB
+  __shared__ double2 s_poly[16 * 64];
+  __shared__ double2 s_gc[kGtChunk];
+  __shared__ double s_iou[kPairCap];
+  __shared__ unsigned short s_pair_lane[kPairCap], s_pair_gt[kPairCap];
+  __shared__ int s_off[kIouThreads / 64];
+  __shared__ u64 s_cmax[kGtChunk];        // column maxima of this workgroup
+  __shared__ unsigned s_npos[2], s_base;  // positives of this workgroup / their first list slot
+  const PolyLds pl{s_poly + (threadIdx.x & 63), 64};
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kIouThreads + tid;
+  const bool live = i < t.A;
+  double acx = 0, acy = 0;
+  if (live) {
+    acx = t.a_centers[i * 3];
+    acy = t.a_centers[i * 3 + 1];
+  }
   double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
   int best_j = 0;
   bool bad = false;
-  for (int j = 0; j < t.G; ++j) {
-    const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
-    if (gate_far(acx, acy, gcx, gcy)) continue;
-    const double v = pair_iou(t, i, j, &bad, pl);
+  auto row_max = [&](int j, double v) {
     if (v > best) {  // strict: first maximum wins, like np.argmax
       best = v;
       best_j = j;
     }
+  };
+  auto consume = [&](int j, double v) {  // overflow path only: one global atomic per pair
+    row_max(j, v);
     if (v > 0.0) {
       const u64 bits = (u64)__double_as_longlong(v);
       atomicMax(&t.col_max[j], bits);
@@ -244,8 +269,100 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
       if (pos < (unsigned)t.cand_cap)
         t.cand[pos] = make_int4((int)i, j, (int)(bits & 0xFFFFFFFFull), (int)(bits >> 32));
     }
+  };
+  for (int j0 = 0; j0 < t.G; j0 += kGtChunk) {
+    const int gn = min(kGtChunk, t.G - j0);
+    __syncthreads();
+    for (int j = tid; j < gn; j += kIouThreads) {
+      s_gc[j] = make_double2(t.g_centers_img[(int64_t)(j0 + j) * 3], t.g_centers_img[(int64_t)(j0 + j) * 3 + 1]);
+      s_cmax[j] = 0;
+    }
+    if (tid < 2) s_npos[tid] = 0;
+    __syncthreads();
+    // gate pass 1: count
+    int cnt = 0;
+    if (live)
+      for (int j = 0; j < gn; ++j) cnt += gate_far(acx, acy, s_gc[j].x, s_gc[j].y) ? 0 : 1;
+    // exclusive prefix sum of the counts over the workgroup (wave scans + wave totals)
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if ((tid & 63) >= d) inc += o;
+    }
+    if ((tid & 63) == 63) s_off[tid >> 6] = inc;
+    __syncthreads();
+    int wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kIouThreads / 64; ++w) {
+      if (w < (tid >> 6)) wave_base += s_off[w];
+      total += s_off[w];
+    }
+    const int my_off = wave_base + inc - cnt;
+    if (total == 0) continue;
+    if (total <= kPairCap) {
+      // gate pass 2: fill the queue (ascending gt inside each anchor's slice)
+      if (live) {
+        int q = my_off;
+        for (int j = 0; j < gn; ++j)
+          if (!gate_far(acx, acy, s_gc[j].x, s_gc[j].y)) {
+            s_pair_lane[q] = (unsigned short)tid;
+            s_pair_gt[q] = (unsigned short)j;
+            ++q;
+          }
+      }
+      __syncthreads();
+      const int64_t i0 = (int64_t)blockIdx.x * kIouThreads;
+      if (tid < 64)  // wave 0 clips, one pair per lane
+        for (int q = tid; q < total; q += 64)
+          s_iou[q] = pair_iou(t, i0 + s_pair_lane[q], j0 + s_pair_gt[q], &bad, pl);
+      __syncthreads();
+      if (live)
+        for (int q = my_off; q < my_off + cnt; ++q) row_max(j0 + s_pair_gt[q], s_iou[q]);
+      // Column maxima and the list of positive pairs: every pair with IoU > 0 needs an
+      // atomicMax on its column and a list slot.  Done per pair on global memory that is
+      // tens of thousands of atomics on G + 1 addresses, which the L2 serialises (it was
+      // 3/4 of this kernel); reduce in LDS and issue one global atomic per (workgroup,
+      // column) and one per workgroup for the list.
+      for (int q = tid; q < total; q += kIouThreads) {
+        const double v = s_iou[q];
+        if (v > 0.0) {
+          atomicMax(&s_cmax[s_pair_gt[q]], (u64)__double_as_longlong(v));
+          atomicAdd(&s_npos[0], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid == 0 && s_npos[0]) s_base = atomicAdd(t.cand_count, s_npos[0]);
+      for (int j = tid; j < gn; j += kIouThreads)
+        if (s_cmax[j]) atomicMax(&t.col_max[j0 + j], s_cmax[j]);
+      __syncthreads();
+      if (s_npos[0]) {
+        const unsigned base = s_base;
+        for (int q = tid; q < total; q += kIouThreads) {
+          const double v = s_iou[q];
+          if (v > 0.0) {
+            const unsigned pos = base + atomicAdd(&s_npos[1], 1u);
+            const u64 bits = (u64)__double_as_longlong(v);
+            if (pos < (unsigned)t.cand_cap)
+              t.cand[pos] = make_int4((int)(i0 + s_pair_lane[q]), j0 + s_pair_gt[q],
+                                      (int)(bits & 0xFFFFFFFFull), (int)(bits >> 32));
+          }
+        }
+      }
+    } else {
+      // queue overflow (never on real scenes): the two waves take turns on the vertex lists
+      for (int turn = 0; turn < kIouThreads / 64; ++turn) {
+        if (live && (tid >> 6) == turn)
+          for (int j = 0; j < gn; ++j) {
+            if (gate_far(acx, acy, s_gc[j].x, s_gc[j].y)) continue;
+            consume(j0 + j, pair_iou(t, i, j0 + j, &bad, pl));
+          }
+        __syncthreads();
+      }
+    }
   }
   if (bad) atomicExch(t.errflag, 1);
+  if (!live) return;
   float *cls = t.cls_targets + i * t.num_classes;
   float *reg = t.reg_targets + i * 9;
   const bool pos = best > t.pos_thresh;  // box_utils.py:195 (strict >)
@@ -495,7 +612,7 @@ extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
     set_error("pp_assign_targets_dev: NULL argument");
     return PP_ERR_VALUE;
   }
-  if (A < 1 || A > INT_MAX / 2 || G < 0 || G > 65536 || prm->num_classes < 1 ||
+  if (A < 1 || A > INT_MAX / 2 || G < 0 || G > 65535 || prm->num_classes < 1 ||
       prm->num_classes > 1024) {
     set_error("pp_assign_targets_dev: bad sizes (A=%lld G=%lld classes=%d)", (long long)A,
               (long long)G, prm->num_classes);
