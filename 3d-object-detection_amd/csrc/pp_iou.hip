@@ -407,8 +407,46 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_cols(TargetArgs t) {
 // the row written by T1 (box_utils.py:204-205, 212-213, 223-228).  A column
 // whose argmax is anchor 0 -- all-zero columns included -- is dropped, exactly
 // like the reference's np.nonzero filter.
+constexpr int kForcedLds = 2048;  // ground truths whose forced anchor / class are staged in LDS
+
 __global__ __launch_bounds__(kIouThreads) void k_targets_forced(TargetArgs t) {
   const int G = t.G;
+  if (G <= kForcedLds && t.num_classes <= 64) {
+    // One round trip to global memory for the column results, everything else in LDS.
+    // (The general path below is a chain of dependent global round trips, ~1.5 us each.)
+    __shared__ int s_i[kForcedLds];
+    __shared__ unsigned char s_c[kForcedLds];
+    for (int j = threadIdx.x; j < G; j += kIouThreads) {
+      s_i[j] = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
+      s_c[j] = (unsigned char)t.g_class[j];
+      t.col_max[j] = 0ull;  // re-arm the scratch words for the next call on this context
+      t.col_arg[j] = INT_MAX;
+    }
+    if (threadIdx.x == 0) *t.cand_count = 0u;
+    __syncthreads();
+    for (int j = threadIdx.x; j < G; j += kIouThreads) {
+      const int i = s_i[j];
+      if (i == 0) continue;
+      // class row of anchor i: ones at the classes of ALL ground truths forcing it (every
+      // duplicate writes the same full row); regression row: the last ground truth wins
+      u64 mask = 0;
+      bool later = false;
+      for (int j2 = 0; j2 < G; ++j2)
+        if (s_i[j2] == i) {
+          mask |= 1ull << (s_c[j2] & 63);
+          later = later || (j2 > j);
+        }
+      float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+      for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;
+      if (!later) {
+        float r[9];
+        make_target_dev(t, i, j, r);
+        float *reg = t.reg_targets + (int64_t)i * 9;
+        for (int d = 0; d < 9; ++d) reg[d] = r[d];
+      }
+    }
+    return;
+  }
   // phase A: clear the class rows of all forced anchors
   for (int j = threadIdx.x; j < G; j += kIouThreads) {
     const int i = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
@@ -424,7 +462,8 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_forced(TargetArgs t) {
   for (int j = threadIdx.x; j < G; j += kIouThreads) {
     const int i = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
     if (i == 0) continue;
-    t.cls_targets[(int64_t)i * t.num_classes + t.g_class[j]] = 1.0f;
+    if ((unsigned)t.g_class[j] < (unsigned)t.num_classes)  // a class outside the row is ignored, never written
+      t.cls_targets[(int64_t)i * t.num_classes + t.g_class[j]] = 1.0f;
     bool later = false;
     for (int j2 = j + 1; j2 < G; ++j2) {
       const int i2 = (t.col_max[j2] != 0ull) ? t.col_arg[j2] : 0;
