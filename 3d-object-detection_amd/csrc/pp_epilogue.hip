@@ -46,9 +46,87 @@ __global__ __launch_bounds__(256) void k_bias_relu_bn(const float *__restrict__ 
   }
 }
 
+// NHWC form: x [pixels][C] contiguous, y rows of y_stride floats (a channel slice of the
+// concatenated output, or x itself).  One float4 = 4 consecutive channels per lane; when C/4
+// divides the grid stride a lane keeps its channel group, so its 12 table values sit in
+// registers for the whole loop.
+template <bool kFixedLane>
+__global__ __launch_bounds__(256) void k_bias_relu_bn_nhwc(const float4 *__restrict__ x,
+                                                           float *__restrict__ y, int c4,
+                                                           int64_t n4, int64_t y_stride,
+                                                           const float *__restrict__ prm) {
+  const int64_t step = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float4 b, s, t;
+  auto load_table = [&](int g) {
+    const float *q = prm + (int64_t)g * 12;
+    b = make_float4(q[0], q[3], q[6], q[9]);
+    s = make_float4(q[1], q[4], q[7], q[10]);
+    t = make_float4(q[2], q[5], q[8], q[11]);
+  };
+  if (kFixedLane) load_table((int)(i % c4));
+  for (; i < n4; i += step) {
+    const int64_t pix = i / c4;
+    const int g = (int)(i - pix * c4);
+    if (!kFixedLane) load_table(g);
+    float4 v = x[i];
+    v.x = fmaxf(v.x + b.x, 0.0f) * s.x + t.x;
+    v.y = fmaxf(v.y + b.y, 0.0f) * s.y + t.y;
+    v.z = fmaxf(v.z + b.z, 0.0f) * s.z + t.z;
+    v.w = fmaxf(v.w + b.w, 0.0f) * s.w + t.w;
+    *reinterpret_cast<float4 *>(y + pix * y_stride + (int64_t)g * 4) = v;
+  }
+}
+
 }  // namespace pp
 
 using namespace pp;
+
+extern "C" int pp_bias_relu_bn_nhwc_dev(pp_ctx_t *ctx, void *stream_, float *x_dev, int64_t pixels,
+                                        int channels, const float *params_dev, float *y_dev,
+                                        int64_t y_channels, int64_t y_channel_offset) {
+  if (!y_dev) {  // in place
+    y_dev = x_dev;
+    y_channels = channels;
+    y_channel_offset = 0;
+  }
+  if (!ctx || !x_dev || !params_dev) {
+    set_error("pp_bias_relu_bn_nhwc_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (pixels < 1 || channels < 4 || (channels & 3) || (y_channels & 3) || (y_channel_offset & 3) ||
+      y_channel_offset < 0 || y_channel_offset + channels > y_channels ||
+      ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(y_dev)) & 15)) {
+    set_error("pp_bias_relu_bn_nhwc_dev: need channels, y_channels, y_channel_offset multiples of 4, "
+              "the slice inside y, 16-byte aligned tensors (pixels=%lld channels=%d y_channels=%lld "
+              "offset=%lld)", (long long)pixels, channels, (long long)y_channels,
+              (long long)y_channel_offset);
+    return PP_ERR_VALUE;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+  const int c4 = channels / 4;
+  const int64_t n4 = pixels * c4;
+  // 256 CUs x 8 workgroups in flight; a grid stride that is a multiple of 256 keeps the lane's
+  // channel group fixed whenever c4 divides 256
+  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 2048);
+  float *y = y_dev + y_channel_offset;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (256 % c4 == 0)
+    hipLaunchKernelGGL(k_bias_relu_bn_nhwc<true>, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(x_dev), y, c4, n4, y_channels, params_dev);
+  else
+    hipLaunchKernelGGL(k_bias_relu_bn_nhwc<false>, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(x_dev), y, c4, n4, y_channels, params_dev);
+  hipError_t e = hipGetLastError();
+  if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("k_bias_relu_bn_nhwc launch failed: %s", hipGetErrorString(e));
+    return PP_ERR_HIP;
+  }
+  return PP_OK;
+}
 
 extern "C" int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream_, float *x_dev, int64_t batch,
                                    int channels, int64_t hw, const float *params_dev,

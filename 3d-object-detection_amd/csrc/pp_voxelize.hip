@@ -336,7 +336,10 @@ struct EmitArgs {
   double *feat_out;  // [B][ncap][9]
   // fused feature-net mode
   const float *pfn_w;  // [64][12]: w[0..8], bias, bn scale, bn shift per output channel
-  float *pfn_out;      // [B][64][P]
+  float *pfn_out;      // [B][64][P], or NULL when only the canvas is wanted
+  // ... scattered straight into the BEV canvas (PPScatter, model/model.py:53-62)
+  float *canvas;       // NULL, [B][H][W][64] (channels last) or [B][64][H][W]
+  int canvas_h, canvas_w, canvas_nhwc;
 };
 
 enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 };
@@ -916,13 +919,31 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       }
       yv[k] = fmaf(acc.scale >= 0.0f ? mx : mn, acc.scale, acc.shift);
     }
-    float *o = a.pfn_out + ((int64_t)b * kPfnChannels + lane) * P + p0;
-    if (kw_eff == KW && (P & 3) == 0) {
-      *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
-    } else {
+    if (a.pfn_out) {
+      float *o = a.pfn_out + ((int64_t)b * kPfnChannels + lane) * P + p0;
+      if (kw_eff == KW && (P & 3) == 0) {
+        *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+      } else {
 #pragma unroll
-      for (int k = 0; k < KW; ++k)
-        if (k < kw_eff) o[k] = yv[k];
+        for (int k = 0; k < KW; ++k)
+          if (k < kw_eff) o[k] = yv[k];
+      }
+    }
+    if (a.canvas) {
+      // out[b, :, row, col] = x[b, :, p] for the flagged pillars only (model/model.py:56-61);
+      // channels last: the 64 lanes write one 256-byte pixel
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        if (k >= kw_eff || cnts[k] == 0) continue;
+        double cx, cy;
+        pillar_canvas(L.slot[k], a.g, cx, cy);
+        const int64_t col = (int64_t)cx, row = (int64_t)cy;
+        if (row < 0 || row >= a.canvas_h || col < 0 || col >= a.canvas_w) continue;
+        if (a.canvas_nhwc)
+          a.canvas[((((int64_t)b * a.canvas_h + row) * a.canvas_w) + col) * kPfnChannels + lane] = yv[k];
+        else
+          a.canvas[((((int64_t)b * kPfnChannels + lane) * a.canvas_h) + row) * a.canvas_w + col] = yv[k];
+      }
     }
   };
   // (4) the points
@@ -1179,7 +1200,9 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     int64_t s0, int64_t s1, int contig, const NPoints &np, int B,
                     int maxn, const GridGeom &g, int P, int N, const VoxLayout &l,
                     int mode, float *out, long long *idx_out, double *feat_out,
-                    bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr) {
+                    bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr,
+                    float *canvas = nullptr, int canvas_h = 0, int canvas_w = 0,
+                    int canvas_nhwc = 0) {
   char *ws = static_cast<char *>(ctx->vox_ws.ptr);
   int *cursor = reinterpret_cast<int *>(ws + l.cursor);
   int2 *cell_rank = reinterpret_cast<int2 *>(ws + l.cell_rank);
@@ -1219,6 +1242,10 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.feat_out = feat_out;
   a.pfn_w = pfn_w;
   a.pfn_out = pfn_out;
+  a.canvas = canvas;
+  a.canvas_h = canvas_h;
+  a.canvas_w = canvas_w;
+  a.canvas_nhwc = canvas_nhwc;
   const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
   // When the timing ring is armed the emit launch carries its own start/stop events
   // (hipExtLaunchKernelGGL binds them to the dispatch packet, so the pair brackets the
@@ -1347,13 +1374,15 @@ extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points
   return PP_OK;
 }
 
-extern "C" int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
-                                   int64_t points_stride, const int32_t *n_points, int batch,
-                                   const pp_voxel_params_t *prm, const float *pfn_params_dev,
-                                   int channels, float *features_dev, int64_t *indices_dev,
-                                   int32_t *num_cells_dev) {
-  if (!ctx || !points_dev || !n_points || !prm || !pfn_params_dev || !features_dev || !indices_dev) {
-    set_error("pp_voxelize_pfn_dev: NULL argument");
+static int voxelize_pfn_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                             int64_t points_stride, const int32_t *n_points, int batch,
+                             const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                             int channels, float *features_dev, int64_t *indices_dev,
+                             int32_t *num_cells_dev, float *canvas_dev, int canvas_h, int canvas_w,
+                             int channels_last) {
+  if (!ctx || !points_dev || !n_points || !prm || !pfn_params_dev || !indices_dev ||
+      (!features_dev && !canvas_dev)) {
+    set_error("pp_voxelize_pfn*_dev: NULL argument");
     return PP_ERR_VALUE;
   }
   if (channels != kPfnChannels) {
@@ -1398,10 +1427,25 @@ extern "C" int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream_, const float *po
   VoxLayout l;
   rc = prepare_ws(ctx, stream, batch, std::max<int64_t>(points_stride, 1), g, P, 16, &l);
   if (rc) return rc;
+  if (canvas_dev) {
+    // rows are (H-1) - fy with H = canvas_height (pillars.cpp:280).  The cell grid carries one
+    // guard row/column for the rounding of (x - x_min)/x_step at the upper edge (never
+    // populated by f32 input); a pillar whose pixel is outside the canvas is not written.
+    if ((double)canvas_h != g.canvas_height || canvas_h < 1 || canvas_w < 1 ||
+        (reinterpret_cast<uintptr_t>(canvas_dev) & 15)) {
+      set_error("canvas %dx%d: height must equal canvas_height=%g (and the tensor be 16-byte "
+                "aligned)", canvas_h, canvas_w, g.canvas_height);
+      return PP_ERR_VALUE;
+    }
+    PP_HIP_TRY(hipMemsetAsync(canvas_dev, 0,
+                              (size_t)batch * kPfnChannels * canvas_h * canvas_w * sizeof(float),
+                              stream));
+  }
   rc = launch_pipeline<float>(ctx, stream, points_dev, points_stride, 4, 1, 1, np, batch, maxn,
                               g, P, N, l, kModePfn, nullptr,
                               reinterpret_cast<long long *>(indices_dev), nullptr, true,
-                              pfn_params_dev, features_dev);
+                              pfn_params_dev, features_dev, canvas_dev, canvas_h, canvas_w,
+                              channels_last ? 1 : 0);
   if (rc) return rc;
   if (num_cells_dev) {
     char *ws = static_cast<char *>(ctx->vox_ws.ptr);
@@ -1409,6 +1453,36 @@ extern "C" int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream_, const float *po
                               hipMemcpyDeviceToDevice, stream));
   }
   return PP_OK;
+}
+
+extern "C" int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                   int64_t points_stride, const int32_t *n_points, int batch,
+                                   const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                                   int channels, float *features_dev, int64_t *indices_dev,
+                                   int32_t *num_cells_dev) {
+  if (!features_dev) {
+    set_error("pp_voxelize_pfn_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  return voxelize_pfn_impl(ctx, stream_, points_dev, points_stride, n_points, batch, prm,
+                           pfn_params_dev, channels, features_dev, indices_dev, num_cells_dev,
+                           nullptr, 0, 0, 0);
+}
+
+extern "C" int pp_voxelize_pfn_canvas_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                          int64_t points_stride, const int32_t *n_points,
+                                          int batch, const pp_voxel_params_t *prm,
+                                          const float *pfn_params_dev, int channels,
+                                          float *canvas_dev, int canvas_h, int canvas_w,
+                                          int channels_last, int64_t *indices_dev,
+                                          int32_t *num_cells_dev) {
+  if (!canvas_dev) {
+    set_error("pp_voxelize_pfn_canvas_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  return voxelize_pfn_impl(ctx, stream_, points_dev, points_stride, n_points, batch, prm,
+                           pfn_params_dev, channels, nullptr, indices_dev, num_cells_dev,
+                           canvas_dev, canvas_h, canvas_w, channels_last);
 }
 
 extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,

@@ -44,23 +44,70 @@ class _Epilogue:
         return self._table
 
     def __call__(self, y, bias, bn, out=None, channel_offset=0):
-        """In place on ``y`` [B,C,H,W], or into channels [channel_offset, +C) of ``out``."""
+        """In place on ``y`` [B,C,H,W], or into channels [channel_offset, +C) of ``out``.
+        ``y`` (and ``out``) may be NCHW-contiguous or channels-last."""
         dev = y.device
         ctx = _Epilogue._ctx.get(dev.index)
         if ctx is None:
             ctx = _Epilogue._ctx[dev.index] = _lib.Context(dev.index)
         tab = self.table(bias, bn)
         B, C, H, W = y.shape
-        if out is not None and (out.shape[0] != B or out.shape[2:] != y.shape[2:]
-                                or not out.is_contiguous() or out.dtype != y.dtype):
+        nhwc = _is_nhwc(y)
+        if out is not None and (out.shape[0] != B or out.shape[2:] != y.shape[2:] or out.dtype != y.dtype
+                                or (_is_nhwc(out) if nhwc else out.is_contiguous()) is not True):
             raise ValueError("epilogue destination does not match the source")
-        rc = _lib.lib().pp_bias_relu_bn_dev(
-            ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-            ctypes.c_void_p(y.data_ptr()), B, C, H * W, ctypes.c_void_p(tab.data_ptr()),
-            ctypes.c_void_p(out.data_ptr()) if out is not None else None,
-            out.shape[1] if out is not None else C, int(channel_offset))
-        _lib.check(rc, "pp_bias_relu_bn_dev")
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        dst = ctypes.c_void_p(out.data_ptr()) if out is not None else None
+        if nhwc:
+            rc = _lib.lib().pp_bias_relu_bn_nhwc_dev(
+                ctx.handle, stream, ctypes.c_void_p(y.data_ptr()), B * H * W, C,
+                ctypes.c_void_p(tab.data_ptr()), dst, out.shape[1] if out is not None else C,
+                int(channel_offset))
+            _lib.check(rc, "pp_bias_relu_bn_nhwc_dev")
+        else:
+            rc = _lib.lib().pp_bias_relu_bn_dev(
+                ctx.handle, stream, ctypes.c_void_p(y.data_ptr()), B, C, H * W,
+                ctypes.c_void_p(tab.data_ptr()), dst, out.shape[1] if out is not None else C,
+                int(channel_offset))
+            _lib.check(rc, "pp_bias_relu_bn_dev")
         return y if out is None else out
+
+
+def _is_nhwc(t):
+    """Dense channels-last 4-d tensor that is not also NCHW-contiguous."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+def _dense(t):
+    """``t`` itself when it is dense in a layout the epilogue kernels take (the channels-last
+    kernel works on groups of 4 channels), else an NCHW copy."""
+    if _is_nhwc(t):
+        return t if t.shape[1] % 4 == 0 else t.contiguous()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _LayoutCache:
+    """A parameter re-laid-out once per version (channels-last conv weights; the merged
+    head), so the inference path launches no per-call conversion kernels."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors, make):
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self._key:
+            with torch.no_grad():
+                self._val = make()
+            self._key = key
+        return self._val
+
+
+def _weight_like(x, weight, cache):
+    """The conv weight in the memory format of the activation ``x``."""
+    if not _is_nhwc(x):
+        return weight
+    return cache.get((weight,), lambda: weight.detach().contiguous(memory_format=torch.channels_last))
 
 
 def _use_fused_epilogue(module, x):
@@ -121,11 +168,21 @@ class PPScatter(nn.Module):
     def __init__(self, canvas_height, canvas_width):
         super().__init__()
         self.h, self.w = int(canvas_height), int(canvas_width)
+        #: inference on the GPU: build the canvas channels-last (what MIOpen's NHWC kernels
+        #: take); one flat [B*H*W + 1, C] buffer whose last row absorbs the unflagged pillars,
+        #: so the canvas is a view of it and nothing is copied
+        self.channels_last_inference = True
 
     def forward(self, x, inds):            # x [B,C,P], inds [B,P,3] int64
         B, C, P = x.shape
         hw = self.h * self.w
         lin = inds[:, :, 2] * self.w + inds[:, :, 1]
+        if (not self.training) and self.channels_last_inference and x.is_cuda and not torch.is_grad_enabled():
+            base = torch.arange(B, device=x.device, dtype=lin.dtype).unsqueeze(1) * hw
+            lin = torch.where(inds[:, :, 0] != 0, lin + base, torch.full_like(lin, B * hw))
+            flat = x.new_zeros((B * hw + 1, C))
+            flat.scatter_(0, lin.reshape(B * P, 1).expand(B * P, C), x.transpose(1, 2).reshape(B * P, C))
+            return flat[:B * hw].view(B, self.h, self.w, C).permute(0, 3, 1, 2)
         lin = torch.where(inds[:, :, 0] != 0, lin, torch.full_like(lin, hw))
         out = x.new_zeros((B, C, hw + 1))
         out.scatter_(2, lin.unsqueeze(1).expand(B, C, P), x)
@@ -146,14 +203,15 @@ class PPDownBlock(nn.Module):
         #: inference only: conv without bias + one fused bias/ReLU/BatchNorm pass per layer
         self.fused_epilogue = True
         self._epi = [_Epilogue() for _ in range(num_layers)]
+        self._wcl = [_LayoutCache() for _ in range(num_layers)]
 
     def forward(self, x):
         if not _use_fused_epilogue(self, x):
             return self.block(x)
         for i, epi in enumerate(self._epi):
             conv, bn = self.block[3 * i], self.block[3 * i + 2]
-            x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
-            x = epi(x if x.is_contiguous() else x.contiguous(), conv.bias, bn)
+            x = F.conv2d(x, _weight_like(x, conv.weight, self._wcl[i]), None, conv.stride, conv.padding)
+            x = epi(_dense(x), conv.bias, bn)
         return x
 
 
@@ -167,14 +225,17 @@ class PPUpBlock(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels)
         self.fused_epilogue = True
         self._epi = _Epilogue()
+        self._wcl = _LayoutCache()
 
     def forward(self, x, out=None, channel_offset=0):
         if not _use_fused_epilogue(self, x):
             return self.bn(F.relu(self.conv2d_t(x)))
         ct = self.conv2d_t
-        y = F.conv_transpose2d(x, ct.weight, None, ct.stride, ct.padding, ct.output_padding)
-        return self._epi(y if y.is_contiguous() else y.contiguous(), ct.bias, self.bn, out,
-                         channel_offset)
+        y = F.conv_transpose2d(x, _weight_like(x, ct.weight, self._wcl), None, ct.stride, ct.padding,
+                               ct.output_padding)
+        if out is not None and _is_nhwc(out) != _is_nhwc(y):
+            y = y.contiguous(memory_format=torch.channels_last if _is_nhwc(out) else torch.contiguous_format)
+        return self._epi(_dense(y), ct.bias, self.bn, out, channel_offset)
 
 
 def up3_output_padding(canvas):
@@ -208,7 +269,8 @@ class PPBackbone(nn.Module):
             # output directly (no torch.cat copy)
             c = self.up1.conv2d_t.out_channels
             x = self.down1(x)
-            out = x.new_empty((x.shape[0], 3 * c, x.shape[2], x.shape[3]))
+            out = torch.empty((x.shape[0], 3 * c, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device,
+                              memory_format=torch.channels_last if _is_nhwc(x) else torch.contiguous_format)
             self.up1(x, out, 0)
             x = self.down2(x)
             self.up2(x, out, c)
@@ -231,9 +293,21 @@ class PPDetectionHead(nn.Module):
         super().__init__()
         self.cls = nn.Conv2d(in_channels, cls_out_channels, kernel_size=1, stride=1)
         self.reg = nn.Conv2d(in_channels, reg_out_channels, kernel_size=1, stride=1)
+        #: inference on channels-last activations: both 1x1 convolutions as ONE (the 384-channel
+        #: input is read once); the results are channel slices of the merged output
+        self.merge_heads = True
+        self._merged = _LayoutCache()
 
     def forward(self, x):
-        return self.cls(x), self.reg(x)
+        if self.training or not self.merge_heads or not x.is_cuda or not _is_nhwc(x):
+            return self.cls(x), self.reg(x)
+        w, b = self._merged.get(
+            (self.cls.weight, self.cls.bias, self.reg.weight, self.reg.bias),
+            lambda: (torch.cat((self.cls.weight, self.reg.weight), 0).contiguous(memory_format=torch.channels_last),
+                     torch.cat((self.cls.bias, self.reg.bias), 0)))
+        y = F.conv2d(x, w, b)
+        n = self.cls.out_channels
+        return y[:, :n], y[:, n:]
 
 
 class PPModel(nn.Module):
@@ -256,6 +330,11 @@ class PPModel(nn.Module):
         x = self.scatter(x, inds)
         x = self.backbone(x)
         return self.det_head(x)
+
+    def forward_canvas(self, canvas):
+        """The network from PPScatter's output on: ``canvas[B,C,H,W]`` in either memory
+        format (the fused HIP voxelizer + feature net + scatter writes it channels-last)."""
+        return self.det_head(self.backbone(canvas))
 
     def forward_features(self, feats, inds):
         """Same network from PPFeatureNet's output ``feats[B,C,P]`` on (the fused

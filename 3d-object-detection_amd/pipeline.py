@@ -37,7 +37,10 @@ class PillarPipeline:
                                            device=self.device)
         self._bufs = None
         self._fbufs = None
+        self._cbuf = None
         self._pfn_params = None
+        #: forward_fused also fuses PPScatter and runs the backbone channels-last
+        self.fused_scatter = True
 
     def _buffers(self, batch):
         cfg = self.vox_cfg
@@ -74,8 +77,21 @@ class PillarPipeline:
             P = self.vox_cfg.max_pillars
             self._fbufs = (torch.empty((B, 64, P), dtype=torch.float32, device=self.device),
                            torch.empty((B, P, 3), dtype=torch.int64, device=self.device))
+        if self.fused_scatter:
+            # ... and PPScatter too: the emit kernel writes each pillar's 64 features to its
+            # channels-last canvas pixel
+            H, W = self.model.scatter.h, self.model.scatter.w
+            canvas, _ = self.voxelizer.pfn_canvas(points, self._pfn_params, (H, W), n_points=n_points,
+                                                  out=(self._canvas(B, H, W), self._fbufs[1]))
+            return self.model.forward_canvas(canvas)
         feats, indices = self.voxelizer.pfn(points, self._pfn_params, n_points=n_points, out=self._fbufs)
         return self.model.forward_features(feats, indices)
+
+    def _canvas(self, B, H, W):
+        if self._cbuf is None or self._cbuf.shape != (B, 64, H, W):
+            self._cbuf = torch.empty((B, 64, H, W), dtype=torch.float32, device=self.device,
+                                     memory_format=torch.channels_last)
+        return self._cbuf
 
     def invalidate_fused_params(self):
         """Call after changing the feature net's weights / BN statistics."""

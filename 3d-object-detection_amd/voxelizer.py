@@ -129,6 +129,43 @@ class PillarVoxelizer:
             return feats, indices, counts
         return feats, indices
 
+    def pfn_canvas(self, points, pfn_params, canvas_hw, n_points=None, channels_last=True,
+                   out=None, return_counts=False):
+        """Voxelizer + feature net + PPScatter (model/model.py:31-62) in one pass:
+        returns ``(canvas[B,64,H,W] f32, indices[B,P,3] i64)``; with
+        ``channels_last`` the canvas is a channels-last tensor (same logical shape,
+        memory [B,H,W,64]) that MIOpen's NHWC convolutions consume directly."""
+        points, B, ncap, n_arr = self._prep(points, n_points)
+        P = self.cfg.max_pillars
+        H, W = int(canvas_hw[0]), int(canvas_hw[1])
+        if (pfn_params.shape != (64, 12) or pfn_params.dtype != torch.float32
+                or pfn_params.device != self.device or not pfn_params.is_contiguous()):
+            raise ValueError("pfn_params must be a contiguous float32 [64,12] tensor on " + str(self.device))
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        if out is None:
+            canvas = torch.empty((B, 64, H, W), dtype=torch.float32, device=self.device, memory_format=fmt)
+            indices = torch.empty((B, P, 3), dtype=torch.int64, device=self.device)
+        else:
+            canvas, indices = out
+            if (canvas.shape != (B, 64, H, W) or canvas.dtype != torch.float32
+                    or not canvas.is_contiguous(memory_format=fmt)
+                    or indices.shape != (B, P, 3) or indices.dtype != torch.int64
+                    or not indices.is_contiguous()):
+                raise ValueError("out buffers have the wrong shape/dtype/layout")
+        counts = (torch.empty((B, 2), dtype=torch.int32, device=self.device)
+                  if return_counts else None)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.lib().pp_voxelize_pfn_canvas_dev(
+            self._ctx.handle, ctypes.c_void_p(stream), ctypes.c_void_p(points.data_ptr()),
+            ncap, n_arr, B, ctypes.byref(self._prm), ctypes.c_void_p(pfn_params.data_ptr()), 64,
+            ctypes.c_void_p(canvas.data_ptr()), H, W, 1 if channels_last else 0,
+            ctypes.c_void_p(indices.data_ptr()),
+            ctypes.c_void_p(counts.data_ptr()) if counts is not None else None)
+        _lib.check(rc, "pp_voxelize_pfn_canvas_dev")
+        if return_counts:
+            return canvas, indices, counts
+        return canvas, indices
+
     def __call__(self, points, n_points=None, out=None, return_counts=False):
         cfg = self.cfg
         points, B, ncap, n_arr = self._prep(points, n_points)

@@ -102,6 +102,22 @@ int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                         int32_t *num_cells_dev);
 
 /*
+ * The same, with PPScatter.forward fused in as well (model/model.py:53-62): the feature
+ * vector of every flagged pillar goes straight to its pixel of the BEV canvas,
+ * canvas[b, :, row, col] = features[b, :, p]; the [batch][64][P] tensor is never built.
+ *   canvas_dev   f32, fully written (zeroed, then scattered): [batch][64][canvas_h][canvas_w]
+ *                or, with channels_last != 0, [batch][canvas_h][canvas_w][64] (one 256-byte
+ *                store per pillar; the layout MIOpen's NHWC convolutions take directly)
+ *   canvas_h     must equal prm->canvas_height; a pillar whose pixel falls outside
+ *                canvas_h x canvas_w is not written (PPScatter would raise there)
+ */
+int pp_voxelize_pfn_canvas_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
+                               int64_t points_stride, const int32_t *n_points, int batch,
+                               const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                               int channels, float *canvas_dev, int canvas_h, int canvas_w,
+                               int channels_last, int64_t *indices_dev, int32_t *num_cells_dev);
+
+/*
  * Host drop-in for create_pillars (pillars.cpp:236-249, exported :433).
  * points [n,>=4], tensor [P',N',>=9], indices [P',>=3]: f64 host arrays with
  * arbitrary BYTE strides, mutated in place; nothing is zeroed (pillars.cpp never
@@ -225,6 +241,13 @@ int pp_decode_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, const float
 int pp_bias_relu_bn_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t batch, int channels,
                         int64_t hw, const float *params_dev, float *y_dev, int64_t y_channels,
                         int64_t y_channel_offset);
+
+/* The same epilogue on a channels-last tensor: x_dev [pixels][channels] f32 (pixels =
+ * batch*h*w), channels a multiple of 4; the result goes in place (y_dev NULL) or to
+ * channels [y_channel_offset, +channels) of y_dev [pixels][y_channels]. */
+int pp_bias_relu_bn_nhwc_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t pixels, int channels,
+                             const float *params_dev, float *y_dev, int64_t y_channels,
+                             int64_t y_channel_offset);
 
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its

@@ -91,3 +91,68 @@ def test_fused_pipeline_equals_dense_pipeline(gpu):
     pipe.model.train()
     with pytest.raises(RuntimeError):
         pipe.forward_fused(pts)
+
+
+def test_fused_scatter_canvas_equals_ppscatter(gpu):
+    """pp_voxelize_pfn_canvas_dev == PPScatter(PPFeatureNet(...)) (model/model.py:53-62), bit for
+    bit against the unfused pfn output scattered by PyTorch: both memory layouts, overflow
+    (cells > P: the dropped cells stay zero), a ragged batch with an empty sweep."""
+    import torch
+    import pp_amd.model as M
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    half, step, P, N = 24.0, 0.2, 3000, 16
+    vox = PillarVoxelizer(VoxelConfig.square(half, step, P, N), device=gpu)
+    H = W = vox.cfg.canvas_height
+    fn = _net(gpu)
+    pts = torch.from_numpy(np.stack([synth.lidar_like(20000, half, s) for s in (1, 2, 3)])).to(gpu)
+    n_points = [20000, 700, 0]
+    feats, idx, cnt = vox.pfn(pts, fn.fused_params(), n_points=n_points, return_counts=True)
+    assert cnt[0, 0].item() > P          # overflow regime on sweep 0
+    sc = M.PPScatter(H, W)
+    sc.channels_last_inference = False
+    want = sc(feats, idx)
+    for cl in (True, False):
+        canvas, idx2 = vox.pfn_canvas(pts, fn.fused_params(), (H, W), n_points=n_points, channels_last=cl)
+        torch.cuda.synchronize()
+        assert canvas.shape == (3, 64, H, W)
+        assert canvas.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+        assert torch.equal(idx, idx2)
+        assert torch.equal(canvas, want)
+    assert (canvas[2] == 0).all()
+    # stale contents of a reused canvas are cleared
+    buf = torch.full((3, 64, H, W), 7.0, device=gpu).contiguous(memory_format=torch.channels_last)
+    out_idx = torch.empty_like(idx)
+    vox.pfn_canvas(pts, fn.fused_params(), (H, W), n_points=n_points, out=(buf, out_idx))
+    assert torch.equal(buf, want)
+    with pytest.raises(Exception):
+        vox.pfn_canvas(pts, fn.fused_params(), (H - 1, W), n_points=n_points)
+    # the channels-last PPScatter of the inference path gives the same canvas, as a view
+    sc2 = M.PPScatter(H, W).eval()
+    with torch.no_grad():
+        got = sc2(feats, idx)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+
+
+def test_fused_scatter_pipeline_equals_dense_pipeline(gpu):
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    pipe = PillarPipeline(VoxelConfig.square(16.0, 0.2, 4000, 32), feature_channels=64, device=gpu, seed=0)
+    pipe.model.eval()
+    pts = torch.from_numpy(np.stack([synth.lidar_like(15000, 16.0, s) for s in (3, 4)])).to(gpu)
+    outs = {}
+    for name, fs, cl in (("nhwc", True, True), ("feats", False, True), ("nchw", False, False)):
+        pipe.fused_scatter = fs
+        pipe.model.scatter.channels_last_inference = cl
+        outs[name] = tuple(t.clone() for t in pipe.forward_fused(pts))
+    outs["dense"] = pipe.forward(pts)
+    torch.cuda.synchronize()
+    c0, r0 = outs["nchw"]
+    assert c0.shape[0] == 2 and c0.shape[1] == 18 and r0.shape[1] == 16
+    for name in ("nhwc", "feats", "dense"):
+        c, r = outs[name]
+        assert c.shape == c0.shape and r.shape == r0.shape
+        assert (c - c0).abs().max().item() <= 1e-4 * max(1.0, c0.abs().max().item()), name
+        assert (r - r0).abs().max().item() <= 1e-4 * max(1.0, r0.abs().max().item()), name

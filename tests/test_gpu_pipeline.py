@@ -104,3 +104,50 @@ def test_fused_epilogue_equals_relu_batchnorm(gpu):
         d.fused_epilogue = False
         b = d(xx)
     assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+
+
+def test_channels_last_backbone_equals_nchw(gpu):
+    """The inference backbone + merged head on a channels-last canvas (MIOpen NHWC kernels,
+    the NHWC epilogue writing channel slices of the concatenated output) == the NCHW path
+    == plain Conv2d -> ReLU -> BatchNorm2d modules."""
+    import torch
+    import pp_amd.model as M
+    torch.manual_seed(7)
+    bb = M.PPBackbone(16, up3_op=M.up3_output_padding(100)).to(gpu)
+    head = M.PPDetectionHead(96, 18, 16).to(gpu)
+    with torch.no_grad():
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.4, 2.0)
+                m.weight.normal_(0, 1.0)
+                m.bias.normal_(0, 0.2)
+    bb.eval()
+    head.eval()
+    x = torch.randn(3, 16, 100, 100, device=gpu)
+    with torch.no_grad():
+        y_nchw = bb(x)
+        c_nchw, r_nchw = head(y_nchw)
+        y_cl = bb(x.contiguous(memory_format=torch.channels_last))
+        c_cl, r_cl = head(y_cl)
+        for m in bb.modules():
+            if hasattr(m, "fused_epilogue"):
+                m.fused_epilogue = False
+        y_ref = bb(x)
+        c_ref, r_ref = head(y_ref)
+    assert y_cl.shape == y_ref.shape == (3, 96, 50, 50)
+    assert y_cl.is_contiguous(memory_format=torch.channels_last)
+    tol = 2e-4 * max(1.0, y_ref.abs().max().item())
+    assert (y_cl - y_ref).abs().max().item() <= tol
+    assert (y_nchw - y_ref).abs().max().item() <= tol
+    for a, b in ((c_cl, c_ref), (r_cl, r_ref), (c_nchw, c_ref), (r_nchw, r_ref)):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+    # channel counts that are not multiples of 4 fall back to the NCHW kernel
+    d = M.PPDownBlock(2, 3, 5).to(gpu).eval()
+    xx = torch.randn(1, 3, 37, 41, device=gpu)
+    with torch.no_grad():
+        a = d(xx.contiguous(memory_format=torch.channels_last))
+        d.fused_epilogue = False
+        b = d(xx)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
