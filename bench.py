@@ -154,8 +154,9 @@ def main():
         f_el = shard.max_over_ranks(ctx, time.perf_counter() - t2, device=dev)
         fused = {"value": a.steps * a.batch * ctx.world_size / f_el, "unit": "sweeps/s",
                  "ms_per_step": f_el / a.steps * 1e3,
-                 "what": "same forward with PPFeatureNet (conv1x1+ReLU+BN(eval)+max) fused into the HIP "
-                         "voxelizer (pp_voxelize_pfn_dev); outputs equal the headline path's within 1e-4"}
+                 "what": "same forward with PPFeatureNet (conv1x1+ReLU+BN(eval)+max) and PPScatter fused into "
+                         "the HIP voxelizer (pp_voxelize_pfn_canvas_dev, channels-last canvas); outputs equal "
+                         "the headline path's within 1e-4"}
 
     if ctx.rank == 0:
         total_sweeps = a.steps * a.batch * ctx.world_size
