@@ -124,9 +124,16 @@ class PPFeatureNet(nn.Module):
         #: inference only: evaluate the same function with two passes over the
         #: [B,C,P,N] intermediate instead of eight (see forward_eval)
         self.fast_eval = True
+        #: ... and on the GPU (9 -> 64 channels, f32) as ONE HIP kernel that reads the dense
+        #: tensor once (csrc/pp_pfn.hip); no [B,C,P,N] intermediate at all
+        self.hip_eval = True
+        self._params = _LayoutCache()
 
     def forward(self, x):                  # [B,D,P,N]
         if not self.training and self.fast_eval:
+            if (self.hip_eval and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                    and x.shape[1] == 9 and self.conv1.out_channels == 64 and not torch.is_grad_enabled()):
+                return self.forward_hip(x)
             return self.forward_eval(x)
         x = self.conv1(x)
         x = F.relu(x)
@@ -148,6 +155,25 @@ class PPFeatureNet(nn.Module):
         shift = self.bn1.bias.reshape(1, C, 1) - self.bn1.running_mean.reshape(1, C, 1) * scale
         r = torch.where(scale >= 0, F.relu(mx + b), F.relu(mn + b))
         return r * scale + shift
+
+    def forward_hip(self, x):
+        """pp_pfn_dense_dev: the same function as ``forward_eval`` in one pass over ``x``."""
+        x = x if x.is_contiguous() else x.contiguous()
+        B, D, P, N = x.shape
+        dev = x.device
+        ctx = _Epilogue._ctx.get(dev.index)
+        if ctx is None:
+            ctx = _Epilogue._ctx[dev.index] = _lib.Context(dev.index)
+        tab = self._params.get((self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
+                                self.bn1.running_mean, self.bn1.running_var),
+                               lambda: self.fused_params().to(dev))
+        out = torch.empty((B, 64, P), dtype=torch.float32, device=dev)
+        rc = _lib.lib().pp_pfn_dense_dev(
+            ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+            ctypes.c_void_p(x.data_ptr()), B, P, N, ctypes.c_void_p(tab.data_ptr()), 64,
+            ctypes.c_void_p(out.data_ptr()))
+        _lib.check(rc, "pp_pfn_dense_dev")
+        return out
 
     @torch.no_grad()
     def fused_params(self):

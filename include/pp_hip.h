@@ -102,6 +102,18 @@ int pp_voxelize_pfn_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                         int32_t *num_cells_dev);
 
 /*
+ * PPFeatureNet.forward in eval mode (model/model.py:31-40) on the dense tensor the plain
+ * voxelizer wrote -- for callers that keep the reference's [9,P,N] hand-over: the input is
+ * read once and the [64,P,N] intermediate never exists.  Same arithmetic as
+ * pp_voxelize_pfn_dev (bit-identical features).
+ *   pillars_dev  [batch][9][P][N] f32      pfn_params_dev [64][12] f32 (as above)
+ *   features_dev [batch][64][P] f32
+ */
+int pp_pfn_dense_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int batch,
+                     int max_pillars, int max_points_per_pillar, const float *pfn_params_dev,
+                     int channels, float *features_dev);
+
+/*
  * The same, with PPScatter.forward fused in as well (model/model.py:53-62): the feature
  * vector of every flagged pillar goes straight to its pixel of the BEV canvas,
  * canvas[b, :, row, col] = features[b, :, p]; the [batch][64][P] tensor is never built.

@@ -41,11 +41,16 @@ def _compare(gpu, cfg_args, pts_list, n_points=None, order=0):
     fn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in fn.state_dict().items()})
     fn64.eval()
     with torch.no_grad():
+        fn.hip_eval = False
         ref = fn(dense)                                    # [B,64,P], PyTorch-ROCm f32
+        fn.hip_eval = True
+        hip = fn(dense)                                    # pp_pfn_dense_dev on the dense tensor
         ref64 = fn64(dense.double())
     feats, idx2, cnt = vox.pfn(pts, fn.fused_params(), n_points=n_points, return_counts=True)
     torch.cuda.synchronize()
     assert torch.equal(idx, idx2)
+    # the dense-tensor kernel and the fused voxelizer run the same arithmetic: identical bits
+    assert torch.equal(hip, feats)
     assert (fn.bn1.weight < 0).any() and (fn.bn1.weight > 0).any()
     err_torch = (ref.double() - ref64).abs().max().item()
     err_fused = (feats.double() - ref64).abs().max().item()
