@@ -9,9 +9,14 @@
 // rows), the intermediate never exists, the output is one 16-byte store per lane.
 // HBM-bound: 4*9*P*N bytes in, 4*64*P bytes out per sweep.
 //
-// The arithmetic (one fmaf chain from the bias in feature order, ReLU, running max AND min,
-// then s >= 0 ? s*max + t : s*min + t) is exactly the fused voxelizer's (pp_voxelize.hip,
-// kModePfn), so the two paths give bit-identical features.
+// The arithmetic is the fused voxelizer's (pp_voxelize.hip, kModePfn: one fmaf chain z from
+// the bias in feature order, r = ReLU(z), then s >= 0 ? s*max(r) + t : s*min(r) + t), so the
+// two paths give bit-identical features.  Two exact rearrangements make it cheaper here:
+// ReLU is monotone, so max_n ReLU(z_n) = ReLU(max_n z_n) and min likewise; and a lane whose
+// BatchNorm scale is negative negates its weights and bias (fma(-w, x, -a) = -fma(w, x, a)
+// exactly), so min_n z_n = -max_n(-z_n): ONE running max per lane, no per-point ReLU.  The
+// chain runs on point pairs with packed f32 FMAs (v_pk_fma_f32, twice the scalar FMA rate):
+// the kernel is VALU-bound (9 MACs x 64 channels per 4-byte input), not HBM-bound.
 
 #include "pp_common.h"
 
@@ -29,9 +34,22 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct PfnLane {
-  float w[9], bias, scale, shift;
+  float w[9], bias, scale, shift;  // w, bias already negated when scale < 0
 };
+
+// z for two points at once; x[d] = {point a, point b} of feature row d
+__device__ __forceinline__ v2f pfn_pair(const PfnLane &A, const v2f x[9]) {
+  v2f z = {A.bias, A.bias};
+#pragma unroll
+  for (int d = 0; d < 9; ++d) {
+    const v2f w = {A.w[d], A.w[d]};
+    z = __builtin_elementwise_fma(w, x[d], z);
+  }
+  return z;
+}
 
 __device__ __forceinline__ float pfn_point(const PfnLane &A, float x0, float x1, float x2, float x3,
                                            float x4, float x5, float x6, float x7, float x8) {
@@ -45,7 +63,13 @@ __device__ __forceinline__ float pfn_point(const PfnLane &A, float x0, float x1,
   r = fmaf(A.w[6], x6, r);
   r = fmaf(A.w[7], x7, r);
   r = fmaf(A.w[8], x8, r);
-  return fmaxf(r, 0.0f);
+  return r;
+}
+
+// the lane's result from its running maximum of (sign-folded) z
+__device__ __forceinline__ float pfn_result(const PfnLane &A, float m) {
+  const float r = fmaxf(A.scale >= 0.0f ? m : -m, 0.0f);
+  return fmaf(r, A.scale, A.shift);
 }
 
 // kVec: N % 4 == 0 and N <= kPfnChunk -- one float4 per lane and feature row covers a
@@ -61,20 +85,36 @@ __global__ __launch_bounds__(kPfnWaves * 64) void k_pfn_dense(const float *__res
   if (p0 >= P) return;  // whole wave; no workgroup barrier below
   const int kw = min(kPfnKW, P - p0);
   float(*sx)[kPfnChunk] = s_x[wave];
-  PfnLane A;
-  {
-    const float *q = prm + lane * 12;
+  const int64_t plane = (int64_t)P * N;
+  const float *xb = x + (int64_t)b * 9 * plane;
+  float yv[kPfnKW];
+
+  auto load_lane = [&](int c) {
+    PfnLane A;
+    const float *q = prm + c * 12;
 #pragma unroll
     for (int d = 0; d < 9; ++d) A.w[d] = q[d];
     A.bias = q[9];
     A.scale = q[10];
     A.shift = q[11];
-  }
-  const int64_t plane = (int64_t)P * N;
-  const float *xb = x + (int64_t)b * 9 * plane;
-  float yv[kPfnKW];
+    if (A.scale < 0.0f) {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) A.w[d] = -A.w[d];
+      A.bias = -A.bias;
+    }
+    return A;
+  };
 
   if (kVec) {
+    // A broadcast LDS read costs the CU's one LDS pipe as much as any other, and with one
+    // channel per lane every float read feeds a single FMA: the LDS pipe, shared by the four
+    // SIMDs, was the bound.  So a lane carries FOUR channels (cg, cg+16, cg+32, cg+48) for a
+    // QUARTER of the points (float4 groups j = g, g+4, ...): a quarter of the LDS reads for
+    // the same FMAs, and the four partial maxima meet in two cross-lane steps per pillar.
+    const int cg = lane & 15, g = lane >> 4;
+    PfnLane A[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A[i] = load_lane(cg + 16 * i);
     const int nq = N >> 2;  // float4 per row, <= 64
     float4 r[9];
     auto fetch = [&](int k) {
@@ -94,31 +134,52 @@ __global__ __launch_bounds__(kPfnWaves * 64) void k_pfn_dense(const float *__res
         }
         wave_sync();
         if (k + 1 < kw) fetch(k + 1);
-        float mx = -INFINITY, mn = INFINITY;
-        for (int j = 0; j < nq; ++j) {
-          float4 v[9];
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int j = g; j < nq; j += 4) {
+          v2f lo[9], hi[9];
 #pragma unroll
-          for (int d = 0; d < 9; ++d) v[d] = reinterpret_cast<const float4 *>(sx[d])[j];
-          const float r0 = pfn_point(A, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x);
-          const float r1 = pfn_point(A, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y);
-          const float r2 = pfn_point(A, v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z, v[8].z);
-          const float r3 = pfn_point(A, v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w, v[8].w);
-          mx = fmaxf(fmaxf(mx, r0), fmaxf(r1, fmaxf(r2, r3)));
-          mn = fminf(fminf(mn, r0), fminf(r1, fminf(r2, r3)));
+          for (int d = 0; d < 9; ++d) {
+            const float4 v = reinterpret_cast<const float4 *>(sx[d])[j];
+            lo[d] = v2f{v.x, v.y};
+            hi[d] = v2f{v.z, v.w};
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const v2f za = pfn_pair(A[i], lo), zb = pfn_pair(A[i], hi);
+            m[i] = fmaxf(fmaxf(m[i], fmaxf(za.x, za.y)), fmaxf(zb.x, zb.y));
+          }
         }
-        yv[k] = fmaf(A.scale >= 0.0f ? mx : mn, A.scale, A.shift);
+        float y = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float mi = fmaxf(m[i], __shfl_xor(m[i], 16, 64));
+          mi = fmaxf(mi, __shfl_xor(mi, 32, 64));
+          const float yi = pfn_result(A[i], mi);
+          y = (i == g) ? yi : y;  // group g stores channel cg + 16*g
+        }
+        yv[k] = y;
         wave_sync();  // every lane is done reading before the next overwrite
       } else {
         yv[k] = 0.0f;
       }
     }
+    float *o = out + ((int64_t)b * kPfnC + cg + 16 * g) * P + p0;
+    if (kw == kPfnKW && (P & 3) == 0) {
+      *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPfnKW; ++k)
+        if (k < kw) o[k] = yv[k];
+    }
+    return;
   } else {
+    const PfnLane A = load_lane(lane);
 #pragma unroll 1
     for (int k = 0; k < kPfnKW; ++k) {
       yv[k] = 0.0f;
       if (k >= kw) continue;
       const float *row = xb + (int64_t)(p0 + k) * N;
-      float mx = -INFINITY, mn = INFINITY;
+      float m = -INFINITY;
       for (int n0 = 0; n0 < N; n0 += kPfnChunk) {
         const int cn = min(kPfnChunk, N - n0);
         for (int i = lane; i < cn; i += 64) {
@@ -127,14 +188,12 @@ __global__ __launch_bounds__(kPfnWaves * 64) void k_pfn_dense(const float *__res
         }
         wave_sync();
         for (int j = 0; j < cn; ++j) {
-          const float rr = pfn_point(A, sx[0][j], sx[1][j], sx[2][j], sx[3][j], sx[4][j], sx[5][j],
-                                     sx[6][j], sx[7][j], sx[8][j]);
-          mx = fmaxf(mx, rr);
-          mn = fminf(mn, rr);
+          m = fmaxf(m, pfn_point(A, sx[0][j], sx[1][j], sx[2][j], sx[3][j], sx[4][j], sx[5][j],
+                                 sx[6][j], sx[7][j], sx[8][j]));
         }
         wave_sync();
       }
-      yv[k] = fmaf(A.scale >= 0.0f ? mx : mn, A.scale, A.shift);
+      yv[k] = pfn_result(A, m);
     }
   }
   float *o = out + ((int64_t)b * kPfnC + lane) * P + p0;
