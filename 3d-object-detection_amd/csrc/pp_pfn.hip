@@ -4,19 +4,21 @@
 // x[b,d,p,n])) over all N slots (zero-padded ones included).  PyTorch-ROCm runs it as a 1x1
 // convolution that writes a [B,64,P,N] intermediate (307 MB per sweep at P=12000, N=100),
 // ReLU, BatchNorm and a max reduction that reads it back: > 2 GB of HBM traffic for 173 MB
-// of input.  Here one wave owns four consecutive pillars, stages their nine feature rows
-// in LDS and every lane carries one output channel: the input is read once (coalesced
-// rows), the intermediate never exists, the output is one 16-byte store per lane.
-// HBM-bound: 4*9*P*N bytes in, 4*64*P bytes out per sweep.
+// of input.  Here one wave owns four consecutive pillars: the input is read once, the
+// intermediate never exists, the output is one 16-byte store per lane
+// (4*9*P*N bytes in, 4*64*P bytes out per sweep).
 //
 // The arithmetic is the fused voxelizer's (pp_voxelize.hip, kModePfn: one fmaf chain z from
 // the bias in feature order, r = ReLU(z), then s >= 0 ? s*max(r) + t : s*min(r) + t), so the
 // two paths give bit-identical features.  Two exact rearrangements make it cheaper here:
 // ReLU is monotone, so max_n ReLU(z_n) = ReLU(max_n z_n) and min likewise; and a lane whose
 // BatchNorm scale is negative negates its weights and bias (fma(-w, x, -a) = -fma(w, x, a)
-// exactly), so min_n z_n = -max_n(-z_n): ONE running max per lane, no per-point ReLU.  The
-// chain runs on point pairs with packed f32 FMAs (v_pk_fma_f32, twice the scalar FMA rate):
-// the kernel is VALU-bound (9 MACs x 64 channels per 4-byte input), not HBM-bound.
+// exactly), so min_n z_n = -max_n(-z_n): ONE running max per lane, no per-point ReLU.
+// 9 MACs x 64 channels per 4-byte input make this compute-bound, not HBM-bound (reading the
+// 173 MB of a 4-sweep step takes 42 us on this chip): as a VALU kernel (v_fma_f32 or
+// v_pk_fma_f32 alike, one or four channels per lane) it ran at ~55 TF/s = 98 us per step; the
+// f32 MFMA form below is the same fmaf chain bit for bit and measures 95 us -- its MFMAs
+// (130 per wave, 45 us in total) and the rest do not overlap yet (profiles/r01/NOTES.md).
 
 #include "pp_common.h"
 
@@ -25,7 +27,8 @@ namespace pp {
 constexpr int kPfnC = 64;        // output channels = lanes
 constexpr int kPfnWaves = 4;     // waves per workgroup
 constexpr int kPfnKW = 4;        // pillars per wave
-constexpr int kPfnChunk = 256;   // points staged per pass
+constexpr int kPfnChunk = 256;   // points staged per pass (generic kernel)
+constexpr int kPfnDepth = 8;     // operand tiles in flight per wave (MFMA kernel)
 
 __device__ __forceinline__ void wave_sync() {
   // LDS operations of one wave execute in program order; this only stops the compiler
@@ -34,22 +37,9 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 struct PfnLane {
   float w[9], bias, scale, shift;  // w, bias already negated when scale < 0
 };
-
-// z for two points at once; x[d] = {point a, point b} of feature row d
-__device__ __forceinline__ v2f pfn_pair(const PfnLane &A, const v2f x[9]) {
-  v2f z = {A.bias, A.bias};
-#pragma unroll
-  for (int d = 0; d < 9; ++d) {
-    const v2f w = {A.w[d], A.w[d]};
-    z = __builtin_elementwise_fma(w, x[d], z);
-  }
-  return z;
-}
 
 __device__ __forceinline__ float pfn_point(const PfnLane &A, float x0, float x1, float x2, float x3,
                                            float x4, float x5, float x6, float x7, float x8) {
@@ -72,13 +62,148 @@ __device__ __forceinline__ float pfn_result(const PfnLane &A, float m) {
   return fmaf(r, A.scale, A.shift);
 }
 
-// kVec: N % 4 == 0 and N <= kPfnChunk -- one float4 per lane and feature row covers a
-// pillar, and the next pillar's rows are in flight while this one is reduced.
-template <bool kVec>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// N % 4 == 0: the feature net as a GEMM on the f32 matrix cores.  The wave's kw*N points are
+// the rows (32 per tile: consecutive pillars are contiguous in every feature row, so a tile
+// may straddle pillars), the 64 channels two column tiles, K = the nine features + one zero
+// term in front: v_mfma_f32_32x32x2_f32 computes D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))
+// -- bit for bit the fmaf chain above with C = bias.  Operands come straight from global
+// memory: lane l holds A[row l&31][k = l>>5], i.e. one float of one feature row per k-step,
+// 32 consecutive floats per half-wave; no LDS.  amdgpu_waves_per_eu(2) caps the wave at 256
+// registers so that the compiler takes the MFMA form with accumulators in arch VGPRs (the
+// maxima read them directly; the AGPR form cost 32 v_accvgpr_read per tile).  The accumulator has the channel on the lane
+// and 16 rows (four groups of four consecutive points) in registers: N % 4 == 0 puts every
+// group inside one pillar, so the running maxima are in-lane, and the two half-waves meet
+// once at the end.  Rows past the wave's last point repeat that point (no effect on a max).
+__global__ __launch_bounds__(kPfnWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void k_pfn_dense_mfma(const float *__restrict__ x,
+                                                                   const float *__restrict__ prm,
+                                                                   float *__restrict__ out, int P,
+                                                                   int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int p0 = (blockIdx.x * kPfnWaves + wave) * kPfnKW;
+  if (p0 >= P) return;
+  const int kw = min(kPfnKW, P - p0);
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t plane = (int64_t)P * N;
+  const float *base = x + (int64_t)b * 9 * plane + (int64_t)p0 * N;
+  const int npts = kw * N;
+  const int tiles = (npts + 31) >> 5;
+
+  // B operand (weights, sign-folded) and C (bias) for the two channel tiles
+  float bw[2][5], cb[2], sc[2], sh[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float *q = prm + (r + 32 * nt) * 12;
+    sc[nt] = q[10];
+    sh[nt] = q[11];
+    const float sign = sc[nt] < 0.0f ? -1.0f : 1.0f;
+    cb[nt] = sign * q[9];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int f = 2 * st + h - 1;  // k-steps: [zero, d0] [d1, d2] [d3, d4] [d5, d6] [d7, d8]
+      bw[nt][st] = (f >= 0) ? sign * q[f] : 0.0f;
+    }
+  }
+  auto load_tile = [&](int t, float a[5]) {
+    const int q = min(t * 32 + r, npts - 1);
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int f = 2 * st + h - 1;
+      a[st] = (f >= 0) ? base[f * plane + q] : 0.0f;
+    }
+  };
+  float m[2][kPfnKW];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int k = 0; k < kPfnKW; ++k) m[nt][k] = -INFINITY;
+
+  // kPfnDepth tiles of operands in flight per wave: a tile is 10 MFMAs (~0.3 us), far less
+  // than an HBM round trip, so a one-tile look-ahead left the kernel latency-bound
+  float a[kPfnDepth][5];
+#pragma unroll
+  for (int i = 0; i < kPfnDepth; ++i)
+    if (i < tiles) load_tile(i, a[i]);
+  for (int t0 = 0; t0 < tiles; t0 += kPfnDepth) {
+#pragma unroll
+    for (int i = 0; i < kPfnDepth; ++i) {
+      const int t = t0 + i;
+      if (t < tiles) {  // wave-uniform
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[nt][v] = cb[nt];
+#pragma unroll
+          for (int st = 0; st < 5; ++st)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][st], bw[nt][st], acc[nt], 0, 0, 0);
+        }
+        if (t + kPfnDepth < tiles) load_tile(t + kPfnDepth, a[i]);
+        // which pillar(s) the tile's 32 rows belong to (wave-uniform; rows past the last point
+        // repeat it, so they count for the last pillar)
+        auto pillar_of = [&](int row) {
+          return min((row >= N ? 1 : 0) + (row >= 2 * N ? 1 : 0) + (row >= 3 * N ? 1 : 0), kw - 1);
+        };
+        const int k_lo = pillar_of(t * 32), k_hi = pillar_of(t * 32 + 31);
+        if (k_lo == k_hi) {
+          // the common case (10 of 13 tiles at N = 100): all 16 registers feed one maximum
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            float g = acc[nt][0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) g = fmaxf(g, acc[nt][v]);
+            if (k_lo == 0) m[nt][0] = fmaxf(m[nt][0], g);
+            else if (k_lo == 1) m[nt][1] = fmaxf(m[nt][1], g);
+            else if (k_lo == 2) m[nt][2] = fmaxf(m[nt][2], g);
+            else m[nt][3] = fmaxf(m[nt][3], g);
+          }
+        } else {
+#pragma unroll
+          for (int vg = 0; vg < 4; ++vg) {
+            // rows vg*8 + h*4 .. +3 of the tile: inside one pillar because N % 4 == 0
+            const int pid = pillar_of(t * 32 + vg * 8 + h * 4);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const float g = fmaxf(fmaxf(acc[nt][4 * vg], acc[nt][4 * vg + 1]),
+                                    fmaxf(acc[nt][4 * vg + 2], acc[nt][4 * vg + 3]));
+#pragma unroll
+              for (int k = 0; k < kPfnKW; ++k) m[nt][k] = (pid == k) ? fmaxf(m[nt][k], g) : m[nt][k];
+            }
+          }
+        }
+      }
+    }
+  }
+  // half h stores channel tile h
+  float yv[kPfnKW];
+#pragma unroll
+  for (int k = 0; k < kPfnKW; ++k) {
+    float y[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float mm = fmaxf(m[nt][k], __shfl_xor(m[nt][k], 32, 64));
+      const float rr = fmaxf(sc[nt] >= 0.0f ? mm : -mm, 0.0f);
+      y[nt] = fmaf(rr, sc[nt], sh[nt]);
+    }
+    yv[k] = h ? y[1] : y[0];
+  }
+  float *o = out + ((int64_t)b * kPfnC + r + 32 * h) * P + p0;
+  if (kw == kPfnKW && (P & 3) == 0) {
+    *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPfnKW; ++k)
+      if (k < kw) o[k] = yv[k];
+  }
+}
+
+// Any N: lanes = channels, feature rows staged in LDS, scalar fmaf chain.
 __global__ __launch_bounds__(kPfnWaves * 64) void k_pfn_dense(const float *__restrict__ x,
                                                               const float *__restrict__ prm,
                                                               float *__restrict__ out, int P, int N) {
-  __shared__ __attribute__((aligned(16))) float s_x[kPfnWaves][9][kPfnChunk];
+  __shared__ float s_x[kPfnWaves][9][kPfnChunk];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int p0 = (blockIdx.x * kPfnWaves + wave) * kPfnKW;
@@ -87,11 +212,9 @@ __global__ __launch_bounds__(kPfnWaves * 64) void k_pfn_dense(const float *__res
   float(*sx)[kPfnChunk] = s_x[wave];
   const int64_t plane = (int64_t)P * N;
   const float *xb = x + (int64_t)b * 9 * plane;
-  float yv[kPfnKW];
-
-  auto load_lane = [&](int c) {
-    PfnLane A;
-    const float *q = prm + c * 12;
+  PfnLane A;
+  {
+    const float *q = prm + lane * 12;
 #pragma unroll
     for (int d = 0; d < 9; ++d) A.w[d] = q[d];
     A.bias = q[9];
@@ -102,107 +225,24 @@ __global__ __launch_bounds__(kPfnWaves * 64) void k_pfn_dense(const float *__res
       for (int d = 0; d < 9; ++d) A.w[d] = -A.w[d];
       A.bias = -A.bias;
     }
-    return A;
-  };
-
-  if (kVec) {
-    // A broadcast LDS read costs the CU's one LDS pipe as much as any other, and with one
-    // channel per lane every float read feeds a single FMA: the LDS pipe, shared by the four
-    // SIMDs, was the bound.  So a lane carries FOUR channels (cg, cg+16, cg+32, cg+48) for a
-    // QUARTER of the points (float4 groups j = g, g+4, ...): a quarter of the LDS reads for
-    // the same FMAs, and the four partial maxima meet in two cross-lane steps per pillar.
-    const int cg = lane & 15, g = lane >> 4;
-    PfnLane A[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) A[i] = load_lane(cg + 16 * i);
-    const int nq = N >> 2;  // float4 per row, <= 64
-    float4 r[9];
-    auto fetch = [&](int k) {
-      const float *row = xb + (int64_t)(p0 + k) * N;
-#pragma unroll
-      for (int d = 0; d < 9; ++d)
-        r[d] = (lane < nq) ? reinterpret_cast<const float4 *>(row + d * plane)[lane]
-                           : make_float4(0, 0, 0, 0);
-    };
-    fetch(0);
-#pragma unroll
-    for (int k = 0; k < kPfnKW; ++k) {
-      if (k < kw) {
-        if (lane < nq) {
-#pragma unroll
-          for (int d = 0; d < 9; ++d) reinterpret_cast<float4 *>(sx[d])[lane] = r[d];
-        }
-        wave_sync();
-        if (k + 1 < kw) fetch(k + 1);
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int j = g; j < nq; j += 4) {
-          v2f lo[9], hi[9];
-#pragma unroll
-          for (int d = 0; d < 9; ++d) {
-            const float4 v = reinterpret_cast<const float4 *>(sx[d])[j];
-            lo[d] = v2f{v.x, v.y};
-            hi[d] = v2f{v.z, v.w};
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const v2f za = pfn_pair(A[i], lo), zb = pfn_pair(A[i], hi);
-            m[i] = fmaxf(fmaxf(m[i], fmaxf(za.x, za.y)), fmaxf(zb.x, zb.y));
-          }
-        }
-        float y = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float mi = fmaxf(m[i], __shfl_xor(m[i], 16, 64));
-          mi = fmaxf(mi, __shfl_xor(mi, 32, 64));
-          const float yi = pfn_result(A[i], mi);
-          y = (i == g) ? yi : y;  // group g stores channel cg + 16*g
-        }
-        yv[k] = y;
-        wave_sync();  // every lane is done reading before the next overwrite
-      } else {
-        yv[k] = 0.0f;
-      }
-    }
-    float *o = out + ((int64_t)b * kPfnC + cg + 16 * g) * P + p0;
-    if (kw == kPfnKW && (P & 3) == 0) {
-      *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < kPfnKW; ++k)
-        if (k < kw) o[k] = yv[k];
-    }
-    return;
-  } else {
-    const PfnLane A = load_lane(lane);
-#pragma unroll 1
-    for (int k = 0; k < kPfnKW; ++k) {
-      yv[k] = 0.0f;
-      if (k >= kw) continue;
-      const float *row = xb + (int64_t)(p0 + k) * N;
-      float m = -INFINITY;
-      for (int n0 = 0; n0 < N; n0 += kPfnChunk) {
-        const int cn = min(kPfnChunk, N - n0);
-        for (int i = lane; i < cn; i += 64) {
-#pragma unroll
-          for (int d = 0; d < 9; ++d) sx[d][i] = row[d * plane + n0 + i];
-        }
-        wave_sync();
-        for (int j = 0; j < cn; ++j) {
-          m = fmaxf(m, pfn_point(A, sx[0][j], sx[1][j], sx[2][j], sx[3][j], sx[4][j], sx[5][j],
-                                 sx[6][j], sx[7][j], sx[8][j]));
-        }
-        wave_sync();
-      }
-      yv[k] = pfn_result(A, m);
-    }
   }
-  float *o = out + ((int64_t)b * kPfnC + lane) * P + p0;
-  if (kw == kPfnKW && (P & 3) == 0) {
-    *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
-  } else {
+#pragma unroll 1
+  for (int k = 0; k < kw; ++k) {
+    const float *row = xb + (int64_t)(p0 + k) * N;
+    float m = -INFINITY;
+    for (int n0 = 0; n0 < N; n0 += kPfnChunk) {
+      const int cn = min(kPfnChunk, N - n0);
+      for (int i = lane; i < cn; i += 64) {
 #pragma unroll
-    for (int k = 0; k < kPfnKW; ++k)
-      if (k < kw) o[k] = yv[k];
+        for (int d = 0; d < 9; ++d) sx[d][i] = row[d * plane + n0 + i];
+      }
+      wave_sync();
+      for (int j = 0; j < cn; ++j)
+        m = fmaxf(m, pfn_point(A, sx[0][j], sx[1][j], sx[2][j], sx[3][j], sx[4][j], sx[5][j],
+                               sx[6][j], sx[7][j], sx[8][j]));
+      wave_sync();
+    }
+    out[((int64_t)b * kPfnC + lane) * P + p0 + k] = pfn_result(A, m);
   }
 }
 
@@ -235,12 +275,12 @@ extern "C" int pp_pfn_dense_dev(pp_ctx_t *ctx, void *stream_, const float *pilla
   if (prev != ctx->device) (void)hipSetDevice(ctx->device);
   const dim3 grid((unsigned)((P + kPfnWaves * kPfnKW - 1) / (kPfnWaves * kPfnKW)), (unsigned)batch);
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if ((N & 3) == 0 && N <= kPfnChunk)
-    hipLaunchKernelGGL(k_pfn_dense<true>, grid, dim3(kPfnWaves * 64), 0, st, pillars_dev,
+  if ((N & 3) == 0)
+    hipLaunchKernelGGL(k_pfn_dense_mfma, grid, dim3(kPfnWaves * 64), 0, st, pillars_dev,
                        pfn_params_dev, features_dev, P, N);
   else
-    hipLaunchKernelGGL(k_pfn_dense<false>, grid, dim3(kPfnWaves * 64), 0, st, pillars_dev,
-                       pfn_params_dev, features_dev, P, N);
+    hipLaunchKernelGGL(k_pfn_dense, grid, dim3(kPfnWaves * 64), 0, st, pillars_dev, pfn_params_dev,
+                       features_dev, P, N);
   hipError_t e = hipGetLastError();
   if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
   if (e != hipSuccess) {
