@@ -94,6 +94,18 @@ def make_anchors(cfg: AnchorConfig):
             "xy": np.ascontiguousarray(xy)}
 
 
+def anchor_type_table(cfg: AnchorConfig):
+    """[per_cell, 13] f64 table for the on-the-fly anchor grid (pp_assign_targets_grid_dev):
+    per anchor type the rotated bottom-corner offsets from the centre (x0,y0,..,x3,y3),
+    then w, l, h, yaw (radians), z.  ``offset + centre`` is the last operation of
+    ``bottom_corners_xy``, so the device's corners equal ``make_anchors``' bit for bit."""
+    dims = np.asarray(cfg.dims, np.float64)
+    yaw = np.deg2rad(np.asarray(cfg.yaws_deg, np.float64))
+    off = bottom_corners_xy(np.zeros((dims.shape[0], 3)), dims, yaw).reshape(-1, 8)
+    return np.ascontiguousarray(np.concatenate(
+        [off, dims, yaw[:, None], np.asarray(cfg.zs, np.float64)[:, None]], 1))
+
+
 def boxes_to_image_space(centers, wlh, yaw, canvas_height):
     """box_utils.py:19-32: ground-truth centres/corners with y flipped into rows."""
     centers = np.array(centers, np.float64, copy=True)

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(kIouThreads) void k_make_ious(
 struct TargetArgs {
   int64_t A;
   int G;
-  const double *a_corners, *a_centers, *a_wlh, *a_yaw;
+  const double *a_corners, *a_centers, *a_wlh, *a_yaw;  // anchor arrays, or all NULL with ...
+  // ... the anchor grid of make_anchor_boxes (box_utils.py:111-159) evaluated on the fly:
+  // anchor i = (y*fm_w + x)*per_cell + d; centre ((x+.5)/fm_scale, (y+.5)/fm_scale, z_d)
+  int grid, fm_w, per_cell;
+  double fm_scale;
+  const double *types;  // [per_cell][kTypeCols]: corner offsets x0,y0..x3,y3, w, l, h, yaw, z
   const double *g_corners, *g_centers_img, *g_centers, *g_wlh, *g_yaw;
   const int *g_class;
   double pos_thresh, canvas_height;
@@ -166,16 +171,64 @@ struct TargetArgs {
   float *reg_targets;  // [A][9]
 };
 
+constexpr int kTypeCols = 13;
+
+struct AnchorId {
+  int d;          // anchor type within the cell
+  double cx, cy;  // centre
+};
+
+__device__ __forceinline__ AnchorId anchor_id(const TargetArgs &t, int64_t i) {
+  AnchorId a;
+  if (t.grid) {
+    const int64_t cell = i / t.per_cell;
+    a.d = (int)(i - cell * t.per_cell);
+    const int64_t y = cell / t.fm_w, x = cell - y * t.fm_w;
+    a.cx = ((double)x + 0.5) / t.fm_scale;  // box_utils.py:137-138, same f64 operations
+    a.cy = ((double)y + 0.5) / t.fm_scale;
+  } else {
+    a.d = 0;
+    a.cx = t.a_centers[i * 3];
+    a.cy = t.a_centers[i * 3 + 1];
+  }
+  return a;
+}
+
+// corners = per-type rotated offsets + centre: the last addition of Box.bottom_corners
+// (boxes.bottom_corners_xy), so the values equal the uploaded arrays' bit for bit
+__device__ __forceinline__ void anchor_corners(const TargetArgs &t, int64_t i, double a[8]) {
+  if (t.grid) {
+    const AnchorId id = anchor_id(t, i);
+    const double *ty = t.types + id.d * kTypeCols;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[2 * k] = ty[2 * k] + id.cx;
+      a[2 * k + 1] = ty[2 * k + 1] + id.cy;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = t.a_corners[i * 8 + k];
+  }
+}
+
 // utils/box_utils.py:70-109
 __device__ void make_target_dev(const TargetArgs &t, int64_t i, int j, float out[9]) {
-  const double ax = t.a_centers[i * 3], ay = t.a_centers[i * 3 + 1], az = t.a_centers[i * 3 + 2];
+  double ax, ay, az, aw, al, ah, at;
+  if (t.grid) {
+    const AnchorId id = anchor_id(t, i);
+    const double *ty = t.types + id.d * kTypeCols;
+    ax = id.cx, ay = id.cy, az = ty[12];
+    aw = ty[8], al = ty[9], ah = ty[10], at = ty[11];
+  } else {
+    ax = t.a_centers[i * 3], ay = t.a_centers[i * 3 + 1], az = t.a_centers[i * 3 + 2];
+    aw = t.a_wlh[i * 3], al = t.a_wlh[i * 3 + 1], ah = t.a_wlh[i * 3 + 2];
+    at = t.a_yaw[i];
+  }
   const double gx = t.g_centers[j * 3];
   double gy = t.g_centers[j * 3 + 1];
   const double gz = t.g_centers[j * 3 + 2];
-  const double aw = t.a_wlh[i * 3], al = t.a_wlh[i * 3 + 1], ah = t.a_wlh[i * 3 + 2];
   const double gw = t.g_wlh[j * 3], gl = t.g_wlh[j * 3 + 1], gh = t.g_wlh[j * 3 + 2];
   const double ad = sqrt(aw * aw + al * al);
-  const double at = t.a_yaw[i];
   double gt = t.g_yaw[j];
   const double pi = 3.141592653589793;  // np.pi
   gy = (t.canvas_height - 1) - gy;       // box_utils.py:83
@@ -207,11 +260,9 @@ __device__ void make_target_dev(const TargetArgs &t, int64_t i, int j, float out
 __device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad,
                                            const PolyLds &pl) {
   double a[8], g[8];
+  anchor_corners(t, i, a);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    a[k] = t.a_corners[i * 8 + k];
-    g[k] = t.g_corners[(int64_t)j * 8 + k];
-  }
+  for (int k = 0; k < 8; ++k) g[k] = t.g_corners[(int64_t)j * 8 + k];
   return iou_pair_dev(a, g, bad, pl);
 }
 
@@ -248,8 +299,9 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
   const bool live = i < t.A;
   double acx = 0, acy = 0;
   if (live) {
-    acx = t.a_centers[i * 3];
-    acy = t.a_centers[i * 3 + 1];
+    const AnchorId id = anchor_id(t, i);
+    acx = id.cx;
+    acy = id.cy;
   }
   double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
   int best_j = 0;
@@ -393,7 +445,8 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_cols(TargetArgs t) {
   }
   if (i >= t.A) return;
   const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
-  const double acx = t.a_centers[i * 3], acy = t.a_centers[i * 3 + 1];
+  const AnchorId aid = anchor_id(t, i);
+  const double acx = aid.cx, acy = aid.cy;
   bool bad = false;
   for (int j = 0; j < t.G; ++j) {
     const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
@@ -639,27 +692,31 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
   return pp_iou_check(ctx, stream);
 }
 
-extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
-                                     const double *a_corners, const double *a_centers,
-                                     const double *a_wlh, const double *a_yaw, int64_t G,
-                                     const double *g_corners, const double *g_centers_img,
-                                     const double *g_centers, const double *g_wlh,
-                                     const double *g_yaw, const int32_t *g_class,
-                                     const pp_target_params_t *prm, float *cls_targets,
-                                     float *reg_targets) {
+struct AnchorSource {
+  const double *corners = nullptr, *centers = nullptr, *wlh = nullptr, *yaw = nullptr;
+  int grid = 0, fm_w = 0, per_cell = 0;
+  double fm_scale = 1.0;
+  const double *types = nullptr;
+};
+
+static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const AnchorSource &an,
+                               int64_t G, const double *g_corners, const double *g_centers_img,
+                               const double *g_centers, const double *g_wlh, const double *g_yaw,
+                               const int32_t *g_class, const pp_target_params_t *prm,
+                               float *cls_targets, float *reg_targets) {
   if (!ctx || !prm) {
-    set_error("pp_assign_targets_dev: NULL argument");
+    set_error("pp_assign_targets*_dev: NULL argument");
     return PP_ERR_VALUE;
   }
   if (A < 1 || A > INT_MAX / 2 || G < 0 || G > 65535 || prm->num_classes < 1 ||
       prm->num_classes > 1024) {
-    set_error("pp_assign_targets_dev: bad sizes (A=%lld G=%lld classes=%d)", (long long)A,
+    set_error("pp_assign_targets*_dev: bad sizes (A=%lld G=%lld classes=%d)", (long long)A,
               (long long)G, prm->num_classes);
     return PP_ERR_VALUE;
   }
-  if (!a_corners || !a_centers || !a_wlh || !a_yaw || !cls_targets || !reg_targets ||
+  if (!cls_targets || !reg_targets ||
       (G > 0 && (!g_corners || !g_centers_img || !g_centers || !g_wlh || !g_yaw || !g_class))) {
-    set_error("pp_assign_targets_dev: NULL array");
+    set_error("pp_assign_targets*_dev: NULL array");
     return PP_ERR_VALUE;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -676,10 +733,15 @@ extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
   TargetArgs t;
   t.A = A;
   t.G = (int)G;
-  t.a_corners = a_corners;
-  t.a_centers = a_centers;
-  t.a_wlh = a_wlh;
-  t.a_yaw = a_yaw;
+  t.a_corners = an.corners;
+  t.a_centers = an.centers;
+  t.a_wlh = an.wlh;
+  t.a_yaw = an.yaw;
+  t.grid = an.grid;
+  t.fm_w = an.fm_w;
+  t.per_cell = an.per_cell;
+  t.fm_scale = an.fm_scale;
+  t.types = an.types;
   t.g_corners = g_corners;
   t.g_centers_img = g_centers_img;
   t.g_centers = g_centers;
@@ -714,4 +776,50 @@ extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
   }
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
+}
+
+extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
+                                     const double *a_corners, const double *a_centers,
+                                     const double *a_wlh, const double *a_yaw, int64_t G,
+                                     const double *g_corners, const double *g_centers_img,
+                                     const double *g_centers, const double *g_wlh,
+                                     const double *g_yaw, const int32_t *g_class,
+                                     const pp_target_params_t *prm, float *cls_targets,
+                                     float *reg_targets) {
+  if (!a_corners || !a_centers || !a_wlh || !a_yaw) {
+    set_error("pp_assign_targets_dev: NULL anchor array");
+    return PP_ERR_VALUE;
+  }
+  AnchorSource an;
+  an.corners = a_corners;
+  an.centers = a_centers;
+  an.wlh = a_wlh;
+  an.yaw = a_yaw;
+  return assign_targets_impl(ctx, stream_, A, an, G, g_corners, g_centers_img, g_centers, g_wlh,
+                             g_yaw, g_class, prm, cls_targets, reg_targets);
+}
+
+extern "C" int pp_assign_targets_grid_dev(pp_ctx_t *ctx, void *stream_, int fm_height, int fm_width,
+                                          double fm_scale, int per_cell,
+                                          const double *anchor_types_dev, int64_t G,
+                                          const double *g_corners, const double *g_centers_img,
+                                          const double *g_centers, const double *g_wlh,
+                                          const double *g_yaw, const int32_t *g_class,
+                                          const pp_target_params_t *prm, float *cls_targets,
+                                          float *reg_targets) {
+  if (fm_height < 1 || fm_width < 1 || per_cell < 1 || per_cell > 1024 || !(fm_scale > 0.0) ||
+      !anchor_types_dev || (int64_t)fm_height * fm_width * per_cell > INT_MAX / 2) {
+    set_error("pp_assign_targets_grid_dev: bad anchor grid (%dx%d, %d per cell, scale %g)",
+              fm_height, fm_width, per_cell, fm_scale);
+    return PP_ERR_VALUE;
+  }
+  AnchorSource an;
+  an.grid = 1;
+  an.fm_w = fm_width;
+  an.per_cell = per_cell;
+  an.fm_scale = fm_scale;
+  an.types = anchor_types_dev;
+  return assign_targets_impl(ctx, stream_, (int64_t)fm_height * fm_width * per_cell, an, G, g_corners,
+                             g_centers_img, g_centers, g_wlh, g_yaw, g_class, prm, cls_targets,
+                             reg_targets);
 }

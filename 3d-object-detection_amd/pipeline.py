@@ -32,7 +32,8 @@ class PillarPipeline:
         self.loss = PPLoss()
         self.assigner = None
         if with_targets:
-            self.assigner = TargetAssigner(boxes.make_anchors(anchor_cfg), canvas_height=h,
+            # anchors evaluated on the fly in the target kernels (no per-anchor arrays)
+            self.assigner = TargetAssigner(anchor_cfg, canvas_height=h,
                                            pos_thresh=pos_thresh, num_classes=num_classes,
                                            device=self.device)
         self._bufs = None

@@ -18,10 +18,31 @@ def _vp(t):
 
 
 class TargetAssigner:
-    """Holds the (constant) anchor arrays on the device; ``assign(gt...)`` returns
-    ``(cls_targets[A,C] f32, reg_targets[A,9] f32)`` for one sample."""
+    """``assign(gt...)`` returns ``(cls_targets[A,C] f32, reg_targets[A,9] f32)`` for one
+    sample.  ``anchors`` is either the dict of flat arrays of ``boxes.make_anchors`` (held
+    on the device: the counterpart of anchor_boxes.pkl, train_prep.py:115-120) or a
+    ``boxes.AnchorConfig`` -- then the kernels evaluate the anchor grid on the fly from a
+    [per_cell,13] table and no per-anchor array exists at all (same results, bit for bit)."""
 
     def __init__(self, anchors, canvas_height, pos_thresh=0.6, num_classes=9, device=None):
+        if isinstance(anchors, boxes.AnchorConfig):
+            self._init_common(canvas_height, pos_thresh, num_classes, device)
+            self.grid = anchors
+            self.A = anchors.num_anchors
+            self.types = torch.as_tensor(boxes.anchor_type_table(anchors), dtype=torch.float64,
+                                         device=self.device).contiguous()
+            self.a_corners = self.a_centers = self.a_wlh = self.a_yaw = None
+            return
+        self._init_common(canvas_height, pos_thresh, num_classes, device)
+        self.grid = None
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.a_corners = torch.as_tensor(np.ascontiguousarray(anchors["corners"]), **f64).contiguous()
+        self.a_centers = torch.as_tensor(np.ascontiguousarray(anchors["centers"]), **f64).contiguous()
+        self.a_wlh = torch.as_tensor(np.ascontiguousarray(anchors["wlh"]), **f64).contiguous()
+        self.a_yaw = torch.as_tensor(np.ascontiguousarray(anchors["yaw"]), **f64).contiguous()
+        self.A = self.a_corners.shape[0]
+
+    def _init_common(self, canvas_height, pos_thresh, num_classes, device):
         if not torch.cuda.is_available():
             raise RuntimeError("TargetAssigner needs a HIP device; there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None
@@ -29,12 +50,6 @@ class TargetAssigner:
         self.canvas_height = float(canvas_height)
         self.pos_thresh = float(pos_thresh)
         self.num_classes = int(num_classes)
-        f64 = dict(dtype=torch.float64, device=self.device)
-        self.a_corners = torch.as_tensor(np.ascontiguousarray(anchors["corners"]), **f64).contiguous()
-        self.a_centers = torch.as_tensor(np.ascontiguousarray(anchors["centers"]), **f64).contiguous()
-        self.a_wlh = torch.as_tensor(np.ascontiguousarray(anchors["wlh"]), **f64).contiguous()
-        self.a_yaw = torch.as_tensor(np.ascontiguousarray(anchors["yaw"]), **f64).contiguous()
-        self.A = self.a_corners.shape[0]
         self._ctx = _lib.Context(self.device.index)
         self._prm = _lib.TargetParams(self.pos_thresh, self.canvas_height, self.num_classes, 0)
 
@@ -64,18 +79,29 @@ class TargetAssigner:
         cls_t = torch.empty((self.A, self.num_classes), dtype=torch.float32, device=self.device)
         reg_t = torch.empty((self.A, 9), dtype=torch.float32, device=self.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = _lib.lib().pp_assign_targets_dev(
-            self._ctx.handle, stream, self.A, _vp(self.a_corners), _vp(self.a_centers),
-            _vp(self.a_wlh), _vp(self.a_yaw), G, _vp(g_corners), _vp(g_centers_img),
-            _vp(g_centers), _vp(g_wlh), _vp(g_yaw), _vp(g_class), ctypes.byref(self._prm),
-            _vp(cls_t), _vp(reg_t))
-        _lib.check(rc, "pp_assign_targets_dev")
+        if self.grid is not None:
+            c = self.grid
+            rc = _lib.lib().pp_assign_targets_grid_dev(
+                self._ctx.handle, stream, c.fm_height, c.fm_width, float(c.fm_scale), c.per_cell,
+                _vp(self.types), G, _vp(g_corners), _vp(g_centers_img), _vp(g_centers), _vp(g_wlh),
+                _vp(g_yaw), _vp(g_class), ctypes.byref(self._prm), _vp(cls_t), _vp(reg_t))
+            _lib.check(rc, "pp_assign_targets_grid_dev")
+        else:
+            rc = _lib.lib().pp_assign_targets_dev(
+                self._ctx.handle, stream, self.A, _vp(self.a_corners), _vp(self.a_centers),
+                _vp(self.a_wlh), _vp(self.a_yaw), G, _vp(g_corners), _vp(g_centers_img),
+                _vp(g_centers), _vp(g_wlh), _vp(g_yaw), _vp(g_class), ctypes.byref(self._prm),
+                _vp(cls_t), _vp(reg_t))
+            _lib.check(rc, "pp_assign_targets_dev")
         if check:
             _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_dev")
         return cls_t, reg_t
 
     def ious(self, g_corners_img, g_centers_img, check=True):
         """Dense [A,G] f64 IoU matrix on the device (make_ious, pillars.cpp:400-427)."""
+        if self.grid is not None:
+            raise RuntimeError("the dense IoU matrix needs the anchor arrays: build the assigner from "
+                               "boxes.make_anchors(cfg)")
         f64 = dict(dtype=torch.float64, device=self.device)
         gc = torch.as_tensor(np.ascontiguousarray(g_corners_img), **f64).contiguous()
         gn = torch.as_tensor(np.ascontiguousarray(g_centers_img), **f64).contiguous()

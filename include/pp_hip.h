@@ -200,6 +200,23 @@ int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream, int64_t A,
                           float *reg_targets);
 
 /*
+ * The same with the anchors evaluated on the fly instead of read from arrays (SURVEY 8f
+ * rank 4: no anchor_boxes.pkl / anchor_xy.pkl, train_prep.py:115-120): the grid of
+ * make_anchor_boxes (utils/box_utils.py:111-159) -- anchor i = (y*fm_width + x)*per_cell + d,
+ * centre ((x+.5)/fm_scale, (y+.5)/fm_scale, z_d), size / yaw of type d.
+ *   anchor_types_dev [per_cell][13] f64: the rotated bottom-corner offsets from the centre
+ *                    x0,y0,..,x3,y3 (Box.bottom_corners order), then w, l, h, yaw, z
+ * Results equal pp_assign_targets_dev on the uploaded arrays bit for bit.
+ */
+int pp_assign_targets_grid_dev(pp_ctx_t *ctx, void *stream, int fm_height, int fm_width,
+                               double fm_scale, int per_cell, const double *anchor_types_dev,
+                               int64_t G, const double *g_corners_dev,
+                               const double *g_centers_img_dev, const double *g_centers_dev,
+                               const double *g_wlh_dev, const double *g_yaw_dev,
+                               const int32_t *g_class_dev, const pp_target_params_t *prm,
+                               float *cls_targets_dev, float *reg_targets_dev);
+
+/*
  * Lidar sweep ingest pre-pass: replaces, per sweep, the point
  * preparation of PPDataset.__getitem__ (data/dataset.py:65-82) --
  * LidarPointCloud.from_file rows (first four f32 columns of `raw_cols`),

@@ -113,3 +113,41 @@ def test_no_ground_truth_and_wrong_winding(gpu, oracle):
     with pytest.raises(ValueError):
         ta.ious(k, c)
     torch.cuda.synchronize()
+
+
+def test_anchor_grid_on_the_fly_equals_uploaded_arrays(gpu, oracle):
+    """anchors evaluated in the kernels from (feature-map size, dims, yaws,
+    zs) -- no per-anchor arrays -- give the SAME bits as the uploaded make_anchors arrays
+    (and therefore the oracle's targets): BASELINE config 3 and the reference's 300x300x6 set."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    for cfg, H, n_gt in ((boxes.AnchorConfig(250, 250), 500, 40),
+                         (boxes.AnchorConfig.reference_default(), 600, 25)):
+        anchors = boxes.make_anchors(cfg)
+        ta_arr = TargetAssigner(anchors, canvas_height=H, device=gpu)
+        ta_grid = TargetAssigner(cfg, canvas_height=H, device=gpu)
+        assert ta_grid.A == ta_arr.A == cfg.num_anchors and ta_grid.a_corners is None
+        for seed in (3, 4):
+            gt = synth.gt_boxes(n_gt, H, seed)
+            c0, r0 = ta_arr.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+            c1, r1 = ta_grid.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+            torch.cuda.synchronize()
+            assert torch.equal(c0, c1) and torch.equal(r0, r1)
+            assert (r1[:, 0] == 1).sum().item() > 0
+        # no ground truth: all-zero targets from the grid path too
+        c1, r1 = ta_grid.assign(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0), np.zeros(0, np.int32))
+        assert not c1.any() and not r1.any()
+    # and against the oracle directly (config 3)
+    cfg = boxes.AnchorConfig(250, 250)
+    anchors = boxes.make_anchors(cfg)
+    gt = synth.gt_boxes(40, 500, 9)
+    c1, r1 = TargetAssigner(cfg, canvas_height=500, device=gpu).assign(
+        gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+    ref_c, ref_r, _ = _oracle_targets(oracle, anchors, gt, 500)
+    _check(c1, r1, ref_c, ref_r)
+    # the type table reproduces make_anchors' corners exactly
+    tab = boxes.anchor_type_table(cfg)
+    d = np.arange(cfg.num_anchors) % cfg.per_cell
+    corners = tab[d, :8].reshape(-1, 4, 2) + anchors["centers"][:, None, :2]
+    assert np.array_equal(corners, anchors["corners"])

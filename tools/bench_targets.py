@@ -7,18 +7,20 @@ from pp_amd import boxes, synth
 from pp_amd.targets import TargetAssigner
 fm = int(sys.argv[1]) if len(sys.argv) > 1 else 250
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-anchors = boxes.make_anchors(boxes.AnchorConfig(fm, fm))
-ta = TargetAssigner(anchors, canvas_height=2 * fm)
+cfg = boxes.AnchorConfig(fm, fm)
 gt = synth.gt_boxes(G, 2 * fm, 0)
-g = ta._gt_to_device(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"])
-for _ in range(10):
-    ta.assign_device(*g)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-it = 200
-for _ in range(it):
-    ta.assign_device(*g)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / it
-A = ta.A
-print(f"A={A} G={G}: {dt*1e6:.1f} us per sample; algorithmic 112*A = {112*A/1e6:.1f} MB -> {112*A/dt/1e9:.0f} GB/s")
+for name, src in (("arrays", boxes.make_anchors(cfg)), ("grid", cfg)):
+    ta = TargetAssigner(src, canvas_height=2 * fm)
+    g = ta._gt_to_device(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"])
+    for _ in range(10):
+        ta.assign_device(*g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    it = 200
+    for _ in range(it):
+        ta.assign_device(*g)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / it
+    A = ta.A
+    print(f"A={A} G={G} anchors={name}: {dt*1e6:.1f} us per sample; algorithmic 112*A = {112*A/1e6:.1f} MB "
+          f"-> {112*A/dt/1e9:.0f} GB/s")
