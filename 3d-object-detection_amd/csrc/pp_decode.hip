@@ -30,8 +30,11 @@ constexpr int kNmsThreads = 256;
 constexpr int kMaxOut = 1024;
 
 struct DecodeArgs {
-  const float *cls;  // [Ac*C][H][W]
-  const float *reg;  // [Ac*8][H][W]
+  // element (channel ch, cell) of cls / reg at [ch*stride_c + cell*stride_pix]: NCHW planes
+  // (stride_c = H*W, stride_pix = 1) or channels-last rows (stride_c = 1, stride_pix = row pitch)
+  const float *cls;
+  const float *reg;
+  int64_t cls_sc, cls_sp, reg_sc, reg_sp;
   const double *a_centers, *a_wlh, *a_yaw, *a_xy;
   int A, Ac, C, HW;
   float pos_thresh, nms_thresh;
@@ -48,11 +51,11 @@ __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + e
 // scores,classes = torch.max(torch.sigmoid(cls), dim=-1)   (evaluate.py:231-235)
 __device__ __forceinline__ void anchor_score(const DecodeArgs &d, int a, float &score, int &klass) {
   const int cell = a / d.Ac, k = a - cell * d.Ac;
-  const float *p = d.cls + (int64_t)(k * d.C) * d.HW + cell;
+  const float *p = d.cls + (int64_t)(k * d.C) * d.cls_sc + (int64_t)cell * d.cls_sp;
   score = -1.0f;
   klass = 0;
   for (int c = 0; c < d.C; ++c) {
-    const float s = sigmoidf_ref(p[(int64_t)c * d.HW]);
+    const float s = sigmoidf_ref(p[(int64_t)c * d.cls_sc]);
     if (s > score) {  // first maximum wins
       score = s;
       klass = c;
@@ -179,7 +182,7 @@ __global__ void k_decode(DecodeArgs d) {
   anchor_score(d, a, score, klass);
   const int cell = a / d.Ac, k = a - cell * d.Ac;
   float off[8];
-  for (int r = 0; r < 8; ++r) off[r] = d.reg[(int64_t)(k * 8 + r) * d.HW + cell];
+  for (int r = 0; r < 8; ++r) off[r] = d.reg[(int64_t)(k * 8 + r) * d.reg_sc + (int64_t)cell * d.reg_sp];
   off[6] = tanhf(off[6]);  // evaluate.py:234
   const double ax = d.a_centers[(int64_t)a * 3], ay = d.a_centers[(int64_t)a * 3 + 1],
                az = d.a_centers[(int64_t)a * 3 + 2];
@@ -209,8 +212,10 @@ __global__ void k_decode(DecodeArgs d) {
 
 using namespace pp;
 
-extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev, const float *reg_dev,
-                             const double *a_centers, const double *a_wlh, const double *a_yaw,
+extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev,
+                                     const float *reg_dev, int64_t cls_stride_c,
+                                     int64_t cls_stride_pix, int64_t reg_stride_c,
+                                     int64_t reg_stride_pix, const double *a_centers, const double *a_wlh, const double *a_yaw,
                              const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
                              int32_t *kept_out, int32_t *count_out) {
   if (!ctx || !cls_dev || !reg_dev || !a_centers || !a_wlh || !a_yaw || !a_xy || !prm || !boxes_out ||
@@ -248,6 +253,10 @@ extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev,
   DecodeArgs d;
   d.cls = cls_dev;
   d.reg = reg_dev;
+  d.cls_sc = cls_stride_c;
+  d.cls_sp = cls_stride_pix;
+  d.reg_sc = reg_stride_c;
+  d.reg_sp = reg_stride_pix;
   d.a_centers = a_centers;
   d.a_wlh = a_wlh;
   d.a_yaw = a_yaw;
@@ -280,4 +289,17 @@ extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev,
   hipLaunchKernelGGL(k_decode, dim3((unsigned)((d.max_out + 127) / 128)), dim3(128), 0, stream, d);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
+}
+
+extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev, const float *reg_dev,
+                             const double *a_centers, const double *a_wlh, const double *a_yaw,
+                             const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
+                             int32_t *kept_out, int32_t *count_out) {
+  if (!prm) {
+    set_error("pp_decode_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  const int64_t hw = (int64_t)prm->fm_height * prm->fm_width;
+  return pp_decode_strided_dev(ctx, stream_, cls_dev, reg_dev, hw, 1, hw, 1, a_centers, a_wlh, a_yaw,
+                               a_xy, prm, boxes_out, kept_out, count_out);
 }

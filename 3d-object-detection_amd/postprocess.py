@@ -40,14 +40,22 @@ class Detector:
             if cls.shape[0] != 1:
                 raise ValueError("one sample at a time (evaluate.py uses batch_size=1)")
             cls, reg = cls[0], reg[0]
-        cls, reg = cls.contiguous(), reg.contiguous()
+        cls, reg = self._cell_strided(cls), self._cell_strided(reg)
         boxes = torch.empty((self.max_out, 9), dtype=torch.float64, device=self.device)
         kept = torch.empty((self.max_out,), dtype=torch.int32, device=self.device)
         count = torch.empty((1,), dtype=torch.int32, device=self.device)
         vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        rc = _lib.lib().pp_decode_dev(
+        rc = _lib.lib().pp_decode_strided_dev(
             self._ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
-            vp(cls), vp(reg), vp(self.a_centers), vp(self.a_wlh), vp(self.a_yaw), vp(self.a_xy),
+            vp(cls), vp(reg), cls.stride(0), cls.stride(2), reg.stride(0), reg.stride(2), vp(self.a_centers), vp(self.a_wlh), vp(self.a_yaw), vp(self.a_xy),
             ctypes.byref(self._prm), vp(boxes), vp(kept), vp(count))
-        _lib.check(rc, "pp_decode_dev")
+        _lib.check(rc, "pp_decode_strided_dev")
         return boxes, kept, count
+
+    @staticmethod
+    def _cell_strided(t):
+        """``t[C,H,W]`` as it is when cell y*W+x sits at a fixed pitch (NCHW planes, channels-last
+        tensors and channel slices of them -- PPModel's eval outputs), else an NCHW copy."""
+        if t.dtype == torch.float32 and t.stride(1) == t.shape[2] * t.stride(2):
+            return t
+        return t.float().contiguous()

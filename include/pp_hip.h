@@ -258,6 +258,16 @@ int pp_decode_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, const float
                   const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
                   int32_t *kept_out, int32_t *count_out);
 
+/* The same on strided network outputs: element (channel ch, cell y*W+x) of cls / reg lives at
+ * [ch*stride_c + cell*stride_pix] (in floats).  NCHW planes: (H*W, 1) -- what pp_decode_dev
+ * passes; channels-last tensors or channel slices of one: (1, row pitch), where an anchor's
+ * class logits and box offsets are contiguous. */
+int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, const float *reg_dev,
+                          int64_t cls_stride_c, int64_t cls_stride_pix, int64_t reg_stride_c,
+                          int64_t reg_stride_pix, const double *a_centers, const double *a_wlh,
+                          const double *a_yaw, const double *a_xy, const pp_decode_params_t *prm,
+                          double *boxes_out, int32_t *kept_out, int32_t *count_out);
+
 /*
  * Fused conv epilogue for the inference backbone: y = max(x + b_c, 0) * s_c + t_c in
  * place on a contiguous NCHW f32 tensor -- the ReLU -> BatchNorm2d(eval) tail (plus the

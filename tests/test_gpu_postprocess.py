@@ -51,3 +51,28 @@ def test_postprocess_no_detection_and_full_batch_guard(gpu, oracle):
     assert int(count_d.item()) == 0 and (kept_d.cpu().numpy() == -1).all() and not boxes_d.any()
     with pytest.raises(ValueError):
         det(torch.zeros(2, 18, 20, 20, device=gpu), torch.zeros(2, 16, 20, 20, device=gpu))
+
+
+def test_postprocess_on_channels_last_slices(gpu, oracle):
+    """The network's eval outputs are channel slices of ONE channels-last tensor (merged head):
+    the decoder reads them in place through (channel, cell) strides -- same result as on NCHW
+    copies -- and odd layouts fall back to a copy."""
+    import torch
+    anchors, acfg, cls, reg, H, det = _setup(gpu, 64, 7, -3.5)
+    merged = torch.from_numpy(np.concatenate([cls, reg], 0))[None].to(gpu)
+    merged = merged.contiguous(memory_format=torch.channels_last)       # [1,34,64,64], memory NHWC
+    c_cl, r_cl = merged[:, :cls.shape[0]], merged[:, cls.shape[0]:]
+    assert not c_cl.is_contiguous() and c_cl.stride(1) == 1
+    b0, k0, n0 = det(c_cl.contiguous(), r_cl.contiguous())
+    b1, k1, n1 = det(c_cl, r_cl)
+    # a layout whose rows are not at a fixed cell pitch (W padded): copy fallback
+    pad = torch.zeros(cls.shape[0], 64, 70, device=gpu)
+    pad[:, :, :64] = torch.from_numpy(cls).to(gpu)
+    b2, k2, n2 = det(pad[:, :, :64], r_cl[0])
+    torch.cuda.synchronize()
+    ref_b, ref_k = oracle.postprocess(cls, reg, anchors["centers"], anchors["wlh"], anchors["yaw"],
+                                      anchors["xy"], H, 0.2, 0.2, -0.1 * H, -0.1 * H)
+    assert int(n1.item()) == len(ref_k) > 0
+    for b, k, n in ((b1, k1, n1), (b2, k2, n2)):
+        assert torch.equal(k, k0) and torch.equal(n, n0) and torch.equal(b, b0)
+    assert np.array_equal(k1.cpu().numpy()[:len(ref_k)], ref_k.astype(np.int32))
