@@ -17,8 +17,8 @@
 // 9 MACs x 64 channels per 4-byte input make this compute-bound, not HBM-bound (reading the
 // 173 MB of a 4-sweep step takes 42 us on this chip): as a VALU kernel (v_fma_f32 or
 // v_pk_fma_f32 alike, one or four channels per lane) it ran at ~55 TF/s = 98 us per step; the
-// f32 MFMA form below is the same fmaf chain bit for bit and measures 95 us -- its MFMAs
-// (130 per wave, 45 us in total) and the rest do not overlap yet (profiles/r01/NOTES.md).
+// f32 MFMA form below is the same fmaf chain bit for bit and measures 86 us -- its MFMAs
+// (130 per wave, 41 us in total) reach 45 % of the pipe (profiles/r01/NOTES.md).
 
 #include "pp_common.h"
 
@@ -28,6 +28,7 @@ constexpr int kPfnC = 64;        // output channels = lanes
 constexpr int kPfnWaves = 4;     // waves per workgroup
 constexpr int kPfnKW = 4;        // pillars per wave
 constexpr int kPfnChunk = 256;   // points staged per pass (generic kernel)
+constexpr int kMfmaKW = 4;       // pillars per wave in the MFMA kernel (8 and 16 measured slower)
 constexpr int kPfnDepth = 8;     // operand tiles in flight per wave (MFMA kernel)
 
 __device__ __forceinline__ void wave_sync() {
@@ -76,18 +77,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // and 16 rows (four groups of four consecutive points) in registers: N % 4 == 0 puts every
 // group inside one pillar, so the running maxima are in-lane, and the two half-waves meet
 // once at the end.  Rows past the wave's last point repeat that point (no effect on a max).
-__global__ __launch_bounds__(kPfnWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void k_pfn_dense_mfma(const float *__restrict__ x,
-                                                                   const float *__restrict__ prm,
-                                                                   float *__restrict__ out, int P,
-                                                                   int N) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(kPfnWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void k_pfn_dense_mfma(
+    const float *__restrict__ x, const float *__restrict__ prm, float *__restrict__ out, int P, int N) {
+  // everything that steers control flow is wave-uniform: say so (readfirstlane), or the
+  // compiler predicates the whole tile loop with exec masks -- that junk, not the MFMAs,
+  // was 3/4 of the first version's issue slots
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y;
-  const int p0 = (blockIdx.x * kPfnWaves + wave) * kPfnKW;
+  const int p0 = (blockIdx.x * kPfnWaves + wave) * kMfmaKW;
   if (p0 >= P) return;
-  const int kw = min(kPfnKW, P - p0);
+  const int kw = min(kMfmaKW, P - p0);
   const int r = lane & 31, h = lane >> 5;
   const int64_t plane = (int64_t)P * N;
-  const float *base = x + (int64_t)b * 9 * plane + (int64_t)p0 * N;
   const int npts = kw * N;
   const int tiles = (npts + 31) >> 5;
 
@@ -106,22 +108,36 @@ __global__ __launch_bounds__(kPfnWaves * 64) __attribute__((amdgpu_waves_per_eu(
       bw[nt][st] = (f >= 0) ? sign * q[f] : 0.0f;
     }
   }
-  auto load_tile = [&](int t, float a[5]) {
-    const int q = min(t * 32 + r, npts - 1);
+  // A operand through a raw buffer: byte offset of (feature f, point q) = f*plane*4 + (p0*N+q)*4.
+  // The zero term (f = -1) gets a negative offset: out of range, and the buffer returns 0.
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(x + (int64_t)b * 9 * plane), 0, (int)(36u * (unsigned)P * (unsigned)N), 0x00020000);
+  unsigned foff[5];
 #pragma unroll
-    for (int st = 0; st < 5; ++st) {
-      const int f = 2 * st + h - 1;
-      a[st] = (f >= 0) ? base[f * plane + q] : 0.0f;
-    }
+  for (int st = 0; st < 5; ++st)
+    foff[st] = (unsigned)(((int64_t)(2 * st + h - 1) * plane + (int64_t)p0 * N) * 4);
+  auto load_tile = [&](int t, float a[5]) {
+    const unsigned q4 = (unsigned)min(t * 32 + r, npts - 1) * 4u;
+#pragma unroll
+    for (int st = 0; st < 5; ++st)
+      a[st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, foff[st] + q4, 0, 0));
   };
-  float m[2][kPfnKW];
+  // which pillar a row of the wave belongs to (rows past the last point repeat it, so they
+  // count for the last pillar)
+  auto pillar_of = [&](int row) {
+    int pid = 0;
+#pragma unroll
+    for (int k = 1; k < kMfmaKW; ++k) pid += (row >= k * N) ? 1 : 0;
+    return min(pid, kw - 1);
+  };
+  float m[2][kMfmaKW];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int k = 0; k < kPfnKW; ++k) m[nt][k] = -INFINITY;
+    for (int k = 0; k < kMfmaKW; ++k) m[nt][k] = -INFINITY;
 
   // kPfnDepth tiles of operands in flight per wave: a tile is 10 MFMAs (~0.3 us), far less
-  // than an HBM round trip, so a one-tile look-ahead left the kernel latency-bound
+  // than an HBM round trip
   float a[kPfnDepth][5];
 #pragma unroll
   for (int i = 0; i < kPfnDepth; ++i)
@@ -130,56 +146,49 @@ __global__ __launch_bounds__(kPfnWaves * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int i = 0; i < kPfnDepth; ++i) {
       const int t = t0 + i;
-      if (t < tiles) {  // wave-uniform
-        f32x16 acc[2];
+      if (t >= tiles) break;  // wave-uniform
+      f32x16 acc[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nt][v] = cb[nt];
+#pragma unroll
+        for (int st = 0; st < 5; ++st)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][st], bw[nt][st], acc[nt], 0, 0, 0);
+      }
+      if (t + kPfnDepth < tiles) load_tile(t + kPfnDepth, a[i]);
+      const int k_lo = pillar_of(t * 32), k_hi = pillar_of(t * 32 + 31);
+      if (k_lo == k_hi) {
+        // the common case (10 of 13 tiles at N = 100): all 16 registers feed one maximum
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+          float g = acc[nt][0];
 #pragma unroll
-          for (int v = 0; v < 16; ++v) acc[nt][v] = cb[nt];
+          for (int v = 1; v < 16; ++v) g = fmaxf(g, acc[nt][v]);
 #pragma unroll
-          for (int st = 0; st < 5; ++st)
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][st], bw[nt][st], acc[nt], 0, 0, 0);
+          for (int k = 0; k < kMfmaKW; ++k)
+            if (k_lo == k) m[nt][k] = fmaxf(m[nt][k], g);  // k_lo is wave-uniform
         }
-        if (t + kPfnDepth < tiles) load_tile(t + kPfnDepth, a[i]);
-        // which pillar(s) the tile's 32 rows belong to (wave-uniform; rows past the last point
-        // repeat it, so they count for the last pillar)
-        auto pillar_of = [&](int row) {
-          return min((row >= N ? 1 : 0) + (row >= 2 * N ? 1 : 0) + (row >= 3 * N ? 1 : 0), kw - 1);
-        };
-        const int k_lo = pillar_of(t * 32), k_hi = pillar_of(t * 32 + 31);
-        if (k_lo == k_hi) {
-          // the common case (10 of 13 tiles at N = 100): all 16 registers feed one maximum
+      } else {
+#pragma unroll
+        for (int vg = 0; vg < 4; ++vg) {
+          // rows vg*8 + h*4 .. +3 of the tile: inside one pillar because N % 4 == 0
+          const int pid = pillar_of(t * 32 + vg * 8 + h * 4);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
-            float g = acc[nt][0];
+            const float g = fmaxf(fmaxf(acc[nt][4 * vg], acc[nt][4 * vg + 1]),
+                                  fmaxf(acc[nt][4 * vg + 2], acc[nt][4 * vg + 3]));
 #pragma unroll
-            for (int v = 1; v < 16; ++v) g = fmaxf(g, acc[nt][v]);
-            if (k_lo == 0) m[nt][0] = fmaxf(m[nt][0], g);
-            else if (k_lo == 1) m[nt][1] = fmaxf(m[nt][1], g);
-            else if (k_lo == 2) m[nt][2] = fmaxf(m[nt][2], g);
-            else m[nt][3] = fmaxf(m[nt][3], g);
-          }
-        } else {
-#pragma unroll
-          for (int vg = 0; vg < 4; ++vg) {
-            // rows vg*8 + h*4 .. +3 of the tile: inside one pillar because N % 4 == 0
-            const int pid = pillar_of(t * 32 + vg * 8 + h * 4);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              const float g = fmaxf(fmaxf(acc[nt][4 * vg], acc[nt][4 * vg + 1]),
-                                    fmaxf(acc[nt][4 * vg + 2], acc[nt][4 * vg + 3]));
-#pragma unroll
-              for (int k = 0; k < kPfnKW; ++k) m[nt][k] = (pid == k) ? fmaxf(m[nt][k], g) : m[nt][k];
-            }
+            for (int k = 0; k < kMfmaKW; ++k) m[nt][k] = (pid == k) ? fmaxf(m[nt][k], g) : m[nt][k];
           }
         }
       }
     }
   }
   // half h stores channel tile h
-  float yv[kPfnKW];
+  float yv[kMfmaKW];
 #pragma unroll
-  for (int k = 0; k < kPfnKW; ++k) {
+  for (int k = 0; k < kMfmaKW; ++k) {
     float y[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -190,11 +199,13 @@ __global__ __launch_bounds__(kPfnWaves * 64) __attribute__((amdgpu_waves_per_eu(
     yv[k] = h ? y[1] : y[0];
   }
   float *o = out + ((int64_t)b * kPfnC + r + 32 * h) * P + p0;
-  if (kw == kPfnKW && (P & 3) == 0) {
-    *reinterpret_cast<float4 *>(o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+  if (kw == kMfmaKW && (P & 3) == 0) {
+#pragma unroll
+    for (int k = 0; k < kMfmaKW; k += 4)
+      *reinterpret_cast<float4 *>(o + k) = make_float4(yv[k], yv[k + 1], yv[k + 2], yv[k + 3]);
   } else {
 #pragma unroll
-    for (int k = 0; k < kPfnKW; ++k)
+    for (int k = 0; k < kMfmaKW; ++k)
       if (k < kw) o[k] = yv[k];
   }
 }
@@ -274,9 +285,10 @@ extern "C" int pp_pfn_dense_dev(pp_ctx_t *ctx, void *stream_, const float *pilla
   (void)hipGetDevice(&prev);
   if (prev != ctx->device) (void)hipSetDevice(ctx->device);
   const dim3 grid((unsigned)((P + kPfnWaves * kPfnKW - 1) / (kPfnWaves * kPfnKW)), (unsigned)batch);
+  const dim3 grid_mfma((unsigned)((P + kPfnWaves * kMfmaKW - 1) / (kPfnWaves * kMfmaKW)), (unsigned)batch);
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if ((N & 3) == 0)
-    hipLaunchKernelGGL(k_pfn_dense_mfma, grid, dim3(kPfnWaves * 64), 0, st, pillars_dev,
+  if ((N & 3) == 0 && 36ll * P * N < (1ll << 31))  // the MFMA kernel's buffer descriptor is 32-bit
+    hipLaunchKernelGGL(k_pfn_dense_mfma, grid_mfma, dim3(kPfnWaves * 64), 0, st, pillars_dev,
                        pfn_params_dev, features_dev, P, N);
   else
     hipLaunchKernelGGL(k_pfn_dense, grid, dim3(kPfnWaves * 64), 0, st, pillars_dev, pfn_params_dev,
