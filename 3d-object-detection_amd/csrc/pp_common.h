@@ -68,6 +68,7 @@ struct pp_ctx {
   pp::DevBuf iou_ws;
   unsigned long long tgt_key = 0;  // shape the target scratch was last armed for
   pp::DevBuf decode_ws;            // post-processing: sort keys + rocPRIM temporary storage
+  pp::DevBuf pfn_ws;               // training feature net: per-workgroup partial sums
   // emit-kernel timing ring (bench.py)
   std::vector<hipEvent_t> ev_start, ev_stop;
   int ev_slots = 0;

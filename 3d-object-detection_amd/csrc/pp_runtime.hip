@@ -125,6 +125,7 @@ extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
   ctx->stage_out2.release();
   ctx->iou_ws.release();
   ctx->decode_ws.release();
+  ctx->pfn_ws.release();
   ctx->pin_in.release();
   ctx->pin_out.release();
   ctx->pin_meta.release();

@@ -114,6 +114,73 @@ def _use_fused_epilogue(module, x):
     return (not module.training) and module.fused_epilogue and x.is_cuda and x.dtype == torch.float32
 
 
+def _hip_ctx(dev):
+    ctx = _Epilogue._ctx.get(dev.index)
+    if ctx is None:
+        ctx = _Epilogue._ctx[dev.index] = _lib.Context(dev.index)
+    return ctx
+
+
+class _PfnTrain(torch.autograd.Function):
+    """PPFeatureNet.forward in training mode (model/model.py:31-40: conv1x1, ReLU, BatchNorm2d
+    with batch statistics, max over N) on the HIP kernels of csrc/pp_pfn_train.hip: the
+    [B,64,P,N] intermediate is never built, forward or backward.  Gradients for the conv and
+    BatchNorm parameters (the input is data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps):
+        B, D, P, N = x.shape
+        M = B * P * N
+        dev = x.device
+        h = _hip_ctx(dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        w = weight.detach().reshape(64, 9)
+        wb = torch.cat([w, bias.detach().reshape(64, 1)], 1).contiguous()
+        sums = torch.empty((21, 64), dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().pp_pfn_train_stats_dev(h.handle, stream, vp(x), B, P, N, vp(wb), 64, vp(sums)),
+                   "pp_pfn_train_stats_dev")
+        mean = sums[1] / M
+        var = (sums[2] / M - mean * mean).clamp_(min=0.0)        # biased, as BatchNorm normalises
+        invstd = torch.rsqrt(var + eps)
+        scale = gamma.detach().double() * invstd
+        shift = beta.detach().double() - mean * scale
+        table = torch.cat([wb.double(), scale[:, None], shift[:, None]], 1).float().contiguous()   # [64,12]
+        out = torch.empty((B, 64, P), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().pp_pfn_dense_dev(h.handle, stream, vp(x), B, P, N, vp(table), 64, vp(out)),
+                   "pp_pfn_dense_dev")
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                unbiased = var * (M / max(M - 1, 1))
+                running_var.mul_(1.0 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        ctx.save_for_backward(x, table, mean.float(), invstd.float(), sums)
+        ctx.M = M
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, table, mean32, invstd32, sums = ctx.saved_tensors
+        B, D, P, N = x.shape
+        M = float(ctx.M)
+        dev = x.device
+        h = _hip_ctx(dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        g = g.contiguous().float()
+        bs = torch.empty((12, 64), dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().pp_pfn_train_backward_dev(h.handle, stream, vp(x), B, P, N, vp(table), vp(mean32),
+                                                        vp(invstd32), vp(g), 64, vp(bs)),
+                   "pp_pfn_train_backward_dev")
+        dbeta, dgamma, db_sel, dw_sel = bs[0], bs[1], bs[2], bs[3:12]
+        scale, mean, invstd = table[:, 10].double(), mean32.double(), invstd32.double()
+        a = scale * (-dbeta / M + mean * dgamma * invstd / M)      # dr = s*dy + a + b*r on z > 0
+        b = -scale * dgamma * invstd / M
+        dw = (dw_sel + a * sums[3:12] + b * sums[12:21]).t().reshape(64, 9, 1, 1)
+        db = db_sel + a * sums[0] + b * sums[1]
+        return None, dw.float(), db.float(), dgamma.float(), dbeta.float(), None, None, None, None
+
+
 class PPFeatureNet(nn.Module):
     """model/model.py:13-40: 1x1 conv D->C, ReLU, THEN BatchNorm, max over N."""
 
@@ -127,6 +194,10 @@ class PPFeatureNet(nn.Module):
         #: ... and on the GPU (9 -> 64 channels, f32) as ONE HIP kernel that reads the dense
         #: tensor once (csrc/pp_pfn.hip); no [B,C,P,N] intermediate at all
         self.hip_eval = True
+        #: training on the GPU: batch statistics, forward and parameter gradients from three
+        #: passes over the dense tensor (csrc/pp_pfn_train.hip) instead of ten over the
+        #: 64x inflated intermediate
+        self.hip_train = True
         self._params = _LayoutCache()
 
     def forward(self, x):                  # [B,D,P,N]
@@ -135,6 +206,15 @@ class PPFeatureNet(nn.Module):
                     and x.shape[1] == 9 and self.conv1.out_channels == 64 and not torch.is_grad_enabled()):
                 return self.forward_hip(x)
             return self.forward_eval(x)
+        if (self.training and self.hip_train and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and x.shape[1] == 9 and self.conv1.out_channels == 64 and not x.requires_grad
+                and self.bn1.track_running_stats and self.bn1.momentum is not None and self.bn1.affine
+                and x.numel() > 0):
+            out = _PfnTrain.apply(x if x.is_contiguous() else x.contiguous(), self.conv1.weight,
+                                  self.conv1.bias, self.bn1.weight, self.bn1.bias, self.bn1.running_mean,
+                                  self.bn1.running_var, float(self.bn1.momentum), float(self.bn1.eps))
+            self.bn1.num_batches_tracked.add_(1)
+            return out
         x = self.conv1(x)
         x = F.relu(x)
         x = self.bn1(x)

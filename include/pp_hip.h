@@ -114,6 +114,36 @@ int pp_pfn_dense_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int 
                      int channels, float *features_dev);
 
 /*
+ * PPFeatureNet in TRAINING mode (BatchNorm with batch statistics) without the [64,P,N]
+ * intermediate.  The forward needs the per-channel batch statistics of r = ReLU(conv(x)); the
+ * backward needs, besides the gradient at each pillar's selected element, per-channel sums that
+ * do not depend on the incoming gradient -- both come from ONE pass over the dense tensor:
+ *   weight_bias_dev [64][10] f32 {w[0..8], bias}
+ *   sums_dev        [21][64] f64: #{z>0}, sum r, sum r^2, S1[d] = sum_{z>0} x_d (9 rows),
+ *                   S2[d] = sum r*x_d (9 rows), over all batch*P*N slots
+ * The forward output is then pp_pfn_dense_dev with scale/shift from the batch statistics.
+ */
+int pp_pfn_train_stats_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int batch,
+                           int max_pillars, int max_points_per_pillar, const float *weight_bias_dev,
+                           int channels, double *sums_dev);
+
+/*
+ * ... and the gradient-dependent part of the backward: per (b,c,p) the element the forward's
+ * max selected is found again (same fmaf chain), and
+ *   sums_dev [12][64] f64: dbeta = sum G, dgamma = sum G*xhat*, then the selected elements'
+ *            contribution to db (1 row) and dW[d] (9 rows)
+ *   pfn_params_dev [64][12] (the forward table: w, bias, scale, shift), mean_dev / invstd_dev [64]
+ *   grad_out_dev [batch][64][P] f32
+ * The caller combines: dW = sparse + A*S1 + B*S2, db = sparse + A*cnt + B*sum r with
+ * A = scale*(-dbeta/M + mean*dgamma*invstd/M), B = -scale*dgamma*invstd/M, M = batch*P*N.
+ */
+int pp_pfn_train_backward_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int batch,
+                              int max_pillars, int max_points_per_pillar,
+                              const float *pfn_params_dev, const float *mean_dev,
+                              const float *invstd_dev, const float *grad_out_dev, int channels,
+                              double *sums_dev);
+
+/*
  * The same, with PPScatter.forward fused in as well (model/model.py:53-62): the feature
  * vector of every flagged pillar goes straight to its pixel of the BEV canvas,
  * canvas[b, :, row, col] = features[b, :, p]; the [batch][64][P] tensor is never built.

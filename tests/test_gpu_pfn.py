@@ -161,3 +161,85 @@ def test_fused_scatter_pipeline_equals_dense_pipeline(gpu):
         assert c.shape == c0.shape and r.shape == r0.shape
         assert (c - c0).abs().max().item() <= 1e-4 * max(1.0, c0.abs().max().item()), name
         assert (r - r0).abs().max().item() <= 1e-4 * max(1.0, r0.abs().max().item()), name
+
+
+def test_training_feature_net_matches_pytorch_autograd(gpu):
+    """PPFeatureNet in train() on the HIP kernels (batch statistics, forward, parameter
+    gradients; no [B,64,P,N] intermediate) against the PyTorch module sequence + autograd in
+    f64 (model/model.py:31-40): output, running statistics, d/d(conv weight, conv bias,
+    BN weight, BN bias).  Tolerance: f32 evaluation of sums over ~2M slots -> 2e-4 relative
+    to each tensor's scale (PyTorch's own f32 path is checked to the same bar)."""
+    import torch
+    import pp_amd.model as M
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    vox = PillarVoxelizer(VoxelConfig.square(20.0, 0.2, 6000, 32), device=gpu)
+    pts = torch.from_numpy(np.stack([synth.lidar_like(20000, 20.0, s) for s in (0, 1, 2)])).to(gpu)
+    dense, _ = vox(pts)
+    # keep magnitudes moderate so that f32 sums are meaningful: the reference subtracts a data mean
+    dense = dense / torch.tensor([20, 20, 3, 255, 200, 200, 1, 1, 1], device=gpu).view(1, 9, 1, 1)
+    results = {}
+    for name, dtype, hip in (("f64", torch.float64, False), ("torch32", torch.float32, False),
+                             ("hip", torch.float32, True)):
+        torch.manual_seed(11)
+        fn = M.PPFeatureNet(9, 64).to(gpu)
+        with torch.no_grad():
+            fn.bn1.weight.normal_(0, 1.0)      # both signs of the BatchNorm scale
+            fn.bn1.bias.normal_(0, 0.3)
+            fn.conv1.weight.mul_(2.0)
+        fn = fn.to(dtype).train()
+        fn.hip_train = hip
+        x = dense.to(dtype)
+        out = fn(x)
+        gsrc = torch.Generator(device="cpu").manual_seed(5)
+        g = torch.randn(out.shape, generator=gsrc).to(gpu).to(dtype)
+        out.backward(g)
+        results[name] = dict(out=out.detach().double(), rm=fn.bn1.running_mean.double(),
+                             rv=fn.bn1.running_var.double(), nb=int(fn.bn1.num_batches_tracked),
+                             dw=fn.conv1.weight.grad.double(), db=fn.conv1.bias.grad.double(),
+                             dg=fn.bn1.weight.grad.double(), dbeta=fn.bn1.bias.grad.double())
+    torch.cuda.synchronize()
+    ref = results["f64"]
+    assert (ref["dg"].abs() > 0).all() and results["hip"]["nb"] == 1
+
+    def err(a, b):
+        return ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+    for key in ("out", "rm", "rv", "dw", "db", "dg", "dbeta"):
+        e_hip, e_t32 = err(results["hip"][key], ref[key]), err(results["torch32"][key], ref[key])
+        assert e_hip <= 2e-4, (key, e_hip, e_t32)
+        assert e_hip <= 10 * e_t32 + 2e-5, (key, e_hip, e_t32)
+    # a second step keeps accumulating the running statistics like BatchNorm2d does
+    assert results["hip"]["rm"].abs().max() > 0
+
+
+def test_training_pipeline_step_uses_hip_feature_net(gpu):
+    """train_forward_backward with the HIP training feature net vs the same step on the
+    PyTorch modules.  The forward agrees to f32 rounding (losses to 1e-5); the gradients of a
+    deep f32 network with batch-statistics BatchNorm amplify that rounding (two PyTorch runs
+    differ by up to 3e-2 of a tensor's scale from MIOpen's atomics alone), so they are compared
+    by direction: cosine >= 0.999 per tensor group and overall."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    cfg = VoxelConfig.square(16.0, 0.2, 3000, 32)
+    pts = torch.from_numpy(np.stack([synth.lidar_like(12000, 16.0, s) for s in (0, 1)])).to(gpu)
+    gts = [synth.gt_boxes(12, cfg.canvas_height, s) for s in (0, 1)]
+    grads, losses = {}, {}
+    for hip in (False, True):
+        pipe = PillarPipeline(cfg, device=gpu, seed=0, with_targets=True)
+        pipe.model.train()
+        pipe.model.feature_net.hip_train = hip
+        losses[hip] = [t.item() for t in pipe.train_forward_backward(pts, gts)]
+        grads[hip] = {n: p.grad.detach().double().flatten() for n, p in pipe.model.named_parameters()}
+    for a, b in zip(losses[True], losses[False]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (losses[True], losses[False])
+
+    def cos(names):
+        u = torch.cat([grads[True][n] for n in names])
+        v = torch.cat([grads[False][n] for n in names])
+        return (u @ v / (u.norm() * v.norm())).item()
+    names = list(grads[False])
+    assert cos(names) >= 0.999
+    for prefix in ("feature_net.", "backbone.down1", "backbone.down2", "backbone.down3", "det_head."):
+        assert cos([n for n in names if n.startswith(prefix)]) >= 0.999, prefix
