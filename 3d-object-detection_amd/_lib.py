@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("PP_HIP_LIB") or os.path.join(_HERE, "libpp_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f)
-           for f in ("pp_runtime.hip", "pp_voxelize.hip", "pp_iou.hip", "pp_ingest.hip", "pp_decode.hip", "pp_epilogue.hip", "pp_pfn.hip", "pp_pfn_train.hip")]
+           for f in ("pp_runtime.hip", "pp_voxelize.hip", "pp_iou.hip", "pp_ingest.hip", "pp_decode.hip", "pp_epilogue.hip", "pp_pfn.hip", "pp_pfn_train.hip", "pp_bn_train.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "pp_common.h"), os.path.join(_ROOT, "include", "pp_hip.h")]
 
 PP_OK, PP_ERR_INDEX, PP_ERR_VALUE, PP_ERR_WINDING = 0, -2, -3, -4
@@ -24,7 +24,7 @@ MAX_BATCH = 32
 EXPORTS = [
     "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
     "pp_voxelize_reserve", "pp_voxelize_dev", "pp_voxelize_pfn_dev", "pp_voxelize_pfn_canvas_dev", "pp_pfn_dense_dev", "pp_pfn_train_stats_dev", "pp_pfn_train_backward_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
-    "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_ingest_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_ctx_set_timing",
+    "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_ingest_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_relu_bn_train_fwd_dev", "pp_relu_bn_train_bwd_dev", "pp_ctx_set_timing",
     "pp_ctx_read_emit_ms",
 ]
 
@@ -132,6 +132,9 @@ def lib():
                                             ctypes.POINTER(DecodeParams), vp, vp, vp]
         L.pp_bias_relu_bn_dev.argtypes = [vp, vp, vp, i64, c_int, i64, vp, vp, i64, i64]
         L.pp_bias_relu_bn_nhwc_dev.argtypes = [vp, vp, vp, i64, c_int, vp, vp, i64, i64]
+        dbl = ctypes.c_double
+        L.pp_relu_bn_train_fwd_dev.argtypes = [vp, vp, vp, i64, c_int, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp]
+        L.pp_relu_bn_train_bwd_dev.argtypes = [vp, vp, vp, vp, i64, c_int, i64, vp, vp, vp, vp, vp, vp]
         L.pp_ctx_set_timing.argtypes = [vp, c_int]
         L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
                                           ctypes.POINTER(c_int)]

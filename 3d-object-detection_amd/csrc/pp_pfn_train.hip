@@ -121,16 +121,31 @@ __global__ __launch_bounds__(kTrWaves * 64) void k_pfn_train_stats(const float *
   tr_flush<kTrStats>(acc, s_red, wave, lane, part);
 }
 
-// part [nwg][K][64] f32 -> sums [K][64] f64; one workgroup per k, one lane per channel
-__global__ __launch_bounds__(256) void k_pfn_train_reduce(const float *__restrict__ part, int nwg, int K,
-                                                          double *__restrict__ sums) {
-  __shared__ double s[4][kTrC];
+// part [nwg][K][64] f32 -> sums [K][64] f64; one workgroup per k: 16 row groups x 64 channels,
+// four independent accumulators per thread (the loads are a latency chain otherwise)
+__global__ __launch_bounds__(1024) void k_pfn_train_reduce(const float *__restrict__ part, int nwg, int K,
+                                                           double *__restrict__ sums) {
+  __shared__ double s[16][kTrC];
   const int k = blockIdx.x, c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  double v = 0.0;
-  for (int w = q; w < nwg; w += 4) v += (double)part[((int64_t)w * K + k) * kTrC + c];
-  s[q][c] = v;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  const float *p = part + (int64_t)k * kTrC + c;
+  const int64_t stride = (int64_t)K * kTrC;
+  int w = q;
+  for (; w + 48 < nwg; w += 64) {
+    v0 += (double)p[(int64_t)w * stride];
+    v1 += (double)p[(int64_t)(w + 16) * stride];
+    v2 += (double)p[(int64_t)(w + 32) * stride];
+    v3 += (double)p[(int64_t)(w + 48) * stride];
+  }
+  for (; w < nwg; w += 16) v0 += (double)p[(int64_t)w * stride];
+  s[q][c] = (v0 + v1) + (v2 + v3);
   __syncthreads();
-  if (q == 0) sums[k * kTrC + c] = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+  if (q == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s[i][c];
+    sums[k * kTrC + c] = t;
+  }
 }
 
 // Backward, the per-(b,c,p) part.  prm [64][12] {w[0..8], bias, scale, shift} (the forward
@@ -243,7 +258,7 @@ extern "C" int pp_pfn_train_stats_dev(pp_ctx_t *ctx, void *stream_, const float 
   float *part = static_cast<float *>(ctx->pfn_ws.ptr);
   hipLaunchKernelGGL(k_pfn_train_stats, dim3(nwg), dim3(kTrWaves * 64), 0, st, pillars_dev,
                      weight_bias_dev, part, batch, max_pillars, max_points_per_pillar);
-  hipLaunchKernelGGL(k_pfn_train_reduce, dim3(kTrStats), dim3(256), 0, st, part, nwg, kTrStats, sums_dev);
+  hipLaunchKernelGGL(k_pfn_train_reduce, dim3(kTrStats), dim3(1024), 0, st, part, nwg, kTrStats, sums_dev);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -281,7 +296,7 @@ extern "C" int pp_pfn_train_backward_dev(pp_ctx_t *ctx, void *stream_, const flo
   hipLaunchKernelGGL(k_pfn_train_bwd, dim3(nwg), dim3(kTrWaves * 64), 0, st, pillars_dev, pfn_params_dev,
                      mean_dev, invstd_dev, grad_out_dev, part, batch, max_pillars,
                      max_points_per_pillar);
-  hipLaunchKernelGGL(k_pfn_train_reduce, dim3(kTrBwd), dim3(256), 0, st, part, nwg, kTrBwd, sums_dev);
+  hipLaunchKernelGGL(k_pfn_train_reduce, dim3(kTrBwd), dim3(1024), 0, st, part, nwg, kTrBwd, sums_dev);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }

@@ -181,6 +181,56 @@ class _PfnTrain(torch.autograd.Function):
         return None, dw.float(), db.float(), dgamma.float(), dbeta.float(), None, None, None, None
 
 
+class _ReluBnTrain(torch.autograd.Function):
+    """``BatchNorm2d(ReLU(z))`` in training mode as two passes forward and two backward over
+    the activation (csrc/pp_bn_train.hip) instead of a ReLU kernel + MIOpen's BatchNorm each
+    way; only ``z`` is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps):
+        B, C, H, W = z.shape
+        dev = z.device
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        y = torch.empty_like(z)
+        mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        rc = _lib.lib().pp_relu_bn_train_fwd_dev(
+            _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z), B, C,
+            H * W, vp(gamma), vp(beta), float(eps), float(momentum), vp(running_mean), vp(running_var),
+            vp(y), vp(mean), vp(invstd))
+        _lib.check(rc, "pp_relu_bn_train_fwd_dev")
+        ctx.save_for_backward(z, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, mean, invstd = ctx.saved_tensors
+        B, C, H, W = z.shape
+        dev = z.device
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        rc = _lib.lib().pp_relu_bn_train_bwd_dev(
+            _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z), vp(dy), B,
+            C, H * W, vp(gamma), vp(mean), vp(invstd), vp(dz), vp(dgamma), vp(dbeta))
+        _lib.check(rc, "pp_relu_bn_train_bwd_dev")
+        return dz, dgamma, dbeta, None, None, None, None
+
+
+def _relu_bn(z, bn, enabled=True):
+    """``bn(relu(z))``; in training mode on the GPU through the fused HIP kernels."""
+    if (enabled and bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4
+            and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and bn.weight.dtype == torch.float32 and z.numel() > 0):
+        y = _ReluBnTrain.apply(z if z.is_contiguous() else z.contiguous(), bn.weight, bn.bias,
+                               bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps))
+        bn.num_batches_tracked.add_(1)
+        return y
+    return bn(F.relu(z))
+
+
 class PPFeatureNet(nn.Module):
     """model/model.py:13-40: 1x1 conv D->C, ReLU, THEN BatchNorm, max over N."""
 
@@ -308,11 +358,17 @@ class PPDownBlock(nn.Module):
         self.block = nn.Sequential(*block)
         #: inference only: conv without bias + one fused bias/ReLU/BatchNorm pass per layer
         self.fused_epilogue = True
+        #: training: ReLU -> BatchNorm2d (batch statistics) through the fused HIP kernels
+        self.fused_train = True
         self._epi = [_Epilogue() for _ in range(num_layers)]
         self._wcl = [_LayoutCache() for _ in range(num_layers)]
 
     def forward(self, x):
         if not _use_fused_epilogue(self, x):
+            if self.training and self.fused_train and x.is_cuda:
+                for i in range(len(self._epi)):
+                    x = _relu_bn(self.block[3 * i](x), self.block[3 * i + 2])
+                return x
             return self.block(x)
         for i, epi in enumerate(self._epi):
             conv, bn = self.block[3 * i], self.block[3 * i + 2]
@@ -330,12 +386,13 @@ class PPUpBlock(nn.Module):
                                            padding=padding, output_padding=output_padding)
         self.bn = nn.BatchNorm2d(out_channels)
         self.fused_epilogue = True
+        self.fused_train = True
         self._epi = _Epilogue()
         self._wcl = _LayoutCache()
 
     def forward(self, x, out=None, channel_offset=0):
         if not _use_fused_epilogue(self, x):
-            return self.bn(F.relu(self.conv2d_t(x)))
+            return _relu_bn(self.conv2d_t(x), self.bn, self.fused_train)
         ct = self.conv2d_t
         y = F.conv_transpose2d(x, _weight_like(x, ct.weight, self._wcl), None, ct.stride, ct.padding,
                                ct.output_padding)

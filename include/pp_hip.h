@@ -318,6 +318,27 @@ int pp_bias_relu_bn_nhwc_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t 
                              const float *params_dev, float *y_dev, int64_t y_channels,
                              int64_t y_channel_offset);
 
+/*
+ * The ReLU -> BatchNorm2d tail of the backbone blocks in TRAINING mode (model/model.py:76-84,
+ * 105-109; BatchNorm with batch statistics), forward and backward, on NCHW f32 tensors:
+ *   forward   y = gamma*(max(z,0) - mean)*invstd + beta with the batch mean / biased variance
+ *             of max(z,0) per channel; mean_out / invstd_out [channels] are kept for the
+ *             backward; running_mean / running_var (both or neither NULL) are updated with
+ *             `momentum` (unbiased variance), exactly as nn.BatchNorm2d does.
+ *   backward  dz = [z > 0] * gamma*invstd * (dy - mean(dy) - xhat*mean(dy*xhat)),
+ *             dgamma = sum dy*xhat, dbeta = sum dy.  Only z is needed from the forward.
+ *   z_dev, y_dev, dy_dev, dz_dev [batch][channels][hw] f32
+ */
+int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev, int64_t batch,
+                             int channels, int64_t hw, const float *gamma_dev, const float *beta_dev,
+                             double eps, double momentum, float *running_mean_dev,
+                             float *running_var_dev, float *y_dev, float *mean_out_dev,
+                             float *invstd_out_dev);
+int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev, const float *dy_dev,
+                             int64_t batch, int channels, int64_t hw, const float *gamma_dev,
+                             const float *mean_dev, const float *invstd_dev, float *dz_dev,
+                             float *dgamma_dev, float *dbeta_dev);
+
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
  * stream around the k_emit launch.  pp_ctx_read_emit_ms synchronises on the

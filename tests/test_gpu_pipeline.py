@@ -151,3 +151,39 @@ def test_channels_last_backbone_equals_nchw(gpu):
         d.fused_epilogue = False
         b = d(xx)
     assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+
+
+def test_fused_relu_batchnorm_training_matches_autograd(gpu):
+    """bn(relu(z)) in train() through the fused HIP kernels (forward: batch statistics, running
+    statistics, output; backward: dz, dgamma, dbeta) against PyTorch's modules + autograd in
+    f64.  Shapes: vector path, odd planes (scalar path), one slice, many slices."""
+    import torch
+    import pp_amd.model as M
+    for shape in ((4, 64, 60, 60), (2, 5, 63, 63), (1, 3, 7, 5), (3, 16, 250, 250)):
+        res = {}
+        for name, dtype, fused in (("f64", torch.float64, False), ("t32", torch.float32, False),
+                                   ("hip", torch.float32, True)):
+            torch.manual_seed(3)
+            bn = torch.nn.BatchNorm2d(shape[1]).to(gpu)
+            with torch.no_grad():
+                bn.weight.normal_(0, 1.0)
+                bn.bias.normal_(0, 0.5)
+                bn.running_mean.normal_(0, 0.2)
+                bn.running_var.uniform_(0.5, 1.5)
+            bn = bn.to(dtype).train()
+            g = torch.Generator(device="cpu").manual_seed(1)
+            z = (torch.randn(shape, generator=g) * 1.5 + 0.2).to(gpu).to(dtype).requires_grad_(True)
+            dy = torch.randn(shape, generator=g).to(gpu).to(dtype)
+            y = M._relu_bn(z, bn, enabled=fused)
+            y.backward(dy)
+            res[name] = dict(y=y.detach().double(), dz=z.grad.double(), dg=bn.weight.grad.double(),
+                             db=bn.bias.grad.double(), rm=bn.running_mean.double(), rv=bn.running_var.double(),
+                             nb=int(bn.num_batches_tracked))
+        torch.cuda.synchronize()
+        assert res["hip"]["nb"] == 1
+        for key in ("y", "dz", "dg", "db", "rm", "rv"):
+            ref = res["f64"][key]
+            scale = ref.abs().max().clamp(min=1e-30)
+            e_hip = ((res["hip"][key] - ref).abs().max() / scale).item()
+            e_t32 = ((res["t32"][key] - ref).abs().max() / scale).item()
+            assert e_hip <= 1e-5 + 4 * e_t32, (shape, key, e_hip, e_t32)
