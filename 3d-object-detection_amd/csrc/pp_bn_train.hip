@@ -5,7 +5,11 @@
 // backward 180 us on a 64 MB activation) + a ReLU-backward kernel, and keeps both the conv
 // output and the ReLU output for the backward.  Here:
 //
-//   forward   pass 1  per-channel sum / sum of squares of r = max(z, 0)      (k_rbn_stats)
+// z may be the convolution WITHOUT its bias: the kernels add the per-channel bias b on the fly
+// (one elementwise kernel less forward) and the backward returns db = sum dz from three extra
+// per-channel sums of its first pass (one reduction kernel less per layer).
+//
+//   forward   pass 1  per-channel sum / sum of squares of r = max(z + b, 0)  (k_rbn_stats)
 //             pass 2  y = s*r + t with s = gamma*invstd, t = beta - mean*s; the first slice
 //                     of every channel also updates the running statistics   (k_rbn_apply)
 //   backward  pass 1  dbeta = sum dy, dgamma = sum dy*xhat                  (k_rbn_bwd_stats)
@@ -38,39 +42,45 @@ __device__ __forceinline__ void rbn_range(const RbnGeom &g, int s, int64_t &lo, 
   }
 }
 
-// block-wide sum of two doubles; result valid in every thread
-__device__ __forceinline__ void rbn_block_sum(double &a, double &b, double (*s_red)[2]) {
+// block-wide sums of NP doubles; results valid in every thread
+template <int NP>
+__device__ __forceinline__ void rbn_block_sum(double (&v)[NP], double (*s_red)[NP]) {
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    a += __shfl_xor(a, d, 64);
-    b += __shfl_xor(b, d, 64);
-  }
+  for (int k = 0; k < NP; ++k)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    s_red[w][0] = a;
-    s_red[w][1] = b;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) s_red[w][k] = v[k];
   }
   __syncthreads();
-  a = 0.0;
-  b = 0.0;
 #pragma unroll
-  for (int i = 0; i < kRbnThreads / 64; ++i) {
-    a += s_red[i][0];
-    b += s_red[i][1];
+  for (int k = 0; k < NP; ++k) {
+    v[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < kRbnThreads / 64; ++i) v[k] += s_red[i][k];
   }
   __syncthreads();
 }
 
-// sum over the slices of channel c of the two partials; result valid in every thread
+// sums over the slices of channel c of the NP partials; results valid in every thread
+template <int NP>
 __device__ __forceinline__ void rbn_channel_sums(const double *__restrict__ part, int c, int nsplit,
-                                                 double &a, double &b, double (*s_red)[2]) {
-  a = 0.0;
-  b = 0.0;
-  if ((int)threadIdx.x < nsplit) {
-    a = part[((int64_t)c * nsplit + threadIdx.x) * 2];
-    b = part[((int64_t)c * nsplit + threadIdx.x) * 2 + 1];
+                                                 double (&v)[NP], double (*s_red)[NP]) {
+#pragma unroll
+  for (int k = 0; k < NP; ++k)
+    v[k] = ((int)threadIdx.x < nsplit) ? part[((int64_t)c * nsplit + threadIdx.x) * NP + k] : 0.0;
+  rbn_block_sum<NP>(v, s_red);
+}
+
+template <int NP>
+__device__ __forceinline__ void rbn_store_partials(double *__restrict__ part, int c, int s, int nsplit,
+                                                   const double (&v)[NP]) {
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) part[((int64_t)c * nsplit + s) * NP + k] = v[k];
   }
-  rbn_block_sum(a, b, s_red);
 }
 
 template <typename F>
@@ -88,43 +98,44 @@ __device__ __forceinline__ void rbn_foreach(const RbnGeom &g, int c, int s, F &&
 }
 
 __global__ __launch_bounds__(kRbnThreads) void k_rbn_stats(const float *__restrict__ z,
+                                                           const float *__restrict__ bias,
                                                            double *__restrict__ part, RbnGeom g) {
   __shared__ double s_red[kRbnThreads / 64][2];
   const int c = blockIdx.x, s = blockIdx.y;
+  const float bc = bias ? bias[c] : 0.0f;
   float sum = 0.0f, sq = 0.0f;
   rbn_foreach(g, c, s, [&](int64_t o, int n) {
     if (n == 4) {
       const float4 v = *reinterpret_cast<const float4 *>(z + o);
-      const float r0 = fmaxf(v.x, 0.0f), r1 = fmaxf(v.y, 0.0f), r2 = fmaxf(v.z, 0.0f),
-                  r3 = fmaxf(v.w, 0.0f);
+      const float r0 = fmaxf(v.x + bc, 0.0f), r1 = fmaxf(v.y + bc, 0.0f), r2 = fmaxf(v.z + bc, 0.0f),
+                  r3 = fmaxf(v.w + bc, 0.0f);
       sum += (r0 + r1) + (r2 + r3);
       sq = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, sq))));
     } else {
-      const float r = fmaxf(z[o], 0.0f);
+      const float r = fmaxf(z[o] + bc, 0.0f);
       sum += r;
       sq = fmaf(r, r, sq);
     }
   });
-  double a = sum, b = sq;
-  rbn_block_sum(a, b, s_red);
-  if (threadIdx.x == 0) {
-    part[((int64_t)c * g.nsplit + s) * 2] = a;
-    part[((int64_t)c * g.nsplit + s) * 2 + 1] = b;
-  }
+  double v[2] = {sum, sq};
+  rbn_block_sum<2>(v, s_red);
+  rbn_store_partials<2>(part, c, s, g.nsplit, v);
 }
 
 __global__ __launch_bounds__(kRbnThreads) void k_rbn_apply(
-    const float *__restrict__ z, float *__restrict__ y, const double *__restrict__ part,
-    const float *__restrict__ gamma, const float *__restrict__ beta, float *running_mean,
+    const float *__restrict__ z, const float *__restrict__ bias, float *__restrict__ y,
+    const double *__restrict__ part, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *running_mean,
     float *running_var, float *__restrict__ mean_out, float *__restrict__ invstd_out, double eps,
     double momentum, RbnGeom g) {
   __shared__ double s_red[kRbnThreads / 64][2];
   const int c = blockIdx.x, s = blockIdx.y;
-  double a, b;
-  rbn_channel_sums(part, c, g.nsplit, a, b, s_red);
+  const float bc = bias ? bias[c] : 0.0f;
+  double v[2];
+  rbn_channel_sums<2>(part, c, g.nsplit, v, s_red);
   const double M = (double)g.B * (double)g.HW;
-  const double mean = a / M;
-  double var = b / M - mean * mean;  // biased: what BatchNorm normalises with
+  const double mean = v[0] / M;
+  double var = v[1] / M - mean * mean;  // biased: what BatchNorm normalises with
   var = var > 0.0 ? var : 0.0;
   const double invstd = 1.0 / sqrt(var + eps);
   const float sc = (float)((double)gamma[c] * invstd);
@@ -140,76 +151,87 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_apply(
   }
   rbn_foreach(g, c, s, [&](int64_t o, int n) {
     if (n == 4) {
-      float4 v = *reinterpret_cast<const float4 *>(z + o);
-      v.x = fmaf(fmaxf(v.x, 0.0f), sc, sh);
-      v.y = fmaf(fmaxf(v.y, 0.0f), sc, sh);
-      v.z = fmaf(fmaxf(v.z, 0.0f), sc, sh);
-      v.w = fmaf(fmaxf(v.w, 0.0f), sc, sh);
-      *reinterpret_cast<float4 *>(y + o) = v;
+      float4 q = *reinterpret_cast<const float4 *>(z + o);
+      q.x = fmaf(fmaxf(q.x + bc, 0.0f), sc, sh);
+      q.y = fmaf(fmaxf(q.y + bc, 0.0f), sc, sh);
+      q.z = fmaf(fmaxf(q.z + bc, 0.0f), sc, sh);
+      q.w = fmaf(fmaxf(q.w + bc, 0.0f), sc, sh);
+      *reinterpret_cast<float4 *>(y + o) = q;
     } else {
-      y[o] = fmaf(fmaxf(z[o], 0.0f), sc, sh);
+      y[o] = fmaf(fmaxf(z[o] + bc, 0.0f), sc, sh);
     }
   });
 }
 
+// partials: sum dy, sum dy*xhat, and for the conv bias gradient sum_{z>0} dy, #{z>0},
+// sum_{z>0} xhat (db = sum dz = s*(sum_{z>0} dy - k1*cnt - k2*sum_{z>0} xhat))
 __global__ __launch_bounds__(kRbnThreads) void k_rbn_bwd_stats(const float *__restrict__ z,
+                                                               const float *__restrict__ bias,
                                                                const float *__restrict__ dy,
                                                                const float *__restrict__ mean,
                                                                const float *__restrict__ invstd,
                                                                double *__restrict__ part, RbnGeom g) {
-  __shared__ double s_red[kRbnThreads / 64][2];
+  __shared__ double s_red[kRbnThreads / 64][5];
   const int c = blockIdx.x, s = blockIdx.y;
+  const float bc = bias ? bias[c] : 0.0f;
   const float mu = mean[c], is = invstd[c];
-  float sd = 0.0f, sdx = 0.0f;
-  rbn_foreach(g, c, s, [&](int64_t o, int n) {
-    if (n == 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(z + o);
-      const float4 d = *reinterpret_cast<const float4 *>(dy + o);
-      sd += (d.x + d.y) + (d.z + d.w);
-      sdx = fmaf(d.x, (fmaxf(v.x, 0.0f) - mu) * is, sdx);
-      sdx = fmaf(d.y, (fmaxf(v.y, 0.0f) - mu) * is, sdx);
-      sdx = fmaf(d.z, (fmaxf(v.z, 0.0f) - mu) * is, sdx);
-      sdx = fmaf(d.w, (fmaxf(v.w, 0.0f) - mu) * is, sdx);
-    } else {
-      const float d = dy[o];
-      sd += d;
-      sdx = fmaf(d, (fmaxf(z[o], 0.0f) - mu) * is, sdx);
-    }
-  });
-  double a = sd, b = sdx;
-  rbn_block_sum(a, b, s_red);
-  if (threadIdx.x == 0) {
-    part[((int64_t)c * g.nsplit + s) * 2] = a;
-    part[((int64_t)c * g.nsplit + s) * 2 + 1] = b;
-  }
-}
-
-__global__ __launch_bounds__(kRbnThreads) void k_rbn_bwd_apply(
-    const float *__restrict__ z, const float *__restrict__ dy, const double *__restrict__ part,
-    const float *__restrict__ gamma, const float *__restrict__ mean,
-    const float *__restrict__ invstd, float *__restrict__ dz, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, RbnGeom g) {
-  __shared__ double s_red[kRbnThreads / 64][2];
-  const int c = blockIdx.x, s = blockIdx.y;
-  double a, b;
-  rbn_channel_sums(part, c, g.nsplit, a, b, s_red);  // a = dbeta, b = dgamma
-  if (s == 0 && threadIdx.x == 0) {
-    dbeta[c] = (float)a;
-    dgamma[c] = (float)b;
-  }
-  const double M = (double)g.B * (double)g.HW;
-  const float mu = mean[c], is = invstd[c];
-  const float sc = gamma[c] * is;
-  const float k1 = (float)(a / M), k2 = (float)(b / M);
+  float sd = 0.0f, sdx = 0.0f, md = 0.0f, mc = 0.0f, mx = 0.0f;
   auto one = [&](float zv, float d) {
+    zv += bc;
     const float xh = (fmaxf(zv, 0.0f) - mu) * is;
-    return zv > 0.0f ? sc * (d - k1 - xh * k2) : 0.0f;
+    const float m = zv > 0.0f ? 1.0f : 0.0f;
+    sd += d;
+    sdx = fmaf(d, xh, sdx);
+    md = fmaf(m, d, md);
+    mc += m;
+    mx = fmaf(m, xh, mx);
   };
   rbn_foreach(g, c, s, [&](int64_t o, int n) {
     if (n == 4) {
       const float4 v = *reinterpret_cast<const float4 *>(z + o);
       const float4 d = *reinterpret_cast<const float4 *>(dy + o);
-      *reinterpret_cast<float4 *>(dz + o) = make_float4(one(v.x, d.x), one(v.y, d.y), one(v.z, d.z), one(v.w, d.w));
+      one(v.x, d.x);
+      one(v.y, d.y);
+      one(v.z, d.z);
+      one(v.w, d.w);
+    } else {
+      one(z[o], dy[o]);
+    }
+  });
+  double v[5] = {sd, sdx, md, mc, mx};
+  rbn_block_sum<5>(v, s_red);
+  rbn_store_partials<5>(part, c, s, g.nsplit, v);
+}
+
+__global__ __launch_bounds__(kRbnThreads) void k_rbn_bwd_apply(
+    const float *__restrict__ z, const float *__restrict__ bias, const float *__restrict__ dy,
+    const double *__restrict__ part, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ dz, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ dbias, RbnGeom g) {
+  __shared__ double s_red[kRbnThreads / 64][5];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const float bc = bias ? bias[c] : 0.0f;
+  double v[5];
+  rbn_channel_sums<5>(part, c, g.nsplit, v, s_red);  // v[0] = dbeta, v[1] = dgamma
+  const double M = (double)g.B * (double)g.HW;
+  const float mu = mean[c], is = invstd[c];
+  const float sc = gamma[c] * is;
+  if (s == 0 && threadIdx.x == 0) {
+    dbeta[c] = (float)v[0];
+    dgamma[c] = (float)v[1];
+    if (dbias) dbias[c] = (float)((double)sc * (v[2] - v[0] / M * v[3] - v[1] / M * v[4]));
+  }
+  const float k1 = (float)(v[0] / M), k2 = (float)(v[1] / M);
+  auto one = [&](float zv, float d) {
+    zv += bc;
+    const float xh = (fmaxf(zv, 0.0f) - mu) * is;
+    return zv > 0.0f ? sc * (d - k1 - xh * k2) : 0.0f;
+  };
+  rbn_foreach(g, c, s, [&](int64_t o, int n) {
+    if (n == 4) {
+      const float4 q = *reinterpret_cast<const float4 *>(z + o);
+      const float4 d = *reinterpret_cast<const float4 *>(dy + o);
+      *reinterpret_cast<float4 *>(dz + o) = make_float4(one(q.x, d.x), one(q.y, d.y), one(q.z, d.z), one(q.w, d.w));
     } else {
       dz[o] = one(z[o], dy[o]);
     }
@@ -245,7 +267,7 @@ static int rbn_setup(const char *who, pp_ctx_t *ctx, int64_t batch, int channels
   const int64_t per_pass = (int64_t)kRbnThreads * (g->vec ? 4 : 1);
   ns = (int)std::min<int64_t>(ns, std::max<int64_t>(1, hw / per_pass));
   g->nsplit = std::max(1, std::min(ns, kRbnMaxSplit));
-  int rc = ctx->pfn_ws.ensure((size_t)channels * kRbnMaxSplit * 2 * sizeof(double) + 4096);
+  int rc = ctx->pfn_ws.ensure((size_t)channels * kRbnMaxSplit * 5 * sizeof(double) + 4096);
   if (rc) return rc;
   *part = static_cast<double *>(ctx->pfn_ws.ptr);
   return PP_OK;
@@ -266,8 +288,9 @@ struct RbnDevice {
 
 using namespace pp;
 
-extern "C" int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream_, const float *z_dev, int64_t batch,
-                                        int channels, int64_t hw, const float *gamma_dev,
+extern "C" int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream_, const float *z_dev,
+                                        const float *conv_bias_dev, int64_t batch, int channels,
+                                        int64_t hw, const float *gamma_dev,
                                         const float *beta_dev, double eps, double momentum,
                                         float *running_mean_dev, float *running_var_dev, float *y_dev,
                                         float *mean_out_dev, float *invstd_out_dev) {
@@ -283,18 +306,18 @@ extern "C" int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream_, const floa
   RbnDevice guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const dim3 grid((unsigned)channels, (unsigned)g.nsplit);
-  hipLaunchKernelGGL(k_rbn_stats, grid, dim3(kRbnThreads), 0, st, z_dev, part, g);
-  hipLaunchKernelGGL(k_rbn_apply, grid, dim3(kRbnThreads), 0, st, z_dev, y_dev, part, gamma_dev, beta_dev,
+  hipLaunchKernelGGL(k_rbn_stats, grid, dim3(kRbnThreads), 0, st, z_dev, conv_bias_dev, part, g);
+  hipLaunchKernelGGL(k_rbn_apply, grid, dim3(kRbnThreads), 0, st, z_dev, conv_bias_dev, y_dev, part, gamma_dev, beta_dev,
                      running_mean_dev, running_var_dev, mean_out_dev, invstd_out_dev, eps, momentum, g);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
 
 extern "C" int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream_, const float *z_dev,
-                                        const float *dy_dev, int64_t batch, int channels, int64_t hw,
-                                        const float *gamma_dev, const float *mean_dev,
-                                        const float *invstd_dev, float *dz_dev, float *dgamma_dev,
-                                        float *dbeta_dev) {
+                                        const float *conv_bias_dev, const float *dy_dev, int64_t batch,
+                                        int channels, int64_t hw, const float *gamma_dev,
+                                        const float *mean_dev, const float *invstd_dev, float *dz_dev,
+                                        float *dgamma_dev, float *dbeta_dev, float *dbias_dev) {
   RbnGeom g;
   double *part = nullptr;
   if (!gamma_dev || !mean_dev || !invstd_dev || !dgamma_dev || !dbeta_dev) {
@@ -307,10 +330,10 @@ extern "C" int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream_, const floa
   RbnDevice guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const dim3 grid((unsigned)channels, (unsigned)g.nsplit);
-  hipLaunchKernelGGL(k_rbn_bwd_stats, grid, dim3(kRbnThreads), 0, st, z_dev, dy_dev, mean_dev, invstd_dev,
-                     part, g);
-  hipLaunchKernelGGL(k_rbn_bwd_apply, grid, dim3(kRbnThreads), 0, st, z_dev, dy_dev, part, gamma_dev,
-                     mean_dev, invstd_dev, dz_dev, dgamma_dev, dbeta_dev, g);
+  hipLaunchKernelGGL(k_rbn_bwd_stats, grid, dim3(kRbnThreads), 0, st, z_dev, conv_bias_dev, dy_dev, mean_dev,
+                     invstd_dev, part, g);
+  hipLaunchKernelGGL(k_rbn_bwd_apply, grid, dim3(kRbnThreads), 0, st, z_dev, conv_bias_dev, dy_dev, part,
+                     gamma_dev, mean_dev, invstd_dev, dz_dev, dgamma_dev, dbeta_dev, dbias_dev, g);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }

@@ -182,12 +182,13 @@ class _PfnTrain(torch.autograd.Function):
 
 
 class _ReluBnTrain(torch.autograd.Function):
-    """``BatchNorm2d(ReLU(z))`` in training mode as two passes forward and two backward over
-    the activation (csrc/pp_bn_train.hip) instead of a ReLU kernel + MIOpen's BatchNorm each
-    way; only ``z`` is kept for the backward."""
+    """``BatchNorm2d(ReLU(z + conv_bias))`` in training mode as two passes forward and two
+    backward over the activation (csrc/pp_bn_train.hip) instead of a bias kernel, a ReLU kernel
+    and MIOpen's BatchNorm each way (plus the bias-gradient reduction); only ``z`` is kept for
+    the backward.  ``conv_bias`` may be None (z already carries it)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps):
+    def forward(ctx, z, conv_bias, gamma, beta, running_mean, running_var, momentum, eps):
         B, C, H, W = z.shape
         dev = z.device
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
@@ -195,39 +196,47 @@ class _ReluBnTrain(torch.autograd.Function):
         mean = torch.empty((C,), dtype=torch.float32, device=dev)
         invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         rc = _lib.lib().pp_relu_bn_train_fwd_dev(
-            _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z), B, C,
-            H * W, vp(gamma), vp(beta), float(eps), float(momentum), vp(running_mean), vp(running_var),
-            vp(y), vp(mean), vp(invstd))
+            _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z),
+            vp(conv_bias), B, C, H * W, vp(gamma), vp(beta), float(eps), float(momentum), vp(running_mean),
+            vp(running_var), vp(y), vp(mean), vp(invstd))
         _lib.check(rc, "pp_relu_bn_train_fwd_dev")
-        ctx.save_for_backward(z, gamma, mean, invstd)
+        ctx.save_for_backward(z, conv_bias, gamma, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        z, gamma, mean, invstd = ctx.saved_tensors
+        z, conv_bias, gamma, mean, invstd = ctx.saved_tensors
         B, C, H, W = z.shape
         dev = z.device
-        vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         dy = dy.contiguous()
         dz = torch.empty_like(z)
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbias = torch.empty((C,), dtype=torch.float32, device=dev) if conv_bias is not None else None
         rc = _lib.lib().pp_relu_bn_train_bwd_dev(
-            _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z), vp(dy), B,
-            C, H * W, vp(gamma), vp(mean), vp(invstd), vp(dz), vp(dgamma), vp(dbeta))
+            _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z),
+            vp(conv_bias), vp(dy), B, C, H * W, vp(gamma), vp(mean), vp(invstd), vp(dz), vp(dgamma), vp(dbeta),
+            vp(dbias))
         _lib.check(rc, "pp_relu_bn_train_bwd_dev")
-        return dz, dgamma, dbeta, None, None, None, None
+        return dz, dbias, dgamma, dbeta, None, None, None, None
 
 
-def _relu_bn(z, bn, enabled=True):
-    """``bn(relu(z))``; in training mode on the GPU through the fused HIP kernels."""
-    if (enabled and bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4
-            and bn.affine and bn.track_running_stats and bn.momentum is not None
-            and bn.weight.dtype == torch.float32 and z.numel() > 0):
-        y = _ReluBnTrain.apply(z if z.is_contiguous() else z.contiguous(), bn.weight, bn.bias,
+def _relu_bn_fusable(z, bn):
+    return (bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32
+            and z.numel() > 0)
+
+
+def _relu_bn(z, bn, enabled=True, conv_bias=None):
+    """``bn(relu(z + conv_bias))``; in training mode on the GPU through the fused HIP kernels."""
+    if enabled and _relu_bn_fusable(z, bn):
+        y = _ReluBnTrain.apply(z if z.is_contiguous() else z.contiguous(), conv_bias, bn.weight, bn.bias,
                                bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps))
         bn.num_batches_tracked.add_(1)
         return y
+    if conv_bias is not None:
+        z = z + conv_bias.view(1, -1, 1, 1)
     return bn(F.relu(z))
 
 
@@ -367,7 +376,9 @@ class PPDownBlock(nn.Module):
         if not _use_fused_epilogue(self, x):
             if self.training and self.fused_train and x.is_cuda:
                 for i in range(len(self._epi)):
-                    x = _relu_bn(self.block[3 * i](x), self.block[3 * i + 2])
+                    conv, bn = self.block[3 * i], self.block[3 * i + 2]
+                    x = _relu_bn(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), bn,
+                                 conv_bias=conv.bias)
                 return x
             return self.block(x)
         for i, epi in enumerate(self._epi):
@@ -392,7 +403,11 @@ class PPUpBlock(nn.Module):
 
     def forward(self, x, out=None, channel_offset=0):
         if not _use_fused_epilogue(self, x):
-            return _relu_bn(self.conv2d_t(x), self.bn, self.fused_train)
+            if self.fused_train and _relu_bn_fusable(x, self.bn):
+                ct = self.conv2d_t
+                return _relu_bn(F.conv_transpose2d(x, ct.weight, None, ct.stride, ct.padding, ct.output_padding),
+                                self.bn, conv_bias=ct.bias)
+            return self.bn(F.relu(self.conv2d_t(x)))
         ct = self.conv2d_t
         y = F.conv_transpose2d(x, _weight_like(x, ct.weight, self._wcl), None, ct.stride, ct.padding,
                                ct.output_padding)

@@ -328,16 +328,20 @@ int pp_bias_relu_bn_nhwc_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t 
  *   backward  dz = [z > 0] * gamma*invstd * (dy - mean(dy) - xhat*mean(dy*xhat)),
  *             dgamma = sum dy*xhat, dbeta = sum dy.  Only z is needed from the forward.
  *   z_dev, y_dev, dy_dev, dz_dev [batch][channels][hw] f32
+ *   conv_bias_dev [channels] or NULL: z is then the convolution WITHOUT its bias, the kernels
+ *             use z + bias, and the backward also returns dbias_dev = sum dz (may be NULL)
  */
-int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev, int64_t batch,
-                             int channels, int64_t hw, const float *gamma_dev, const float *beta_dev,
+int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev,
+                             const float *conv_bias_dev, int64_t batch, int channels, int64_t hw,
+                             const float *gamma_dev, const float *beta_dev,
                              double eps, double momentum, float *running_mean_dev,
                              float *running_var_dev, float *y_dev, float *mean_out_dev,
                              float *invstd_out_dev);
-int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev, const float *dy_dev,
-                             int64_t batch, int channels, int64_t hw, const float *gamma_dev,
-                             const float *mean_dev, const float *invstd_dev, float *dz_dev,
-                             float *dgamma_dev, float *dbeta_dev);
+int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev,
+                             const float *conv_bias_dev, const float *dy_dev, int64_t batch,
+                             int channels, int64_t hw, const float *gamma_dev, const float *mean_dev,
+                             const float *invstd_dev, float *dz_dev, float *dgamma_dev,
+                             float *dbeta_dev, float *dbias_dev);
 
 /* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
  * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its

@@ -174,14 +174,18 @@ def test_fused_relu_batchnorm_training_matches_autograd(gpu):
             g = torch.Generator(device="cpu").manual_seed(1)
             z = (torch.randn(shape, generator=g) * 1.5 + 0.2).to(gpu).to(dtype).requires_grad_(True)
             dy = torch.randn(shape, generator=g).to(gpu).to(dtype)
-            y = M._relu_bn(z, bn, enabled=fused)
+            cb = None
+            if shape[1] != 5:      # with the convolution bias folded in (and its gradient out)
+                cb = (torch.randn(shape[1], generator=g) * 0.5).to(gpu).to(dtype).requires_grad_(True)
+            y = M._relu_bn(z, bn, enabled=fused, conv_bias=cb)
             y.backward(dy)
             res[name] = dict(y=y.detach().double(), dz=z.grad.double(), dg=bn.weight.grad.double(),
+                             dcb=(cb.grad.double() if cb is not None else torch.zeros(1, device=gpu).double()),
                              db=bn.bias.grad.double(), rm=bn.running_mean.double(), rv=bn.running_var.double(),
                              nb=int(bn.num_batches_tracked))
         torch.cuda.synchronize()
         assert res["hip"]["nb"] == 1
-        for key in ("y", "dz", "dg", "db", "rm", "rv"):
+        for key in ("y", "dz", "dg", "db", "dcb", "rm", "rv"):
             ref = res["f64"][key]
             scale = ref.abs().max().clamp(min=1e-30)
             e_hip = ((res["hip"][key] - ref).abs().max() / scale).item()
