@@ -83,6 +83,13 @@ __device__ __forceinline__ void rbn_store_partials(double *__restrict__ part, in
   }
 }
 
+// The statistics are summed about a provisional value of the channel (shifted data): the
+// activation of its first element.  On the sparse BEV canvas most of a plane sits at exactly
+// that value, and E[r^2] - E[r]^2 would otherwise cancel.
+__device__ __forceinline__ float rbn_shift(const float *__restrict__ z, float bc, int c, const RbnGeom &g) {
+  return fmaxf(z[(int64_t)c * g.HW] + bc, 0.0f);
+}
+
 template <typename F>
 __device__ __forceinline__ void rbn_foreach(const RbnGeom &g, int c, int s, F &&f) {
   int64_t lo, hi;
@@ -103,16 +110,17 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_stats(const float *__restri
   __shared__ double s_red[kRbnThreads / 64][2];
   const int c = blockIdx.x, s = blockIdx.y;
   const float bc = bias ? bias[c] : 0.0f;
+  const float c0 = rbn_shift(z, bc, c, g);
   float sum = 0.0f, sq = 0.0f;
   rbn_foreach(g, c, s, [&](int64_t o, int n) {
     if (n == 4) {
       const float4 v = *reinterpret_cast<const float4 *>(z + o);
-      const float r0 = fmaxf(v.x + bc, 0.0f), r1 = fmaxf(v.y + bc, 0.0f), r2 = fmaxf(v.z + bc, 0.0f),
-                  r3 = fmaxf(v.w + bc, 0.0f);
+      const float r0 = fmaxf(v.x + bc, 0.0f) - c0, r1 = fmaxf(v.y + bc, 0.0f) - c0,
+                  r2 = fmaxf(v.z + bc, 0.0f) - c0, r3 = fmaxf(v.w + bc, 0.0f) - c0;
       sum += (r0 + r1) + (r2 + r3);
       sq = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, sq))));
     } else {
-      const float r = fmaxf(z[o] + bc, 0.0f);
+      const float r = fmaxf(z[o] + bc, 0.0f) - c0;
       sum += r;
       sq = fmaf(r, r, sq);
     }
@@ -134,8 +142,9 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_apply(
   double v[2];
   rbn_channel_sums<2>(part, c, g.nsplit, v, s_red);
   const double M = (double)g.B * (double)g.HW;
-  const double mean = v[0] / M;
-  double var = v[1] / M - mean * mean;  // biased: what BatchNorm normalises with
+  const double dm = v[0] / M;  // sums are about rbn_shift()
+  const double mean = (double)rbn_shift(z, bc, c, g) + dm;
+  double var = v[1] / M - dm * dm;  // biased: what BatchNorm normalises with
   var = var > 0.0 ? var : 0.0;
   const double invstd = 1.0 / sqrt(var + eps);
   const float sc = (float)((double)gamma[c] * invstd);

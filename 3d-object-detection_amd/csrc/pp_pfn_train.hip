@@ -6,7 +6,7 @@
 // of a 29.6 ms training step.  Everything the step needs is a handful of PER-CHANNEL SUMS
 // over that intermediate plus per-(b,c,p) work on the argmax element:
 //
-//   forward   batch statistics       sum r, sum r^2                     (k_pfn_train_stats)
+//   forward   batch statistics       sum (r-c0), sum (r-c0)^2, c0 = max(b,0) (k_pfn_train_stats)
 //             y = s*r + t is monotone, so out = s >= 0 ? s*max r + t : s*min r + t
 //                                                                        (pp_pfn_dense_dev)
 //   backward  dy is G[b,c,p] at the argmax element and 0 elsewhere, so
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(kTrWaves * 64) void k_pfn_train_stats(const float *
 #pragma unroll
   for (int d = 0; d < 9; ++d) A.w[d] = wb[lane * 10 + d];
   A.bias = wb[lane * 10 + 9];
+  // Most slots are zero padding, where r = max(bias, 0) exactly: the statistics are summed
+  // about that value (shifted data), or E[r^2] - E[r]^2 would cancel catastrophically for a
+  // channel whose live points barely move it.
+  const float c0 = fmaxf(A.bias, 0.0f);
   float acc[kTrStats];
 #pragma unroll
   for (int k = 0; k < kTrStats; ++k) acc[k] = 0.0f;
@@ -107,9 +111,10 @@ __global__ __launch_bounds__(kTrWaves * 64) void k_pfn_train_stats(const float *
       const float z = tr_z(A, xv);
       const float r = fmaxf(z, 0.0f);
       const float mk = z > 0.0f ? 1.0f : 0.0f;
+      const float rs = r - c0;  // exactly 0 on a zero-padded slot
       acc[0] += mk;
-      acc[1] += r;
-      acc[2] = fmaf(r, r, acc[2]);
+      acc[1] += rs;
+      acc[2] = fmaf(rs, rs, acc[2]);
 #pragma unroll
       for (int d = 0; d < 9; ++d) {
         acc[3 + d] = fmaf(mk, xv[d], acc[3 + d]);

@@ -140,8 +140,10 @@ class _PfnTrain(torch.autograd.Function):
         sums = torch.empty((21, 64), dtype=torch.float64, device=dev)
         _lib.check(_lib.lib().pp_pfn_train_stats_dev(h.handle, stream, vp(x), B, P, N, vp(wb), 64, vp(sums)),
                    "pp_pfn_train_stats_dev")
-        mean = sums[1] / M
-        var = (sums[2] / M - mean * mean).clamp_(min=0.0)        # biased, as BatchNorm normalises
+        c0 = bias.detach().double().clamp(min=0.0)               # r on a zero-padded slot; sums are about it
+        dm = sums[1] / M
+        mean = c0 + dm
+        var = (sums[2] / M - dm * dm).clamp_(min=0.0)            # biased, as BatchNorm normalises
         invstd = torch.rsqrt(var + eps)
         scale = gamma.detach().double() * invstd
         shift = beta.detach().double() - mean * scale
@@ -154,6 +156,7 @@ class _PfnTrain(torch.autograd.Function):
                 running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
                 unbiased = var * (M / max(M - 1, 1))
                 running_var.mul_(1.0 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        sums[1] += M * c0                                        # now sum r (the backward's db term)
         ctx.save_for_backward(x, table, mean.float(), invstd.float(), sums)
         ctx.M = M
         return out

@@ -119,8 +119,10 @@ int pp_pfn_dense_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int 
  * backward needs, besides the gradient at each pillar's selected element, per-channel sums that
  * do not depend on the incoming gradient -- both come from ONE pass over the dense tensor:
  *   weight_bias_dev [64][10] f32 {w[0..8], bias}
- *   sums_dev        [21][64] f64: #{z>0}, sum r, sum r^2, S1[d] = sum_{z>0} x_d (9 rows),
- *                   S2[d] = sum r*x_d (9 rows), over all batch*P*N slots
+ *   sums_dev        [21][64] f64: #{z>0}, sum (r-c0), sum (r-c0)^2 with c0 = max(bias,0) (the
+ *                   value of a zero-padded slot: shifted sums, no cancellation in the
+ *                   variance), S1[d] = sum_{z>0} x_d (9 rows), S2[d] = sum r*x_d (9 rows),
+ *                   over all batch*P*N slots
  * The forward output is then pp_pfn_dense_dev with scale/shift from the batch statistics.
  */
 int pp_pfn_train_stats_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int batch,
