@@ -78,9 +78,62 @@ __global__ __launch_bounds__(256) void k_bias_relu_bn_nhwc(const float4 *__restr
   }
 }
 
+// pillar -= data_mean (data/dataset.py:102-105): the optional per-element dataset mean of
+// the [9,P,N] tensor (pillar_means.pkl, make_means.py), the same for every sweep of the batch
+__global__ __launch_bounds__(256) void k_subtract_mean(float *__restrict__ x,
+                                                       const float *__restrict__ mean, int64_t n,
+                                                       bool vec) {
+  float *xb = x + (int64_t)blockIdx.y * n;
+  if (vec) {
+    float4 *x4 = reinterpret_cast<float4 *>(xb);
+    const float4 *m4 = reinterpret_cast<const float4 *>(mean);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      float4 v = x4[i];
+      const float4 m = m4[i];
+      v.x -= m.x;
+      v.y -= m.y;
+      v.z -= m.z;
+      v.w -= m.w;
+      x4[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+      xb[i] -= mean[i];
+  }
+}
+
 }  // namespace pp
 
 using namespace pp;
+
+extern "C" int pp_subtract_mean_dev(pp_ctx_t *ctx, void *stream_, float *pillars_dev, int batch,
+                                    int64_t elems_per_sweep, const float *mean_dev) {
+  if (!ctx || !pillars_dev || !mean_dev) {
+    set_error("pp_subtract_mean_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || batch > 65535 || elems_per_sweep < 1) {
+    set_error("pp_subtract_mean_dev: bad sizes (batch=%d elems=%lld)", batch, (long long)elems_per_sweep);
+    return PP_ERR_VALUE;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+  const bool vec = (elems_per_sweep % 4 == 0) &&
+                   (((reinterpret_cast<uintptr_t>(pillars_dev) | reinterpret_cast<uintptr_t>(mean_dev)) & 15) == 0);
+  const int64_t work = vec ? elems_per_sweep / 4 : elems_per_sweep;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((work + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_subtract_mean, dim3(gx, (unsigned)batch), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), pillars_dev, mean_dev, elems_per_sweep, vec);
+  hipError_t e = hipGetLastError();
+  if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("k_subtract_mean launch failed: %s", hipGetErrorString(e));
+    return PP_ERR_HIP;
+  }
+  return PP_OK;
+}
 
 extern "C" int pp_bias_relu_bn_nhwc_dev(pp_ctx_t *ctx, void *stream_, float *x_dev, int64_t pixels,
                                         int channels, const float *params_dev, float *y_dev,

@@ -18,14 +18,15 @@ from .voxelizer import PillarVoxelizer, VoxelConfig
 class PillarPipeline:
     def __init__(self, vox_cfg: VoxelConfig, anchor_cfg: boxes.AnchorConfig = None,
                  feature_channels=64, num_classes=9, reg_dims=8, device=None, seed=0,
-                 pos_thresh=0.6, with_targets=False):
+                 pos_thresh=0.6, with_targets=False, data_mean=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.vox_cfg = vox_cfg
         h, w = vox_cfg.canvas_height, vox_cfg.canvas_width
         if anchor_cfg is None:
             anchor_cfg = boxes.AnchorConfig(fm_height=(h + 1) // 2, fm_width=(w + 1) // 2)
         self.anchor_cfg = anchor_cfg
-        self.voxelizer = PillarVoxelizer(vox_cfg, device=self.device)
+        # data_mean: the optional pillar_means.pkl of train.py:61 / evaluate.py:207
+        self.voxelizer = PillarVoxelizer(vox_cfg, device=self.device, data_mean=data_mean)
         torch.manual_seed(seed)  # model/model.py:9
         self.model = PPModel(9, feature_channels, anchor_cfg.per_cell * num_classes,
                              anchor_cfg.per_cell * reg_dims, h, w).to(self.device)
@@ -69,6 +70,9 @@ class PillarPipeline:
         ``model.eval()`` (BatchNorm as an affine map)."""
         if self.model.training:
             raise RuntimeError("forward_fused is inference only: call model.eval() first")
+        if self.voxelizer.data_mean is not None:
+            # a data mean makes the zero-padded slots non-zero: nothing to skip, use the dense path
+            return self.forward(points, n_points)
         if self._pfn_params is None:
             self._pfn_params = self.model.feature_net.fused_params().to(self.device)
         if points.dim() == 2:

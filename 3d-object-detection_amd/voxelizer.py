@@ -65,7 +65,7 @@ class PillarVoxelizer:
     all rows).  Everything runs on ``torch.cuda.current_stream()``.
     """
 
-    def __init__(self, cfg: VoxelConfig, device=None):
+    def __init__(self, cfg: VoxelConfig, device=None, data_mean=None):
         if not torch.cuda.is_available():
             raise RuntimeError("PillarVoxelizer needs a HIP device; there is no CPU fallback")
         self.cfg = cfg
@@ -73,6 +73,21 @@ class PillarVoxelizer:
                                    else torch.device(device).index or 0)
         self._ctx = _lib.Context(self.device.index)
         self._prm = cfg.params()
+        self.data_mean = None
+        self.set_data_mean(data_mean)
+
+    def set_data_mean(self, data_mean):
+        """The optional dataset mean of the pillar tensor (pillar_means.pkl: a flat
+        9*P*N float32 tensor, data/dataset.py:102-105, make_means.py); it is subtracted from
+        every sweep's ``[9,P,N]`` output.  ``None`` switches it off."""
+        if data_mean is None:
+            self.data_mean = None
+            return
+        n = _lib.NUM_FEATURES * self.cfg.max_pillars * self.cfg.max_points_per_pillar
+        m = torch.as_tensor(data_mean, dtype=torch.float32).reshape(-1)
+        if m.numel() != n:
+            raise ValueError(f"data_mean has {m.numel()} elements, the pillar tensor {n}")
+        self.data_mean = m.to(self.device).contiguous()
 
     def reserve(self, batch, max_points):
         _lib.check(_lib.lib().pp_voxelize_reserve(self._ctx.handle, int(batch), int(max_points),
@@ -108,6 +123,7 @@ class PillarVoxelizer:
         ``pfn_params`` is the [64,12] tensor of ``PPFeatureNet.fused_params()``."""
         points, B, ncap, n_arr = self._prep(points, n_points)
         P = self.cfg.max_pillars
+        self._no_mean("pfn")
         if (pfn_params.shape != (64, 12) or pfn_params.dtype != torch.float32
                 or pfn_params.device != self.device or not pfn_params.is_contiguous()):
             raise ValueError("pfn_params must be a contiguous float32 [64,12] tensor on " + str(self.device))
@@ -137,6 +153,7 @@ class PillarVoxelizer:
         memory [B,H,W,64]) that MIOpen's NHWC convolutions consume directly."""
         points, B, ncap, n_arr = self._prep(points, n_points)
         P = self.cfg.max_pillars
+        self._no_mean("pfn_canvas")
         H, W = int(canvas_hw[0]), int(canvas_hw[1])
         if (pfn_params.shape != (64, 12) or pfn_params.dtype != torch.float32
                 or pfn_params.device != self.device or not pfn_params.is_contiguous()):
@@ -166,6 +183,11 @@ class PillarVoxelizer:
             return canvas, indices, counts
         return canvas, indices
 
+    def _no_mean(self, what):
+        if self.data_mean is not None:
+            raise RuntimeError(f"{what}: the fused feature net skips the zero-padded slots, which a data_mean "
+                               "makes non-zero; use the dense path (voxelizer(points) + PPFeatureNet)")
+
     def __call__(self, points, n_points=None, out=None, return_counts=False):
         cfg = self.cfg
         points, B, ncap, n_arr = self._prep(points, n_points)
@@ -188,6 +210,11 @@ class PillarVoxelizer:
             ctypes.c_void_p(indices.data_ptr()),
             ctypes.c_void_p(counts.data_ptr()) if counts is not None else None)
         _lib.check(rc, "pp_voxelize_dev")
+        if self.data_mean is not None:       # dataset.py:102-105
+            rc = _lib.lib().pp_subtract_mean_dev(
+                self._ctx.handle, ctypes.c_void_p(stream), ctypes.c_void_p(pillars.data_ptr()), B,
+                _lib.NUM_FEATURES * P * N, ctypes.c_void_p(self.data_mean.data_ptr()))
+            _lib.check(rc, "pp_subtract_mean_dev")
         if return_counts:
             return pillars, indices, counts
         return pillars, indices

@@ -85,6 +85,15 @@ int pp_voxelize_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                     int64_t *indices_dev, int32_t *num_cells_dev);
 
 /*
+ * The optional last step of the voxel stage (data/dataset.py:102-105): pillar -= data_mean,
+ * the per-element dataset mean of the [9,P,N] tensor (pillar_means.pkl), f32 - f32 like the
+ * reference, the same mean for every sweep.
+ *   pillars_dev [batch][elems_per_sweep] f32 in place; mean_dev [elems_per_sweep] f32
+ */
+int pp_subtract_mean_dev(pp_ctx_t *ctx, void *stream, float *pillars_dev, int batch,
+                         int64_t elems_per_sweep, const float *mean_dev);
+
+/*
  * Device-resident voxelizer with the feature net fused in (inference only;
  * SURVEY 8f rank 1): replaces the voxel stage above AND PPFeatureNet.forward
  * (model/model.py:31-40: conv1x1 9->64, ReLU, then BatchNorm2d in eval mode,

@@ -178,9 +178,9 @@ def make_ious(a_corners, g_corners, a_centers, g_centers, ious):
 
 def dataset_voxel_stage(lidar_points, max_pillars, max_points, x_step, y_step,
                         x_min, y_min, z_min, x_max, y_max, z_max, canvas_height,
-                        order=ORDER_ROW_MAJOR):
-    """np.zeros + create_pillars + transpose + f32 cast, exactly the work of
-    data/dataset.py:89-106 (minus the optional data_mean).  Returns
+                        order=ORDER_ROW_MAJOR, data_mean=None):
+    """np.zeros + create_pillars + transpose + f32 cast (+ the optional data_mean), exactly
+    the work of data/dataset.py:89-106.  Returns
     (pillar[9,P,N] float32, indices[P,3] int64, num_cells)."""
     pillar = np.zeros((max_pillars, max_points, 9))          # dataset.py:89
     indices = np.zeros((max_pillars, 3))                     # dataset.py:90
@@ -189,6 +189,9 @@ def dataset_voxel_stage(lidar_points, max_pillars, max_points, x_step, y_step,
                        canvas_height, order)                 # dataset.py:92-97
     pillar = pillar.transpose([2, 0, 1])                     # dataset.py:99
     pillar = np.ascontiguousarray(pillar, dtype=np.float32)  # dataset.py:101 (.float())
+    if data_mean is not None:                                # dataset.py:102-105, f32 - f32
+        shape = pillar.shape
+        pillar = (pillar.reshape(-1) - np.asarray(data_mean, np.float32).reshape(-1)).reshape(shape)
     indices = indices.astype(np.int64)                       # dataset.py:106 (.long())
     return pillar, indices, m
 

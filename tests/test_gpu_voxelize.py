@@ -265,3 +265,32 @@ def test_soak_alternating_inputs_same_context(gpu):
             if it % 50 < 6:
                 assert torch.equal(out, ref[key][1]) and torch.equal(idx, ref[key][2])
     torch.cuda.synchronize()
+
+
+def test_data_mean_subtraction(gpu, oracle):
+    """dataset.py:102-105: the optional per-element dataset mean (pillar_means.pkl) is
+    subtracted from every sweep's [9,P,N] tensor, f32 - f32: bit-identical to the oracle's voxel
+    stage with the same mean; odd element counts (scalar path); the fused modes refuse it."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    for half, step, P, N in ((20.0, 0.2, 9000, 32), (10.0, 0.5, 333, 7)):
+        rng = np.random.default_rng(3)
+        mean = rng.normal(0, 2.0, 9 * P * N).astype(np.float32)
+        cfg = VoxelConfig.square(half, step, P, N)
+        vox = PillarVoxelizer(cfg, device=gpu, data_mean=mean)
+        clouds = np.stack([synth.lidar_like(15000, half, s) for s in (0, 1)])
+        pil, idx = vox(torch.from_numpy(clouds).to(gpu))
+        torch.cuda.synchronize()
+        for b in range(2):
+            ref_p, ref_i, _ = oracle.dataset_voxel_stage(clouds[b].astype(np.float64), P, N,
+                                                         *grid_args(half, step), data_mean=mean)
+            assert np.array_equal(idx[b].cpu().numpy(), ref_i)
+            assert np.array_equal(pil[b].cpu().numpy(), ref_p)
+        with pytest.raises(RuntimeError):
+            vox.pfn(torch.from_numpy(clouds).to(gpu), torch.zeros(64, 12, device=gpu))
+        vox.set_data_mean(None)
+        pil0, _ = vox(torch.from_numpy(clouds).to(gpu))
+        assert torch.equal(pil0 - torch.from_numpy(mean).to(gpu).view(1, 9, P, N), pil)
+    with pytest.raises(ValueError):
+        PillarVoxelizer(cfg, device=gpu, data_mean=np.zeros(5, np.float32))
