@@ -75,6 +75,35 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def pybind_module_path():
+    """Where build_pybind_module() puts the reference-style extension module ``pillars``."""
+    import sysconfig
+    return os.path.join(_HERE, "native", "pillars" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind_module(force=False, verbose=False):
+    """Compile csrc/pillars_module.cpp (the reference's pybind11 module surface,
+    data/pillars.cpp:429-435, on the C ABI) with g++ and link it against libpp_hip.so."""
+    import pybind11
+    import sysconfig
+    src = os.path.join(_HERE, "csrc", "pillars_module.cpp")
+    out = pybind_module_path()
+    build()
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_ROOT, "include", "pp_hip.h")))
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+           "-I" + os.path.join(_ROOT, "include"), src, "-o", out + ".tmp",
+           "-L" + _HERE, "-lpp_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 _lib = None
 _lock = threading.Lock()
 

@@ -20,6 +20,7 @@ def _native_built():
     import pp_amd
     if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) or shutil.which("hipcc"):
         pp_amd._lib.build()
+        pp_amd._lib.build_pybind_module()
     from oracle import oracle as O
     O.build()
 

@@ -90,3 +90,35 @@ def test_argument_validation_surface():
                           np.zeros((4, 2)))
     assert pillars.create_pillars.__doc__.startswith("pillars") and pillars.make_ious.__doc__.startswith("ious")
     assert pillars.__doc__.startswith("point pillars data prep functions")   # pillars.cpp:431-433
+
+
+def test_pybind11_module_surface_and_loud_failure_without_gpu():
+    """The reference's own kind of binding: an extension module named `pillars` exporting
+    exactly make_ious / create_pillars with the reference's doc strings
+    (data/pillars.cpp:429-435), built from csrc/pillars_module.cpp on the C ABI.  Without a
+    HIP device a call must fail loudly (no CPU fallback); argument checks come first."""
+    import importlib.util
+    import numpy as np
+    import torch
+    import pp_amd
+    path = pp_amd._lib.build_pybind_module()
+    spec = importlib.util.spec_from_file_location("pillars", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.__doc__ == "point pillars data prep functions"
+    assert sorted(n for n in dir(mod) if not n.startswith("_")) == ["create_pillars", "make_ious"]
+    assert mod.create_pillars.__doc__.strip().endswith("pillars")
+    assert mod.make_ious.__doc__.strip().endswith("ious")
+    T, I = np.zeros((2, 2, 9)), np.zeros((2, 3))
+    with pytest.raises(TypeError):      # f32 output: the reference would lose the writes
+        mod.create_pillars(np.zeros((3, 4)), T.astype(np.float32), I, 2, 2, 1., 1., 0., 0., 0., 4., 4., 4., 4)
+    with pytest.raises(IndexError):     # wrong rank, pybind11's index_error
+        mod.create_pillars(np.zeros((3, 4)), np.zeros((2, 9)), I, 2, 2, 1., 1., 0., 0., 0., 4., 4., 4., 4)
+    with pytest.raises(TypeError):      # missing positional arguments
+        mod.create_pillars(np.zeros((3, 4)), T, I)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            mod.create_pillars(np.zeros((3, 4)), T, I, 2, 2, 1., 1., 0., 0., 0., 4., 4., 4., 4)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            mod.make_ious(np.zeros((1, 4, 2)), np.zeros((1, 4, 2)), np.zeros((1, 3)), np.zeros((1, 3)),
+                          np.zeros((1, 1)))

@@ -8,6 +8,24 @@ from util import grid_args
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["ctypes", "pybind11"])
+def pillars(request):
+    """Both host bindings of the two-function module surface: the ctypes mirror
+    (pp_amd.pillars) and the pybind11 extension module `pillars` built from
+    csrc/pillars_module.cpp -- the reference's own kind of module (pillars.cpp:429-435)."""
+    if request.param == "ctypes":
+        from pp_amd import pillars as mod
+        return mod
+    import importlib.util
+    import pp_amd
+    path = pp_amd._lib.build_pybind_module()
+    spec = importlib.util.spec_from_file_location("pillars", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.__doc__ == "point pillars data prep functions"
+    return mod
+
+
 def _v1_points():
     # SURVEY 8c V1: cell (1,2) x5 points, cell (0,0) x2 points, 3 boundary rejects
     return np.array([[1.1, 2.1, 0.0, 10], [0.5, 0.5, 0, 1], [1.2, 2.2, 0.1, 11], [1.3, 2.3, 0.2, 12],
@@ -15,8 +33,7 @@ def _v1_points():
                      [0.25, 0.75, 0.5, 2], [1.8, 2.8, 0.4, 14]])
 
 
-def test_v1_hand_case_bit_exact(gpu, oracle):
-    from pp_amd import pillars
+def test_v1_hand_case_bit_exact(gpu, oracle, pillars):
     pts = _v1_points()
     T, I = np.zeros((4, 3, 9)), np.zeros((4, 3))
     assert pillars.create_pillars(pts, T, I, 3, 4, 1, 1, 0, 0, -1, 4, 4, 1, 4) is None
@@ -28,11 +45,10 @@ def test_v1_hand_case_bit_exact(gpu, oracle):
     assert list(I[0]) == [1, 1, 1] and list(I[1]) == [1, 0, 3]
 
 
-def test_f64_points_strided_prefilled(gpu, oracle):
+def test_f64_points_strided_prefilled(gpu, oracle, pillars):
     """f64 (not f32-representable) coordinates, F-order strided view like
     data/dataset.py:88, outputs pre-filled with a sentinel stay untouched where
     the reference would not write, Python ints / numpy ints as scalars."""
-    from pp_amd import pillars
     rng = np.random.default_rng(3)
     agg = rng.uniform(-12, 12, (4, 30000))          # [4, n] like agg_pc
     agg[2] = rng.uniform(-3, 3, 30000)
@@ -49,8 +65,8 @@ def test_f64_points_strided_prefilled(gpu, oracle):
     assert (T == 7.5).any() and (I[m:] == -3.0).all()
 
 
-def test_non_contiguous_outputs_and_f32_input(gpu, oracle):
-    from pp_amd import pillars, synth
+def test_non_contiguous_outputs_and_f32_input(gpu, oracle, pillars):
+    from pp_amd import synth
     pts32 = synth.lidar_like(5000, 8.0, 2)          # f32 input is force-cast (harmless)
     P, N = 4000, 8
     big = np.zeros((P, N, 18))
@@ -64,8 +80,7 @@ def test_non_contiguous_outputs_and_f32_input(gpu, oracle):
     assert not big[:, :, 1::2].any() and not Ibig[:, 1::2].any()
 
 
-def test_errors_match_reference_surface(gpu, oracle):
-    from pp_amd import pillars
+def test_errors_match_reference_surface(gpu, oracle, pillars):
     pts = _v1_points()
     # non-f64 outputs are rejected loudly (the reference silently loses the writes)
     with pytest.raises(TypeError):
@@ -86,8 +101,8 @@ def test_errors_match_reference_surface(gpu, oracle):
         pillars.create_pillars(pts, np.zeros((4, 3, 9)), np.zeros((4, 3)), 3, 4, 0.0, 1, 0, 0, -1, 4, 4, 1, 4)
 
 
-def test_max_pillars_and_max_points_caps(gpu, oracle):
-    from pp_amd import pillars, synth
+def test_max_pillars_and_max_points_caps(gpu, oracle, pillars):
+    from pp_amd import synth
     pts = synth.lidar_like(20000, 10.0, 9).astype(np.float64)
     for P, N in ((50, 3), (0, 5), (5, 0), (100000, 1000)):
         shape_p = max(P, 1) if P < 100000 else 12000
@@ -98,8 +113,8 @@ def test_max_pillars_and_max_points_caps(gpu, oracle):
         assert np.array_equal(T, Tr) and np.array_equal(I, Ir), (P, N)
 
 
-def test_make_ious_host_dropin(gpu, oracle):
-    from pp_amd import boxes, pillars, synth
+def test_make_ious_host_dropin(gpu, oracle, pillars):
+    from pp_amd import boxes, synth
     anchors = boxes.make_anchors(boxes.AnchorConfig(60, 60))
     gt = synth.gt_boxes(12, 120, seed=4, margin=15.0)
     c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 120)
