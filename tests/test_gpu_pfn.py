@@ -282,3 +282,44 @@ def test_feature_net_kernels_odd_slot_counts(gpu):
                                               f2.bn1.weight.grad, f2.bn1.bias.grad, f2.bn1.running_var)]
         for a, b in zip(out["hip"], out["f64"]):
             assert (a - b).abs().max().item() <= 2e-4 * max(1e-6, b.abs().max().item()), (N, P)
+
+
+def test_fused_canvas_and_dense_feature_net_in_a_hip_graph(gpu):
+    """pp_voxelize_pfn_canvas_dev (memset + four kernels) and pp_voxelize_dev + pp_pfn_dense_dev
+    allocate and synchronise nothing once warm: both sequences capture into one HIP graph
+    and replay on new inputs with the eager results."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    P, N = 3000, 16
+    vox = PillarVoxelizer(VoxelConfig.square(12.0, 0.2, P, N), device=gpu)
+    H = W = vox.cfg.canvas_height
+    fn = _net(gpu)
+    params = fn.fused_params()
+    clouds = [torch.from_numpy(synth.lidar_like(9000, 12.0, s)[None]).to(gpu) for s in (40, 41)]
+    static_in = clouds[0].clone()
+    canvas = torch.empty((1, 64, H, W), device=gpu).contiguous(memory_format=torch.channels_last)
+    idx = torch.empty((1, P, 3), dtype=torch.int64, device=gpu)
+    dense = (torch.empty((1, 9, P, N), device=gpu), torch.empty((1, P, 3), dtype=torch.int64, device=gpu))
+
+    def step():
+        vox.pfn_canvas(static_in, params, (H, W), out=(canvas, idx))
+        vox(static_in, out=dense)
+        with torch.no_grad():
+            return fn(dense[0])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        feats = step()
+    for c in (clouds[1], clouds[0], clouds[1]):
+        static_in.copy_(c)
+        g.replay()
+        torch.cuda.synchronize()
+        want_canvas, _ = vox.pfn_canvas(c, params, (H, W))
+        want_feats, _ = vox.pfn(c, params)
+        assert torch.equal(canvas, want_canvas)
+        assert torch.equal(feats, want_feats)
