@@ -8,6 +8,7 @@ from pp_amd.pipeline import PillarPipeline
 from pp_amd.voxelizer import VoxelConfig
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 torch.backends.cudnn.benchmark = True
+torch.backends.cudnn.deterministic = bool(int(os.environ.get("PP_DETERMINISTIC", "0")))
 pipe = PillarPipeline(VoxelConfig.square(50.0, 0.2, 12000, 100), seed=0)
 pipe.model.eval()
 pts = torch.from_numpy(np.stack([synth.lidar_like(60000, 50.0, s) for s in range(B)])).cuda()
