@@ -103,9 +103,79 @@ __global__ __launch_bounds__(256) void k_subtract_mean(float *__restrict__ x,
   }
 }
 
+// PPScatter.forward (model/model.py:53-62) on the feature net's output: out[b,:,row,col] =
+// x[b,:,p] for the flagged pillars.  One wave moves a 64-channel x 64-pillar tile: coalesced
+// 256-byte row reads of x[b][c][p0..p0+63], an LDS transpose, and for a channels-last canvas one
+// 256-byte pixel per pillar (64 lanes = 64 channels); NCHW canvases get 4-byte scattered stores.
+__global__ __launch_bounds__(256) void k_scatter_canvas(const float *__restrict__ x,
+                                                        const long long *__restrict__ idx,
+                                                        float *__restrict__ canvas, int C, int P,
+                                                        int H, int W, int nhwc) {
+  __shared__ float s_t[4][64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z;
+  const int p0 = (blockIdx.x * 4 + wave) * 64;
+  const int c0 = blockIdx.y * 64;
+  if (p0 >= P) return;  // whole wave; no workgroup barrier below
+  float(*t)[65] = s_t[wave];
+  const int np = min(64, P - p0), nc = min(64, C - c0);
+  for (int c = 0; c < nc; ++c)
+    t[c][lane] = (lane < np) ? x[((int64_t)b * C + c0 + c) * P + p0 + lane] : 0.0f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int q = 0; q < np; ++q) {
+    const long long *io = idx + ((int64_t)b * P + p0 + q) * 3;
+    const long long flag = io[0], col = io[1], row = io[2];  // {1, canvas_x, canvas_y}, pillars.cpp:390-392
+    if (flag == 0 || row < 0 || row >= H || col < 0 || col >= W) continue;  // wave-uniform
+    if (lane < nc) {
+      const float v = t[lane][q];
+      if (nhwc)
+        canvas[(((int64_t)b * H + row) * W + col) * C + c0 + lane] = v;
+      else
+        canvas[(((int64_t)b * C + c0 + lane) * H + row) * W + col] = v;
+    }
+  }
+}
+
 }  // namespace pp
 
 using namespace pp;
+
+extern "C" int pp_scatter_canvas_dev(pp_ctx_t *ctx, void *stream_, const float *features_dev,
+                                     const int64_t *indices_dev, int batch, int channels,
+                                     int max_pillars, float *canvas_dev, int canvas_h, int canvas_w,
+                                     int channels_last) {
+  if (!ctx || !features_dev || !indices_dev || !canvas_dev) {
+    set_error("pp_scatter_canvas_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || batch > 65535 || channels < 1 || channels > 65535 * 64 || max_pillars < 1 ||
+      canvas_h < 1 || canvas_w < 1) {
+    set_error("pp_scatter_canvas_dev: bad sizes (batch=%d channels=%d P=%d canvas %dx%d)", batch,
+              channels, max_pillars, canvas_h, canvas_w);
+    return PP_ERR_VALUE;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  int rc = PP_OK;
+  hipError_t e = hipMemsetAsync(canvas_dev, 0,
+                                (size_t)batch * channels * canvas_h * canvas_w * sizeof(float), st);
+  if (e == hipSuccess) {
+    const dim3 grid((unsigned)((max_pillars + 255) / 256), (unsigned)((channels + 63) / 64), (unsigned)batch);
+    hipLaunchKernelGGL(k_scatter_canvas, grid, dim3(256), 0, st, features_dev,
+                       reinterpret_cast<const long long *>(indices_dev), canvas_dev, channels, max_pillars,
+                       canvas_h, canvas_w, channels_last ? 1 : 0);
+    e = hipGetLastError();
+  }
+  if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("pp_scatter_canvas_dev failed: %s", hipGetErrorString(e));
+    rc = PP_ERR_HIP;
+  }
+  return rc;
+}
 
 extern "C" int pp_subtract_mean_dev(pp_ctx_t *ctx, void *stream_, float *pillars_dev, int batch,
                                     int64_t elems_per_sweep, const float *mean_dev) {

@@ -346,6 +346,18 @@ class PPScatter(nn.Module):
         hw = self.h * self.w
         lin = inds[:, :, 2] * self.w + inds[:, :, 1]
         if (not self.training) and self.channels_last_inference and x.is_cuda and not torch.is_grad_enabled():
+            if x.dtype == torch.float32 and inds.dtype == torch.int64:
+                # one memset + one HIP kernel (64x64 tile transpose, a 256-byte pixel per pillar)
+                x = x if x.is_contiguous() else x.contiguous()
+                inds = inds if inds.is_contiguous() else inds.contiguous()
+                out = torch.empty((B, C, self.h, self.w), dtype=torch.float32, device=x.device,
+                                  memory_format=torch.channels_last)
+                rc = _lib.lib().pp_scatter_canvas_dev(
+                    _hip_ctx(x.device).handle, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream),
+                    ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(inds.data_ptr()), B, C, P,
+                    ctypes.c_void_p(out.data_ptr()), self.h, self.w, 1)
+                _lib.check(rc, "pp_scatter_canvas_dev")
+                return out
             base = torch.arange(B, device=x.device, dtype=lin.dtype).unsqueeze(1) * hw
             lin = torch.where(inds[:, :, 0] != 0, lin + base, torch.full_like(lin, B * hw))
             flat = x.new_zeros((B * hw + 1, C))

@@ -123,6 +123,17 @@ int pp_pfn_dense_dev(pp_ctx_t *ctx, void *stream, const float *pillars_dev, int 
                      int channels, float *features_dev);
 
 /*
+ * PPScatter.forward (model/model.py:53-62) alone, for callers that already hold the feature
+ * net's output: canvas[b,:,row,col] = features[b,:,p] for every flagged pillar
+ * (indices[b,p] = {1, col, row}); the canvas is fully written (zeroed, then scattered).
+ *   features_dev [batch][channels][P] f32, indices_dev [batch][P][3] int64
+ *   canvas_dev   [batch][channels][H][W] f32, or [batch][H][W][channels] with channels_last
+ */
+int pp_scatter_canvas_dev(pp_ctx_t *ctx, void *stream, const float *features_dev,
+                          const int64_t *indices_dev, int batch, int channels, int max_pillars,
+                          float *canvas_dev, int canvas_h, int canvas_w, int channels_last);
+
+/*
  * PPFeatureNet in TRAINING mode (BatchNorm with batch statistics) without the [64,P,N]
  * intermediate.  The forward needs the per-channel batch statistics of r = ReLU(conv(x)); the
  * backward needs, besides the gradient at each pillar's selected element, per-channel sums that

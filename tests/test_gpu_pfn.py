@@ -132,11 +132,22 @@ def test_fused_scatter_canvas_equals_ppscatter(gpu):
     assert torch.equal(buf, want)
     with pytest.raises(Exception):
         vox.pfn_canvas(pts, fn.fused_params(), (H - 1, W), n_points=n_points)
-    # the channels-last PPScatter of the inference path gives the same canvas, as a view
+    # PPScatter's own inference path (pp_scatter_canvas_dev) gives the same canvas, channels last
     sc2 = M.PPScatter(H, W).eval()
     with torch.no_grad():
         got = sc2(feats, idx)
+        got24 = sc2(feats[:, :24].contiguous(), idx)          # a channel count that is not 64
     assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    assert torch.equal(got24, want[:, :24])
+    # ... and through the C ABI into an NCHW canvas
+    import ctypes
+    from pp_amd import _lib
+    nchw = torch.full((3, 64, H, W), 5.0, device=gpu)
+    rc = _lib.lib().pp_scatter_canvas_dev(M._hip_ctx(gpu).handle, None, ctypes.c_void_p(feats.data_ptr()),
+                                          ctypes.c_void_p(idx.data_ptr()), 3, 64, P, ctypes.c_void_p(nchw.data_ptr()),
+                                          H, W, 0)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(nchw, want)
 
 
 def test_fused_scatter_pipeline_equals_dense_pipeline(gpu):
