@@ -122,3 +122,45 @@ def test_pybind11_module_surface_and_loud_failure_without_gpu():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             mod.make_ious(np.zeros((1, 4, 2)), np.zeros((1, 4, 2)), np.zeros((1, 3)), np.zeros((1, 3)),
                           np.zeros((1, 1)))
+
+
+def test_device_entry_points_reject_null_and_bad_sizes_without_touching_a_device():
+    """Every device entry point validates its arguments before any HIP call: with a NULL context
+    or NULL tensors it returns PP_ERR_VALUE and leaves a message (runs on a CPU-only box)."""
+    from pp_amd import _lib
+    L = _lib.lib()
+    V = _lib.PP_ERR_VALUE
+    prm = _lib.make_voxel_params(4, 8, 1, 1, 0, 0, 0, 4, 4, 4, 4, 0)
+    tp = _lib.TargetParams(0.6, 4.0, 9, 0)
+    calls = {
+        "pp_voxelize_dev": lambda: L.pp_voxelize_dev(None, None, None, 0, None, 1, ctypes.byref(prm), None, None, None),
+        "pp_voxelize_pfn_dev": lambda: L.pp_voxelize_pfn_dev(None, None, None, 0, None, 1, ctypes.byref(prm), None, 64,
+                                                              None, None, None),
+        "pp_voxelize_pfn_canvas_dev": lambda: L.pp_voxelize_pfn_canvas_dev(None, None, None, 0, None, 1,
+                                                                            ctypes.byref(prm), None, 64, None, 4, 4, 1,
+                                                                            None, None),
+        "pp_subtract_mean_dev": lambda: L.pp_subtract_mean_dev(None, None, None, 1, 16, None),
+        "pp_pfn_dense_dev": lambda: L.pp_pfn_dense_dev(None, None, None, 1, 8, 4, None, 64, None),
+        "pp_scatter_canvas_dev": lambda: L.pp_scatter_canvas_dev(None, None, None, None, 1, 64, 8, None, 4, 4, 1),
+        "pp_pfn_train_stats_dev": lambda: L.pp_pfn_train_stats_dev(None, None, None, 1, 8, 4, None, 64, None),
+        "pp_pfn_train_backward_dev": lambda: L.pp_pfn_train_backward_dev(None, None, None, 1, 8, 4, None, None, None,
+                                                                          None, 64, None),
+        "pp_assign_targets_dev": lambda: L.pp_assign_targets_dev(None, None, 10, None, None, None, None, 0, None, None,
+                                                                  None, None, None, None, ctypes.byref(tp), None, None),
+        "pp_assign_targets_grid_dev": lambda: L.pp_assign_targets_grid_dev(None, None, 2, 2, 0.5, 2, None, 0, None, None,
+                                                                            None, None, None, None, ctypes.byref(tp),
+                                                                            None, None),
+        "pp_make_ious_dev": lambda: L.pp_make_ious_dev(None, None, None, None, 3, 4, None, None, 3, 2, None),
+        "pp_ingest_dev": lambda: L.pp_ingest_dev(None, None, None, 4, 5, None, 1.0, None),
+        "pp_bias_relu_bn_dev": lambda: L.pp_bias_relu_bn_dev(None, None, None, 1, 4, 16, None, None, 4, 0),
+        "pp_bias_relu_bn_nhwc_dev": lambda: L.pp_bias_relu_bn_nhwc_dev(None, None, None, 16, 4, None, None, 4, 0),
+        "pp_relu_bn_train_fwd_dev": lambda: L.pp_relu_bn_train_fwd_dev(None, None, None, None, 1, 4, 16, None, None,
+                                                                        1e-5, 0.1, None, None, None, None, None),
+        "pp_relu_bn_train_bwd_dev": lambda: L.pp_relu_bn_train_bwd_dev(None, None, None, None, None, 1, 4, 16, None,
+                                                                        None, None, None, None, None, None),
+        "pp_ctx_set_timing": lambda: L.pp_ctx_set_timing(None, 4),
+    }
+    for name, call in calls.items():
+        rc = call()
+        assert rc == V, (name, rc)
+        assert L.pp_last_error(), name
