@@ -59,6 +59,36 @@ def reduce_loss_scalars(ctx, cls_loss, reg_loss, ort_loss, total, n_local, devic
     return buf[:4] / buf[4].clamp_min(1.0)
 
 
+def allreduce_gradients(ctx, parameters, bucket_bytes=32 << 20):
+    """Average the gradients over all ranks: what the reference's ``nn.DataParallel`` does
+    implicitly (train.py:88-89: one loss over the gathered batch, gradients reduced onto GPU 0).
+    The gradients are packed into flat buckets (one all-reduce per ``bucket_bytes``; the whole
+    network is 19 MB of f32, i.e. ONE ring all-reduce over xGMI), summed and divided by the
+    world size.  Every rank ends with identical gradients, so identical optimizer steps keep the
+    replicas in sync without ever broadcasting weights."""
+    if not ctx.distributed:
+        return 0
+    grads = [p.grad for p in parameters if p.grad is not None]
+    n_calls, i = 0, 0
+    while i < len(grads):
+        bucket, size = [], 0
+        while i < len(grads) and (not bucket or size + grads[i].numel() * grads[i].element_size() <= bucket_bytes):
+            if bucket and grads[i].dtype != bucket[0].dtype:
+                break
+            bucket.append(grads[i])
+            size += grads[i].numel() * grads[i].element_size()
+            i += 1
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(ctx.world_size)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        n_calls += 1
+    return n_calls
+
+
 def max_over_ranks(ctx, seconds, device=None):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     if ctx.distributed:

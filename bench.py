@@ -145,6 +145,7 @@ def main():
             return pipe.forward(points)
         pipe.model.zero_grad(set_to_none=True)
         losses = pipe.train_forward_backward(points, gts)
+        shard.allreduce_gradients(ctx, pipe.model.parameters())     # DataParallel's gradient reduction
         return shard.reduce_loss_scalars(ctx, *losses, n_local=a.batch, device=dev)
 
     for _ in range(a.warmup):

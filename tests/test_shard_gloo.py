@@ -28,8 +28,16 @@ def _worker(rank, world, port, q):
     vals = [float(sum(mine)) + k for k in range(4)]
     red = shard.reduce_loss_scalars(ctx, *vals, n_local=len(mine))
     tmax = shard.max_over_ranks(ctx, 1.0 + rank)
+    # gradient averaging (the DataParallel semantics of train.py:88-89): two buckets
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    x = torch.full((4, 6), float(rank + 1))
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    calls = shard.allreduce_gradients(ctx, net.parameters(), bucket_bytes=100)
     shard.barrier(ctx)
-    q.put((rank, mine, red.tolist(), tmax))
+    q.put((rank, mine, red.tolist(), tmax, [g.tolist() for g in local],
+           [p.grad.tolist() for p in net.parameters()], calls))
     shard.shutdown(ctx)
 
 
@@ -50,6 +58,12 @@ def test_two_rank_shard_and_reduce():
     for r in res:
         assert torch.allclose(torch.tensor(r[2]), torch.tensor(exp), atol=1e-6)
         assert r[3] == 2.0
+    # every rank holds the mean of the two local gradients, in every bucket
+    assert res[0][6] >= 2 and res[0][6] == res[1][6]
+    for k in range(len(res[0][4])):
+        mean = (torch.tensor(res[0][4][k]) + torch.tensor(res[1][4][k])) / 2
+        for r in res:
+            assert torch.allclose(torch.tensor(r[5][k]), mean, atol=1e-6)
 
 
 def test_single_process_is_world_one(monkeypatch):
