@@ -165,7 +165,7 @@ def lib():
         L.pp_bias_relu_bn_nhwc_dev.argtypes = [vp, vp, vp, i64, c_int, vp, vp, i64, i64]
         dbl = ctypes.c_double
         L.pp_relu_bn_train_fwd_dev.argtypes = [vp, vp, vp, vp, i64, c_int, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp]
-        L.pp_relu_bn_train_bwd_dev.argtypes = [vp, vp, vp, vp, vp, i64, c_int, i64, vp, vp, vp, vp, vp, vp, vp]
+        L.pp_relu_bn_train_bwd_dev.argtypes = [vp, vp, vp, vp, vp, i64, i64, c_int, i64, vp, vp, vp, vp, vp, vp, vp]
         L.pp_ctx_set_timing.argtypes = [vp, c_int]
         L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
                                           ctypes.POINTER(c_int)]

@@ -30,6 +30,7 @@ constexpr int kRbnMaxSplit = 64;
 struct RbnGeom {
   int B, C, nsplit;
   int64_t HW;
+  int64_t dy_extra;  // dy only: (batch stride of dy) - C*HW, for a channel slice of a wider tensor
   bool vec;  // HW % 4 == 0 and 16-byte aligned tensors: float4 accesses
 };
 
@@ -90,16 +91,18 @@ __device__ __forceinline__ float rbn_shift(const float *__restrict__ z, float bc
   return fmaxf(z[(int64_t)c * g.HW] + bc, 0.0f);
 }
 
+// f(offset in z / y / dz, offset in dy, elements)
 template <typename F>
 __device__ __forceinline__ void rbn_foreach(const RbnGeom &g, int c, int s, F &&f) {
   int64_t lo, hi;
   rbn_range(g, s, lo, hi);
   for (int b = 0; b < g.B; ++b) {
     const int64_t base = ((int64_t)b * g.C + c) * g.HW;
+    const int64_t dbase = base + (int64_t)b * g.dy_extra;
     if (g.vec) {
-      for (int64_t i = lo + (int64_t)threadIdx.x * 4; i < hi; i += kRbnThreads * 4) f(base + i, 4);
+      for (int64_t i = lo + (int64_t)threadIdx.x * 4; i < hi; i += kRbnThreads * 4) f(base + i, dbase + i, 4);
     } else {
-      for (int64_t i = lo + threadIdx.x; i < hi; i += kRbnThreads) f(base + i, 1);
+      for (int64_t i = lo + threadIdx.x; i < hi; i += kRbnThreads) f(base + i, dbase + i, 1);
     }
   }
 }
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_stats(const float *__restri
   const float bc = bias ? bias[c] : 0.0f;
   const float c0 = rbn_shift(z, bc, c, g);
   float sum = 0.0f, sq = 0.0f;
-  rbn_foreach(g, c, s, [&](int64_t o, int n) {
+  rbn_foreach(g, c, s, [&](int64_t o, int64_t od, int n) {
     if (n == 4) {
       const float4 v = *reinterpret_cast<const float4 *>(z + o);
       const float r0 = fmaxf(v.x + bc, 0.0f) - c0, r1 = fmaxf(v.y + bc, 0.0f) - c0,
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_apply(
       running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
   }
-  rbn_foreach(g, c, s, [&](int64_t o, int n) {
+  rbn_foreach(g, c, s, [&](int64_t o, int64_t od, int n) {
     if (n == 4) {
       float4 q = *reinterpret_cast<const float4 *>(z + o);
       q.x = fmaf(fmaxf(q.x + bc, 0.0f), sc, sh);
@@ -195,16 +198,16 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_bwd_stats(const float *__re
     mc += m;
     mx = fmaf(m, xh, mx);
   };
-  rbn_foreach(g, c, s, [&](int64_t o, int n) {
+  rbn_foreach(g, c, s, [&](int64_t o, int64_t od, int n) {
     if (n == 4) {
       const float4 v = *reinterpret_cast<const float4 *>(z + o);
-      const float4 d = *reinterpret_cast<const float4 *>(dy + o);
+      const float4 d = *reinterpret_cast<const float4 *>(dy + od);
       one(v.x, d.x);
       one(v.y, d.y);
       one(v.z, d.z);
       one(v.w, d.w);
     } else {
-      one(z[o], dy[o]);
+      one(z[o], dy[od]);
     }
   });
   double v[5] = {sd, sdx, md, mc, mx};
@@ -236,13 +239,13 @@ __global__ __launch_bounds__(kRbnThreads) void k_rbn_bwd_apply(
     const float xh = (fmaxf(zv, 0.0f) - mu) * is;
     return zv > 0.0f ? sc * (d - k1 - xh * k2) : 0.0f;
   };
-  rbn_foreach(g, c, s, [&](int64_t o, int n) {
+  rbn_foreach(g, c, s, [&](int64_t o, int64_t od, int n) {
     if (n == 4) {
       const float4 q = *reinterpret_cast<const float4 *>(z + o);
-      const float4 d = *reinterpret_cast<const float4 *>(dy + o);
+      const float4 d = *reinterpret_cast<const float4 *>(dy + od);
       *reinterpret_cast<float4 *>(dz + o) = make_float4(one(q.x, d.x), one(q.y, d.y), one(q.z, d.z), one(q.w, d.w));
     } else {
-      dz[o] = one(z[o], dy[o]);
+      dz[o] = one(z[o], dy[od]);
     }
   });
 }
@@ -270,6 +273,7 @@ static int rbn_setup(const char *who, pp_ctx_t *ctx, int64_t batch, int channels
   g->B = (int)batch;
   g->C = channels;
   g->HW = hw;
+  g->dy_extra = 0;
   g->vec = aligned && (hw % 4 == 0);
   // >= 2048 workgroups over the chip, a slice no smaller than one pass of the workgroup
   int ns = (2048 + channels - 1) / channels;
@@ -323,8 +327,9 @@ extern "C" int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream_, const floa
 }
 
 extern "C" int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream_, const float *z_dev,
-                                        const float *conv_bias_dev, const float *dy_dev, int64_t batch,
-                                        int channels, int64_t hw, const float *gamma_dev,
+                                        const float *conv_bias_dev, const float *dy_dev,
+                                        int64_t dy_batch_stride, int64_t batch, int channels,
+                                        int64_t hw, const float *gamma_dev,
                                         const float *mean_dev, const float *invstd_dev, float *dz_dev,
                                         float *dgamma_dev, float *dbeta_dev, float *dbias_dev) {
   RbnGeom g;
@@ -336,6 +341,13 @@ extern "C" int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream_, const floa
   int rc = rbn_setup("pp_relu_bn_train_bwd_dev", ctx, batch, channels, hw, {z_dev, dy_dev, dz_dev}, &g,
                      &part);
   if (rc) return rc;
+  if (dy_batch_stride == 0) dy_batch_stride = (int64_t)channels * hw;
+  if (dy_batch_stride < (int64_t)channels * hw) {
+    set_error("pp_relu_bn_train_bwd_dev: dy_batch_stride %lld < channels*hw", (long long)dy_batch_stride);
+    return PP_ERR_VALUE;
+  }
+  g.dy_extra = dy_batch_stride - (int64_t)channels * hw;
+  if (g.dy_extra % 4 != 0) g.vec = false;  // float4 alignment of the later batches of dy
   RbnDevice guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const dim3 grid((unsigned)channels, (unsigned)g.nsplit);

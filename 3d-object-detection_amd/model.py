@@ -212,14 +212,17 @@ class _ReluBnTrain(torch.autograd.Function):
         B, C, H, W = z.shape
         dev = z.device
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        dy = dy.contiguous()
+        # a channel slice of a wider NCHW tensor (torch.cat's gradient) is read in place
+        if not (dy.dtype == torch.float32 and dy.stride(3) == 1 and dy.stride(2) == W and dy.stride(1) == H * W
+                and (B == 1 or dy.stride(0) >= C * H * W)):
+            dy = dy.contiguous().float()
         dz = torch.empty_like(z)
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
         dbias = torch.empty((C,), dtype=torch.float32, device=dev) if conv_bias is not None else None
         rc = _lib.lib().pp_relu_bn_train_bwd_dev(
             _hip_ctx(dev).handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), vp(z),
-            vp(conv_bias), vp(dy), B, C, H * W, vp(gamma), vp(mean), vp(invstd), vp(dz), vp(dgamma), vp(dbeta),
+            vp(conv_bias), vp(dy), dy.stride(0) if B > 1 else 0, B, C, H * W, vp(gamma), vp(mean), vp(invstd), vp(dz), vp(dgamma), vp(dbeta),
             vp(dbias))
         _lib.check(rc, "pp_relu_bn_train_bwd_dev")
         return dz, dbias, dgamma, dbeta, None, None, None, None

@@ -350,6 +350,8 @@ int pp_bias_relu_bn_nhwc_dev(pp_ctx_t *ctx, void *stream, float *x_dev, int64_t 
  *   backward  dz = [z > 0] * gamma*invstd * (dy - mean(dy) - xhat*mean(dy*xhat)),
  *             dgamma = sum dy*xhat, dbeta = sum dy.  Only z is needed from the forward.
  *   z_dev, y_dev, dy_dev, dz_dev [batch][channels][hw] f32
+ *   dy_batch_stride (floats; 0 = channels*hw): dy may be a channel slice of a wider NCHW
+ *             tensor (the gradient of one input of torch.cat), read in place
  *   conv_bias_dev [channels] or NULL: z is then the convolution WITHOUT its bias, the kernels
  *             use z + bias, and the backward also returns dbias_dev = sum dz (may be NULL)
  */
@@ -360,8 +362,9 @@ int pp_relu_bn_train_fwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev,
                              float *running_var_dev, float *y_dev, float *mean_out_dev,
                              float *invstd_out_dev);
 int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev,
-                             const float *conv_bias_dev, const float *dy_dev, int64_t batch,
-                             int channels, int64_t hw, const float *gamma_dev, const float *mean_dev,
+                             const float *conv_bias_dev, const float *dy_dev, int64_t dy_batch_stride,
+                             int64_t batch, int channels, int64_t hw, const float *gamma_dev,
+                             const float *mean_dev,
                              const float *invstd_dev, float *dz_dev, float *dgamma_dev,
                              float *dbeta_dev, float *dbias_dev);
 

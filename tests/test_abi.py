@@ -156,7 +156,7 @@ def test_device_entry_points_reject_null_and_bad_sizes_without_touching_a_device
         "pp_bias_relu_bn_nhwc_dev": lambda: L.pp_bias_relu_bn_nhwc_dev(None, None, None, 16, 4, None, None, 4, 0),
         "pp_relu_bn_train_fwd_dev": lambda: L.pp_relu_bn_train_fwd_dev(None, None, None, None, 1, 4, 16, None, None,
                                                                         1e-5, 0.1, None, None, None, None, None),
-        "pp_relu_bn_train_bwd_dev": lambda: L.pp_relu_bn_train_bwd_dev(None, None, None, None, None, 1, 4, 16, None,
+        "pp_relu_bn_train_bwd_dev": lambda: L.pp_relu_bn_train_bwd_dev(None, None, None, None, None, 0, 1, 4, 16, None,
                                                                         None, None, None, None, None, None),
         "pp_ctx_set_timing": lambda: L.pp_ctx_set_timing(None, 4),
     }
