@@ -66,8 +66,62 @@ def test_random_configuration(gpu, oracle, case):
         fn.bn1.running_mean.normal_(0, 0.3)
         fn.bn1.running_var.uniform_(0.5, 1.5)
         fn.bn1.weight.normal_(0, 1.0)
-        ref = fn(pil)
+        dense_hip = fn(pil)                 # pp_pfn_dense_dev (MFMA kernel when N % 4 == 0)
+        fn.hip_eval = False
+        ref = fn(pil)                       # PyTorch-ROCm
     feats, idx2 = vox.pfn(t, fn.fused_params())
+    H = W = cfg.canvas_height
+    canvas, idx3 = vox.pfn_canvas(t, fn.fused_params(), (H, W))
     torch.cuda.synchronize()
-    assert torch.equal(idx, idx2)
+    assert torch.equal(idx, idx2) and torch.equal(idx, idx3)
     assert (feats - ref).abs().max().item() <= 1e-4
+    assert torch.equal(dense_hip, feats)    # same fmaf chain in both kernels
+    sc = M.PPScatter(H, W)
+    sc.channels_last_inference = False
+    assert torch.equal(canvas, sc(feats, idx))
+
+
+@pytest.mark.parametrize("case", list(range(10)))
+def test_random_target_assignment(gpu, oracle, case):
+    """Random anchor grids (1-3 anchor types per cell, random sizes / yaws) and ground-truth sets
+    (0-30 boxes, some duplicated, some far outside): anchors on the fly AND uploaded arrays
+    against the oracle's create_target -- classes / flags exact, regression rows within 1e-6."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    rng = np.random.default_rng(7000 + case)
+    fm = int(rng.integers(20, 70))
+    per_cell = int(rng.integers(1, 4))
+    dims = tuple(tuple(float(v) for v in (rng.uniform(4, 14), rng.uniform(8, 30), rng.uniform(1, 3)))
+                 for _ in range(per_cell))
+    yaws = tuple(float(rng.choice([0.0, 90.0, 30.0])) for _ in range(per_cell))
+    zs = tuple(float(rng.uniform(0.3, 1.2)) for _ in range(per_cell))
+    acfg = boxes.AnchorConfig(fm, fm, 0.5, dims, yaws, zs)
+    H = 2 * fm
+    anchors = boxes.make_anchors(acfg)
+    G = int(rng.integers(0, 31))
+    gt = {"centers": np.column_stack([rng.uniform(-10, H + 10, G), rng.uniform(-10, H + 10, G), rng.uniform(0, 2, G)]),
+          "wlh": np.column_stack([rng.uniform(4, 14, G), rng.uniform(8, 30, G), rng.uniform(1, 3, G)]),
+          "yaw": rng.uniform(-np.pi, np.pi, G), "classes": rng.integers(0, 9, G).astype(np.int32)}
+    if G >= 4:          # exact duplicates: ties in the column argmax, several classes on one anchor
+        for k in ("centers", "wlh", "yaw"):
+            gt[k][1] = gt[k][0]
+        # a box that sits exactly on an anchor: IoU 1 with it
+        d = int(rng.integers(0, per_cell))
+        i = int(rng.integers(0, fm * fm)) * per_cell + d
+        gt["centers"][2] = anchors["centers"][i]
+        gt["wlh"][2] = anchors["wlh"][i]
+        gt["yaw"][2] = anchors["yaw"][i]
+    c_img, k_img = oracle.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
+    ref_c, ref_r, _ = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                           anchors["yaw"], gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], H,
+                                           pos_thresh=0.6)
+    for src in (acfg, anchors):
+        ta = TargetAssigner(src, canvas_height=H, device=gpu)
+        cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+        torch.cuda.synchronize()
+        cls_t, reg_t = cls_t.cpu().numpy(), reg_t.cpu().numpy()
+        assert np.array_equal(cls_t, ref_c.astype(np.float32)), (fm, per_cell, G)
+        assert np.array_equal(reg_t[:, 0], ref_r[:, 0].astype(np.float32))
+        assert np.array_equal(reg_t[:, 8], ref_r[:, 8].astype(np.float32))
+        assert np.abs(reg_t - ref_r.astype(np.float32)).max() <= 1e-6
