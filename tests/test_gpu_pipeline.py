@@ -223,3 +223,45 @@ def test_training_steps_reduce_the_loss(gpu):
     assert totals[-1] < 0.8 * totals[0], totals
     assert not torch.equal(rv0, pipe.model.backbone.down1.block[2].running_var)
     assert int(pipe.model.feature_net.bn1.num_batches_tracked) == 12
+
+
+def test_inference_chain_raw_rows_to_boxes(gpu, oracle):
+    """The whole device-resident inference chain of INTEGRATION.md section 3: raw .bin rows ->
+    pp_ingest_dev -> fused voxelizer / feature net / scatter -> backbone + head (channels last)
+    -> pp_decode_strided_dev on the channel slices.  The fused + strided chain must give exactly
+    the boxes of the dense, copy-based chain fed to the oracle's post-processing."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.ingest import LidarIngest
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.postprocess import Detector
+    from pp_amd.voxelizer import VoxelConfig
+    half, step = 16.0, 0.2
+    cfg = VoxelConfig.square(half, step, 4000, 32)
+    pipe = PillarPipeline(cfg, device=gpu, seed=3)
+    pipe.model.eval()
+    with torch.no_grad():      # make some anchors fire
+        pipe.model.det_head.cls.bias.fill_(-1.0)
+    acfg = pipe.anchor_cfg
+    anchors = boxes.make_anchors(acfg)
+    H = cfg.canvas_height
+    det = Detector(anchors, acfg, H, step, step, -half, -half, pos_thresh=0.3, nms_thresh=0.1, device=gpu)
+    raw = np.concatenate([synth.lidar_like(9000, half, 5), np.zeros((9000, 1), np.float32)], 1)   # 5 columns
+    pose = np.eye(4)
+    pose[:3, 3] = [0.5, -0.25, 0.1]
+    pts = LidarIngest(device=gpu)([(raw, pose), (raw[:3000] * np.float32(0.5), np.eye(4))]).unsqueeze(0)
+    cls_f, reg_f = pipe.forward_fused(pts)
+    assert cls_f.stride(1) == 1                                   # channel slices of the merged head
+    b_f, k_f, n_f = det(cls_f[0], reg_f[0])                       # read in place
+    pipe.fused_scatter = False
+    pipe.model.scatter.channels_last_inference = False
+    cls_d, reg_d = pipe.forward(pts)                              # dense tensor, NCHW throughout
+    torch.cuda.synchronize()
+    assert (cls_f - cls_d).abs().max().item() <= 1e-4 * max(1.0, cls_d.abs().max().item())
+    ref_b, ref_k = oracle.postprocess(cls_f[0].contiguous().cpu().numpy(), reg_f[0].contiguous().cpu().numpy(),
+                                      anchors["centers"], anchors["wlh"], anchors["yaw"], anchors["xy"], H,
+                                      step, step, -half, -half, pos_thresh=0.3, nms_thresh=0.1)
+    n = int(n_f.item())
+    assert n == len(ref_k) and n > 0
+    assert np.array_equal(k_f.cpu().numpy()[:n], ref_k.astype(np.int32))
+    assert np.allclose(b_f.cpu().numpy()[:n], ref_b, rtol=1e-5, atol=1e-5)
