@@ -119,20 +119,36 @@ __global__ __launch_bounds__(256) void k_scatter_canvas(const float *__restrict_
   if (p0 >= P) return;  // whole wave; no workgroup barrier below
   float(*t)[65] = s_t[wave];
   const int np = min(64, P - p0), nc = min(64, C - c0);
-  for (int c = 0; c < nc; ++c)
-    t[c][lane] = (lane < np) ? x[((int64_t)b * C + c0 + c) * P + p0 + lane] : 0.0f;
+  // 16 row loads in flight at a time (one after the other they are a 64-step latency chain)
+  const float *xr = x + ((int64_t)b * C + c0) * P + p0 + lane;
+#pragma unroll 1
+  for (int cb = 0; cb < nc; cb += 16) {
+    float rr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rr[k] = (cb + k < nc && lane < np) ? xr[(int64_t)(cb + k) * P] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (cb + k < nc) t[cb + k][lane] = rr[k];
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (int q = 0; q < np; ++q) {
-    const long long *io = idx + ((int64_t)b * P + p0 + q) * 3;
+  // every lane resolves ONE pillar's pixel (three 8-byte loads, all 64 in flight together:
+  // read one after the other they were a 64-step latency chain, 50 us per launch)
+  int64_t pix = -1;
+  if (lane < np) {
+    const long long *io = idx + ((int64_t)b * P + p0 + lane) * 3;
     const long long flag = io[0], col = io[1], row = io[2];  // {1, canvas_x, canvas_y}, pillars.cpp:390-392
-    if (flag == 0 || row < 0 || row >= H || col < 0 || col >= W) continue;  // wave-uniform
+    if (flag != 0 && row >= 0 && row < H && col >= 0 && col < W) pix = row * W + col;
+  }
+  for (int q = 0; q < np; ++q) {
+    const int64_t pq = __shfl(pix, q, 64);  // wave-uniform
+    if (pq < 0) continue;
     if (lane < nc) {
       const float v = t[lane][q];
       if (nhwc)
-        canvas[(((int64_t)b * H + row) * W + col) * C + c0 + lane] = v;
+        canvas[((int64_t)b * H * W + pq) * C + c0 + lane] = v;
       else
-        canvas[(((int64_t)b * C + c0 + lane) * H + row) * W + col] = v;
+        canvas[((int64_t)b * C + c0 + lane) * H * W + pq] = v;
     }
   }
 }
