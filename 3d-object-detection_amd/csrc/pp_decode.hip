@@ -104,75 +104,10 @@ __device__ __forceinline__ bool suppresses(const NmsBox &i, const NmsBox &j, flo
   return ovr > thresh;
 }
 
-__global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
-  __shared__ NmsBox s_kept[kMaxOut];
-  __shared__ NmsBox s_chunk[kNmsThreads];
-  __shared__ u64 s_mask[kNmsThreads][kNmsThreads / 64];  // s_mask[i]: later chunk members i suppresses
-  __shared__ int s_alive[kNmsThreads];
-  __shared__ int s_id[kNmsThreads];
-  __shared__ int s_nkept, s_done;
-  const int t = threadIdx.x;
-  if (t == 0) {
-    s_nkept = 0;
-    s_done = 0;
-  }
-  for (int i = t; i < d.max_out; i += kNmsThreads) d.kept[i] = -1;
-  __syncthreads();
-  for (int c0 = 0; c0 < d.A; c0 += kNmsThreads) {
-    const int nk = s_nkept;
-    const u64 key = (c0 + t < d.A) ? d.keys[c0 + t] : kSentinel;
-    const bool valid = key != kSentinel;
-    const int a = (int)(key & 0xFFFFFull);
-    NmsBox b = {0, 0, 0, 0, 0};
-    int alive = 0;
-    if (valid) {
-      b = load_box(d, a);
-      alive = 1;
-      for (int k = 0; k < nk && alive; ++k)
-        if (suppresses(s_kept[k], b, d.nms_thresh)) alive = 0;
-    }
-    s_chunk[t] = b;
-    s_alive[t] = alive;
-    s_id[t] = a;
-    __syncthreads();
-    // suppression matrix inside the chunk: bit j of s_mask[t] = (j > t and t suppresses j)
-    {
-      u64 m[kNmsThreads / 64] = {0, 0, 0, 0};
-      if (alive) {
-        for (int j = t + 1; j < kNmsThreads; ++j)
-          if (s_alive[j] && suppresses(b, s_chunk[j], d.nms_thresh)) m[j >> 6] |= 1ull << (j & 63);
-      }
-#pragma unroll
-      for (int w = 0; w < kNmsThreads / 64; ++w) s_mask[t][w] = m[w];
-    }
-    __syncthreads();
-    if (t == 0) {
-      u64 removed[kNmsThreads / 64] = {0, 0, 0, 0};
-      int n = s_nkept;
-      for (int i = 0; i < kNmsThreads && n < d.max_out; ++i) {
-        if (!s_alive[i] || ((removed[i >> 6] >> (i & 63)) & 1ull)) continue;
-        s_kept[n] = s_chunk[i];
-        d.kept[n] = s_id[i];
-        ++n;
-#pragma unroll
-        for (int w = 0; w < kNmsThreads / 64; ++w) removed[w] |= s_mask[i][w];
-      }
-      s_nkept = n;
-      // sorted keys: the first sentinel ends the candidates
-      s_done = (n >= d.max_out) ? 1 : 0;
-    }
-    __syncthreads();
-    if (s_done || !__syncthreads_or(valid && t == kNmsThreads - 1)) break;
-  }
-  if (t == 0) *d.count = s_nkept;
-}
-
-// make_pred_boxes (evaluate.py:33-89) + move_box_to_car_space (:91-125, image=True)
-__global__ void k_decode(DecodeArgs d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.max_out) return;
+// make_pred_boxes (evaluate.py:33-89) + move_box_to_car_space (:91-125, image=True) for output
+// row i; a = kept anchor id or -1
+__device__ void decode_row(const DecodeArgs &d, int i, int a) {
   double *o = d.boxes + (int64_t)i * 9;
-  const int a = d.kept[i];
   if (a < 0) {
     for (int k = 0; k < 9; ++k) o[k] = 0.0;
     return;
@@ -206,6 +141,90 @@ __global__ void k_decode(DecodeArgs d) {
   o[6] = yaw;
   o[7] = (double)score;
   o[8] = (double)klass;
+}
+
+__global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
+  __shared__ NmsBox s_kept[kMaxOut];
+  __shared__ NmsBox s_chunk[kNmsThreads];
+  __shared__ u64 s_mask[kNmsThreads][kNmsThreads / 64];  // s_mask[i]: later chunk members i suppresses
+  __shared__ int s_alive[kNmsThreads];
+  __shared__ u64 s_alive_mask[kNmsThreads / 64];  // the same as wave ballots, for the serial pass
+  __shared__ int s_id[kNmsThreads];
+  __shared__ int s_keptid[kMaxOut];
+  __shared__ int s_nkept, s_done;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    s_nkept = 0;
+    s_done = 0;
+  }
+  for (int i = t; i < d.max_out; i += kNmsThreads) s_keptid[i] = -1;
+  __syncthreads();
+  for (int c0 = 0; c0 < d.A; c0 += kNmsThreads) {
+    const int nk = s_nkept;
+    const u64 key = (c0 + t < d.A) ? d.keys[c0 + t] : kSentinel;
+    const bool valid = key != kSentinel;
+    const int a = (int)(key & 0xFFFFFull);
+    NmsBox b = {0, 0, 0, 0, 0};
+    int alive = 0;
+    if (valid) {
+      b = load_box(d, a);
+      alive = 1;
+      for (int k = 0; k < nk && alive; ++k)
+        if (suppresses(s_kept[k], b, d.nms_thresh)) alive = 0;
+    }
+    s_chunk[t] = b;
+    s_alive[t] = alive;
+    s_id[t] = a;
+    {
+      const u64 bal = __ballot(alive != 0);
+      if ((t & 63) == 0) s_alive_mask[t >> 6] = bal;
+    }
+    __syncthreads();
+    // suppression matrix inside the chunk: bit j of s_mask[t] = (j > t and t suppresses j)
+    {
+      u64 m[kNmsThreads / 64] = {0, 0, 0, 0};
+      if (alive) {
+        for (int j = t + 1; j < kNmsThreads; ++j)
+          if (s_alive[j] && suppresses(b, s_chunk[j], d.nms_thresh)) m[j >> 6] |= 1ull << (j & 63);
+      }
+#pragma unroll
+      for (int w = 0; w < kNmsThreads / 64; ++w) s_mask[t][w] = m[w];
+    }
+    __syncthreads();
+    if (t == 0) {
+      // greedy pass in score order over the ALIVE members only (ballot words, lowest bit first)
+      u64 removed[kNmsThreads / 64] = {0, 0, 0, 0};
+      int n = s_nkept;
+#pragma unroll
+      for (int w0 = 0; w0 < kNmsThreads / 64; ++w0) {
+        u64 pend = s_alive_mask[w0];
+        while (pend && n < d.max_out) {
+          const int bpos = __builtin_ctzll(pend);
+          pend &= pend - 1;
+          if ((removed[w0] >> bpos) & 1ull) continue;
+          const int i = w0 * 64 + bpos;
+          s_kept[n] = s_chunk[i];
+          s_keptid[n] = s_id[i];
+          ++n;
+#pragma unroll
+          for (int w = 0; w < kNmsThreads / 64; ++w) removed[w] |= s_mask[i][w];
+        }
+      }
+      s_nkept = n;
+      // sorted keys: the first sentinel ends the candidates
+      s_done = (n >= d.max_out) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_done || !__syncthreads_or(valid && t == kNmsThreads - 1)) break;
+  }
+  __syncthreads();
+  if (t == 0) *d.count = s_nkept;
+  // the kept list and the decoded boxes (one thread per output row)
+  for (int i = t; i < d.max_out; i += kNmsThreads) {
+    const int a = s_keptid[i];
+    d.kept[i] = a;
+    decode_row(d, i, a);
+  }
 }
 
 }  // namespace pp
@@ -285,8 +304,7 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
     return PP_ERR_HIP;
   }
   d.keys = sorted;
-  hipLaunchKernelGGL(k_nms, dim3(1), dim3(kNmsThreads), 0, stream, d);
-  hipLaunchKernelGGL(k_decode, dim3((unsigned)((d.max_out + 127) / 128)), dim3(128), 0, stream, d);
+  hipLaunchKernelGGL(k_nms, dim3(1), dim3(kNmsThreads), 0, stream, d);  // + box decode
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
