@@ -5,19 +5,21 @@
 // backward 180 us on a 64 MB activation) + a ReLU-backward kernel, and keeps both the conv
 // output and the ReLU output for the backward.  Here:
 //
-// z may be the convolution WITHOUT its bias: the kernels add the per-channel bias b on the fly
-// (one elementwise kernel less forward) and the backward returns db = sum dz from three extra
-// per-channel sums of its first pass (one reduction kernel less per layer).
-//
-//   forward   pass 1  per-channel sum / sum of squares of r = max(z + b, 0)  (k_rbn_stats)
+//   forward   pass 1  per-channel sum / sum of squares of r = max(z + b, 0), taken about the
+//                     channel's first activation (shifted data: no cancellation)  (k_rbn_stats)
 //             pass 2  y = s*r + t with s = gamma*invstd, t = beta - mean*s; the first slice
 //                     of every channel also updates the running statistics   (k_rbn_apply)
-//   backward  pass 1  dbeta = sum dy, dgamma = sum dy*xhat                  (k_rbn_bwd_stats)
+//   backward  pass 1  dbeta = sum dy, dgamma = sum dy*xhat (+ three sums for db)  (k_rbn_bwd_stats)
 //             pass 2  dz = [z > 0] * s * (dy - dbeta/M - xhat*dgamma/M)     (k_rbn_bwd_apply)
 //
+// z may be the convolution WITHOUT its bias: the kernels add the per-channel bias b on the fly
+// (one elementwise kernel less forward) and the backward returns db = sum dz from three extra
+// per-channel sums of its first pass (one reduction kernel less per layer).  dy may be a
+// channel slice of a wider NCHW tensor (torch.cat's gradient), read in place.
+//
 // Only z is kept for the backward.  Grid = (channels, slices): a workgroup owns one slice of
-// one channel's planes; partial sums go to a [C][slices][2] f64 scratch, and the apply kernels
-// reduce their channel's row themselves (no extra launch, no atomics, deterministic).
+// one channel's planes; partial sums go to a [C][slices][2 or 5] f64 scratch, and the apply
+// kernels reduce their channel's row themselves (no extra launch, no atomics, deterministic).
 // HBM-bound: 12 B (forward) + 20 B (backward) per element.
 
 #include "pp_common.h"
