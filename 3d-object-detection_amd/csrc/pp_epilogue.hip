@@ -1,4 +1,7 @@
-// pp_epilogue.hip -- fused conv epilogue for the inference backbone.
+// pp_epilogue.hip -- the elementwise / data-movement kernels around the network (inference):
+//   k_bias_relu_bn[_nhwc]  the backbone's Conv2d -> ReLU -> BatchNorm2d tail in one pass
+//   k_subtract_mean        pillar -= data_mean (data/dataset.py:102-105)
+//   k_scatter_canvas       PPScatter.forward (model/model.py:53-62)
 //
 // Every block of the reference backbone is Conv2d -> ReLU -> BatchNorm2d
 // (/root/reference model/model.py:76-84, 105-109).  In eval mode PyTorch-ROCm runs
