@@ -47,7 +47,9 @@ struct GridGeom {
   double x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max, canvas_height;
   int nx, ny;         // columns / rows of the cell grid
   int ncells;         // nx * ny
-  int ncells_pad;     // rounded up to the scan tile
+  int tile_shift;     // a tile = 1 << tile_shift consecutive slots (64..1024)
+  int ntiles;         // ceil(ncells / tile slots) <= 4096
+  int tile_bits;      // bits of a tile id
   int order;          // PP_ORDER_*
   unsigned long long mult, mult_inv;  // scrambled order: slot = cell*mult % ncells
 };
@@ -61,6 +63,17 @@ struct pp_ctx {
   // voxelizer scratch, laid out by VoxWorkspace (pp_voxelize.hip)
   pp::DevBuf vox_ws;
   unsigned long long vox_layout_key[6] = {0, 0, 0, 0, 0, 0};
+  unsigned scan_spin_limit = 1u << 22;  // polls of one status word before k_tile gives up
+  // per k_tile instance [f64 input][4/8/16 waves][ticket, no ticket]: dynamic-LDS attribute set
+  // so far; the no-ticket instances also cache their resident capacity for that LDS size
+  struct TileKernelInfo {
+    size_t lds_armed = 0, capacity_lds = 0;
+    long long capacity = 0;
+  } tile_info[2][3][2];
+  size_t split_lds_armed[2] = {0, 0};
+  int force_tile_waves = 0;  // development knobs: PP_TILE_WAVES / PP_FORCE_TICKET in the environment
+  int force_ticket = 0;
+  size_t dbg_stamps_off = 0, dbg_stamps_bytes = 0;  // PP_STAMPS builds (tools/lab)
   // host drop-in staging
   pp::DevBuf stage_in, stage_out, stage_out2;
   pp::PinBuf pin_in, pin_out, pin_meta;

@@ -3,6 +3,7 @@
 
 #include "pp_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace pp {
@@ -110,6 +111,11 @@ extern "C" int pp_ctx_create(int device, pp_ctx_t **out) {
   pp_ctx *c = new (std::nothrow) pp_ctx();
   if (!c) return PP_ERR_NOMEM;
   c->device = device;
+  if (const char *e = getenv("PP_TILE_WAVES")) {  // development knobs, see pp_common.h
+    const int v = atoi(e);
+    if (v == 4 || v == 8 || v == 16) c->force_tile_waves = v;
+  }
+  if (const char *e = getenv("PP_FORCE_TICKET")) c->force_ticket = atoi(e) != 0;
   *out = c;
   return PP_OK;
 }

@@ -4,25 +4,27 @@
 // device-resident path, the caller glue around it (data/dataset.py:88-106):
 // np.zeros + create_pillars + transpose to [9,P,N] + f64->f32 + indices->int64.
 //
-// Pipeline (one launch each, grid.y = sweep of the batch):
-//   k_bin_count  point -> cell slot (f64 true division + floor, half-open range
-//                test: pillars.cpp:271-280); ONE returning atomic per point gives
-//                the per-cell population and the point's arrival rank
-//   k_scan       single-pass decoupled-look-back scan over the cell grid:
-//                pillar index of every non-empty cell (P-index compaction) and
-//                CSR offset of its bucket, written in place of the counts
-//   k_fill       atomic-free CSR fill: point record + point index go to
-//                bucket start + arrival rank
-//   k_emit       one wave per 4 consecutive pillars: coalesced bucket read,
-//                LDS-staged, input order restored, sequential running mean
-//                (pillars.cpp:311-328), N-cap, 9 features (pillars.cpp:30-31,
-//                48-56,381-383), dense [9,P,N] f32 store incl. the zero padding,
-//                [P,3] int64 indices
+// Pipeline (three launches, grid.y = sweep of the batch; no global atomics on
+// the data path -- the cell grid only ever exists in LDS):
+//   k_split  1024 points per workgroup: point -> cell slot (f64 true division +
+//            floor, half-open range test: pillars.cpp:271-280), then a STABLE
+//            workgroup-local multisplit by tile (a tile = 64..1024 consecutive
+//            slots): wave ballots find each point's peers, per-wave byte
+//            histograms in LDS give its position.  Writes the chunk's points
+//            grouped by tile plus one {offset,count} entry per (tile, chunk).
+//   k_tile   one wave per tile: walks the tile's runs chunk by chunk (= input
+//            order), LDS histogram over the tile's cells, wave prefix sums,
+//            one decoupled look-back per 16 tiles for the pillar index
+//            (P-index compaction) and the CSR offset; second walk places every
+//            point at bucket start + rank, rank from ballots -> buckets hold
+//            their points in INPUT order (pillars.cpp:98 push_back order).
+//   k_emit   one wave per 4 consecutive pillars: coalesced bucket read,
+//            LDS-staged, sequential running mean (pillars.cpp:311-328), N-cap,
+//            9 features (pillars.cpp:30-31,48-56,381-383), dense [9,P,N] f32
+//            store incl. the zero padding, [P,3] int64 indices
 //
 // The path is HBM-bound: 97% of the bytes are the dense store of
-// k_emit.  Every 128-byte line of the output is written once, whole: lines
-// without live points are zero-filled before the bucket data arrives, lines
-// with live points are written (data + zero tail) after it.
+// k_emit.  Every 128-byte line of the output is written once, whole.
 // All arithmetic that decides a value is f64 with contraction disabled
 // (-ffp-contract=off), matching the reference's x86-64 build.
 
@@ -41,9 +43,12 @@ namespace pp {
 // constants                                                                  //
 // ------------------------------------------------------------------------- //
 constexpr int kWave = 64;
-constexpr int kBinThreads = 256;
-constexpr int kScanThreads = 1024;
-constexpr int kScanTile = kScanThreads * 4;  // cells per scan workgroup
+constexpr int kChunk = 1024;                 // points per split workgroup, one per thread
+constexpr int kSplitThreads = kChunk;
+constexpr int kSplitWaves = kSplitThreads / kWave;
+constexpr int kMinTileSlots = 256, kMaxTileSlots = 4096;  // a tile's cells live in LDS (20 B each)
+constexpr int kTargetTiles = 256;            // tiles (= k_tile workgroups, split bins) aimed at
+constexpr int kMaxTiles = 4096;              // split bins: byte histograms [16][T] must fit LDS
 constexpr int kEmitWaves = 4;                // waves per emit workgroup
 constexpr int kEmitThreads = kEmitWaves * kWave;
 constexpr int KW = 4;      // pillars per emit wave
@@ -52,7 +57,6 @@ constexpr int KW = 4;      // pillars per emit wave
 #endif
 constexpr int CAPW = PP_CAPW;  // pooled bucket capacity (points, 4-padded per pillar) per emit wave
 constexpr int kPre = CAPW / 64;  // bucket entries prefetched per lane
-constexpr unsigned kSpinLimit = 1u << 26;
 
 using u64 = unsigned long long;
 
@@ -87,39 +91,24 @@ __device__ __forceinline__ int slot_to_cell(int slot, const GridGeom &g) {
   return (int)(((u64)slot * g.mult_inv) % (u64)g.ncells);
 }
 
+template <typename T> struct Rec4;
+template <> struct Rec4<float> { using type = float4; };
+template <> struct Rec4<double> { using type = double4; };
+
 // ------------------------------------------------------------------------- //
-// k_bin_count                                                                 //
+// k_split                                                                     //
 // ------------------------------------------------------------------------- //
 template <typename T>
-__device__ __forceinline__ void load_point(const T *pts, int64_t row, int64_t s0,
-                                           int64_t s1, bool contig, T &x, T &y,
-                                           T &z, T &r);
-
-template <>
-__device__ __forceinline__ void load_point<float>(const float *pts, int64_t row,
-                                                  int64_t s0, int64_t s1,
-                                                  bool contig, float &x, float &y,
-                                                  float &z, float &r) {
+__device__ __forceinline__ typename Rec4<T>::type load_point(const T *pts, int64_t row,
+                                                             int64_t s0, int64_t s1, bool contig) {
+  typename Rec4<T>::type v;
   if (contig) {
-    float4 v = reinterpret_cast<const float4 *>(pts)[row];  // 16 B/lane, coalesced
-    x = v.x; y = v.y; z = v.z; r = v.w;
+    v = reinterpret_cast<const typename Rec4<T>::type *>(pts)[row];  // 16/32 B per lane, coalesced
   } else {
-    const float *p = pts + row * s0;
-    x = p[0]; y = p[s1]; z = p[2 * s1]; r = p[3 * s1];
+    const T *p = pts + row * s0;
+    v.x = p[0]; v.y = p[s1]; v.z = p[2 * s1]; v.w = p[3 * s1];
   }
-}
-template <>
-__device__ __forceinline__ void load_point<double>(const double *pts, int64_t row,
-                                                   int64_t s0, int64_t s1,
-                                                   bool contig, double &x, double &y,
-                                                   double &z, double &r) {
-  if (contig) {
-    const double4 v = reinterpret_cast<const double4 *>(pts)[row];
-    x = v.x; y = v.y; z = v.z; r = v.w;
-  } else {
-    const double *p = pts + row * s0;
-    x = p[0]; y = p[s1]; z = p[2 * s1]; r = p[3 * s1];
-  }
+  return v;
 }
 
 // pillars.cpp:271-280.  Returns the cell id (row-major over ascending
@@ -136,29 +125,116 @@ __device__ __forceinline__ int point_cell(double x, double y, double z,
   return ((g.ny - 1) - iy) * g.nx + ix;
 }
 
+__device__ __forceinline__ u64 lanes_below(int lane) {
+  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// Lanes of this wave that hold the same key (the low `bits` bits), among the
+// lanes in `valid`.  One ballot per key bit.
+__device__ __forceinline__ u64 wave_peers(unsigned key, int bits, bool valid) {
+  u64 peers = __ballot(valid);
+  for (int k = 0; k < bits; ++k) {
+    const bool bit = (key >> k) & 1u;
+    const u64 bk = __ballot(bit);
+    peers &= bit ? bk : ~bk;
+  }
+  return peers;
+}
+
+__device__ __forceinline__ int shfl_up_i(int v, int d) { return __shfl_up(v, d, kWave); }
+
+// LDS of k_split: byte histograms [kSplitWaves][Tp], bin offsets u16 [Tp], wave totals.
+__host__ __device__ inline int split_tp(int ntiles) { return (ntiles + 3) & ~3; }
+__host__ __device__ inline size_t split_lds_bytes(int ntiles) {
+  const size_t Tp = (size_t)split_tp(ntiles);
+  return kSplitWaves * Tp + 2 * Tp + 4 * kSplitWaves;
+}
+
 template <typename T>
-__global__ __launch_bounds__(kBinThreads) void k_bin_count(
-    const T *__restrict__ pts, int64_t sweep_stride, int64_t s0, int64_t s1,
-    int contig, NPoints np, GridGeom g, int2 *__restrict__ cell_rank, int ncap,
-    int *__restrict__ cursor) {
+__global__ __launch_bounds__(kSplitThreads) void k_split(
+    const T *__restrict__ pts, int64_t sweep_stride, int64_t s0, int64_t s1, int contig,
+    NPoints np, GridGeom g, int ncap, int nchunks_cap, int *__restrict__ kslot,
+    typename Rec4<T>::type *__restrict__ kpts, int2 *__restrict__ mat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char split_smem[];
+  using Rec = typename Rec4<T>::type;
   const int b = blockIdx.y;
   const int n = np.n[b];
-  const int i = blockIdx.x * kBinThreads + threadIdx.x;
-  if (i >= n) return;
-  T x, y, z, r;
-  load_point<T>(pts + (int64_t)b * sweep_stride * 4, i, s0, s1, contig != 0, x, y, z, r);
-  const int cell = point_cell((double)x, (double)y, (double)z, g);
-  int slot = -1, rank = 0;
-  if (cell >= 0) {
-    slot = cell_to_slot(cell, g);
-    // the only atomic of the pipeline: population count + arrival rank in one
-    rank = atomicAdd(&cursor[(int64_t)b * g.ncells_pad + slot], 1);
+  const int chunk = blockIdx.x;
+  if (chunk * kChunk >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ntiles = g.ntiles;
+  const int Tp = split_tp(ntiles);
+  unsigned char *whist = split_smem;
+  unsigned short *binoff = reinterpret_cast<unsigned short *>(split_smem + kSplitWaves * Tp);
+  unsigned *wtot = reinterpret_cast<unsigned *>(split_smem + kSplitWaves * Tp + 2 * Tp);
+  for (int i = tid; i < kSplitWaves * Tp / 4; i += kSplitThreads)
+    reinterpret_cast<unsigned *>(whist)[i] = 0u;
+  // the point, its slot and tile
+  const int i = chunk * kChunk + tid;
+  Rec rec;
+  rec.x = rec.y = rec.z = rec.w = 0;
+  int slot = -1;
+  if (i < n) {
+    rec = load_point<T>(pts + (int64_t)b * sweep_stride * 4, i, s0, s1, contig != 0);
+    const int cell = point_cell((double)rec.x, (double)rec.y, (double)rec.z, g);
+    if (cell >= 0) slot = cell_to_slot(cell, g);
   }
-  cell_rank[(int64_t)b * ncap + i] = make_int2(slot, rank);
+  const bool valid = slot >= 0;
+  const unsigned tile = valid ? (unsigned)slot >> g.tile_shift : 0u;
+  const u64 peers = wave_peers(tile, g.tile_bits, valid);
+  const int rank_w = __popcll(peers & lanes_below(lane));
+  __syncthreads();
+  if (valid && rank_w == 0) whist[w * Tp + tile] = (unsigned char)__popcll(peers);  // <= 64
+  __syncthreads();
+  // bin totals over the 16 waves, exclusive scan over the bins (consecutive bins per thread)
+  const int nb = (ntiles + kSplitThreads - 1) / kSplitThreads;  // <= kMaxTiles / 1024 = 4
+  unsigned tot[4] = {0u, 0u, 0u, 0u};
+  unsigned mine = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int bin = tid * nb + e;
+    if (e < nb && bin < ntiles) {
+      unsigned t = 0;
+#pragma unroll
+      for (int ww = 0; ww < kSplitWaves; ++ww) t += whist[ww * Tp + bin];
+      tot[e] = t;
+      mine += t;
+    }
+  }
+  int inc = (int)mine;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int o = shfl_up_i(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == kWave - 1) wtot[w] = (unsigned)inc;
+  __syncthreads();
+  unsigned base = (unsigned)inc - mine;
+#pragma unroll
+  for (int ww = 0; ww < kSplitWaves; ++ww)
+    if (ww < w) base += wtot[ww];
+  int2 *mrow = mat + (int64_t)b * ntiles * nchunks_cap + chunk;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int bin = tid * nb + e;
+    if (e < nb && bin < ntiles) {
+      binoff[bin] = (unsigned short)base;  // < 1024
+      mrow[(int64_t)bin * nchunks_cap] = make_int2((int)base, (int)tot[e]);
+      base += tot[e];
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    unsigned pos = binoff[tile] + (unsigned)rank_w;
+    for (int ww = 0; ww < w; ++ww) pos += whist[ww * Tp + tile];
+    const int64_t dst = (int64_t)b * ncap + (int64_t)chunk * kChunk + pos;
+    kslot[dst] = slot;
+    kpts[dst] = rec;
+  }
 }
 
 // ------------------------------------------------------------------------- //
-// k_scan: decoupled look-back over the cell grid                             //
+// k_tile                                                                      //
 // ------------------------------------------------------------------------- //
 __device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
   int lo = __shfl_up((int)(v & 0xFFFFFFFFull), d, kWave);
@@ -175,130 +251,329 @@ __device__ __forceinline__ u64 wave_sum64(u64 v) {
   return v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_scan(
-    int *__restrict__ cursor, int ncells_pad, int P, int4 *__restrict__ pillar_meta,
-    u64 *status, unsigned *ticket, int2 *__restrict__ totals, int *errflag) {
+// A tile's points, in INPUT order, are the concatenation over the chunks of the
+// chunk's run for that tile.  The workgroup walks them through "windows" of kWin
+// chunks: one wave takes four {offset,count} entries per lane, prefix sums across
+// the wave, the sums staged in LDS; every position (one per thread and round) then
+// finds its run by a binary search.
+constexpr int kWin = 256;    // chunks per window
+constexpr int kCapT = 2048;  // positions per tile whose {source, cell} stay cached in LDS for pass 2
+constexpr int kP1 = 4;       // pass 1: rounds whose gathers are in flight together
+constexpr int kP2 = 3;       // pass 2: rounds fetched ahead
+constexpr unsigned kDropped = 0xFFFFFFFFu;
+
+struct TileLds {
+  unsigned *cur;          // [tile slots] population, then bucket cursor
+  unsigned *hist;         // [tile slots][WAVES bytes] per-round, per-wave point counts of a cell
+  unsigned *pre, *srcb;   // [kWin] inclusive run ends / run source minus run start
+  unsigned *csrc;         // [kCapT]
+  unsigned short *cq;     // [kCapT]
+};
+__host__ __device__ inline size_t tile_lds_bytes(int tile_slots, int waves) {
+  return ((size_t)tile_slots * (1 + waves / 4) + 2 * kWin + kCapT + kCapT / 2) * 4;
+}
+
+// Stages window `win` of the tile's row (ONE wave); returns the number of positions in it.
+__device__ __forceinline__ int tile_stage_window(const int2 *__restrict__ row, int nch, int win,
+                                                 const TileLds &L, int lane) {
+  const int c0 = win * kWin + 4 * lane;
+  int2 e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = (c0 + i < nch) ? row[c0 + i] : make_int2(0, 0);
+  const int loc = e[0].y + e[1].y + e[2].y + e[3].y;
+  int incl = loc;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int o = shfl_up_i(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const int G = __builtin_amdgcn_readlane(incl, kWave - 1);
+  int run = incl - loc;  // exclusive
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    L.srcb[4 * lane + i] = (unsigned)((c0 + i) * kChunk + e[i].x - run);
+    run += e[i].y;
+    L.pre[4 * lane + i] = (unsigned)run;
+  }
+  return G;
+}
+
+// source index (into the sweep's split arrays) of window position j < G
+__device__ __forceinline__ int tile_find(const TileLds &L, int j) {
+  int lo = 0;  // number of runs that end at or before position j (< kWin for j < G)
+#pragma unroll
+  for (int s = kWin / 2; s >= 1; s >>= 1)
+    if (L.pre[lo + s - 1] <= (unsigned)j) lo += s;
+  return (int)(L.srcb[lo] + (unsigned)j);
+}
+
+__device__ __forceinline__ unsigned byte_sum(unsigned v) { return __builtin_amdgcn_sad_u8(v, 0u, 0u); }
+
+#ifdef PP_STAMPS
+#define PP_STAMP(k)                                                                  \
+  do {                                                                               \
+    if (stamps && lane == 0)                                                          \
+      stamps[(((size_t)b * gridDim.x + blockIdx.x) * 16 + w) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define PP_STAMP(k) do {} while (0)
+#endif
+
+// One workgroup of WAVES waves per tile (1 << tile_shift consecutive slots, all of them
+// in LDS).  TICKET: tile ids are handed out by an atomic ticket, so that a workgroup only
+// ever waits for workgroups that have started; without it the tile is blockIdx.x, which
+// the launcher uses only when the whole grid is resident at once.
+template <typename T, int WAVES, bool TICKET>
+__global__ __launch_bounds__(WAVES * kWave) void k_tile(
+    NPoints np, GridGeom g, int P, int ncap, int nchunks_cap, const int *__restrict__ kslot,
+    const typename Rec4<T>::type *__restrict__ kpts, const int2 *__restrict__ mat,
+    typename Rec4<T>::type *__restrict__ sorted_pts, int4 *__restrict__ pillar_meta,
+    u64 *status, unsigned *ticket, int2 *__restrict__ totals, int *errflag,
+    unsigned spin_limit, u64 *stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned tile_smem[];
+  using Rec = typename Rec4<T>::type;
+  constexpr int THREADS = WAVES * kWave;
+  constexpr int HW = WAVES / 4;  // dwords of a cell's per-wave byte counts
   __shared__ unsigned s_ticket;
-  __shared__ u64 s_wave[kScanThreads / kWave];
+  __shared__ int s_G;
+  __shared__ u64 s_wave[WAVES];
   __shared__ u64 s_excl;
   const int b = blockIdx.y;
-  const int nwg = gridDim.x;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // Dynamic tile id: a workgroup that holds ticket t knows tickets < t have
-  // started, so the look-back below never waits on an unscheduled workgroup.
-  if (tid == 0) s_ticket = atomicAdd(&ticket[b], 1u);
-  __syncthreads();
-  const int t = (int)s_ticket;
+  const int nwg = gridDim.x;  // = g.ntiles
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  PP_STAMP(0);
+  const int TS = 1 << g.tile_shift;
+  TileLds L;
+  L.cur = tile_smem;
+  L.hist = L.cur + TS;
+  L.pre = L.hist + HW * TS;
+  L.srcb = L.pre + kWin;
+  L.csrc = L.srcb + kWin;
+  L.cq = reinterpret_cast<unsigned short *>(L.csrc + kCapT);
+  int tile = blockIdx.x;
+  if (TICKET) {
+    if (tid == 0) s_ticket = atomicAdd(&ticket[b], 1u);
+  }
+  for (int q = tid; q < (1 + HW) * TS; q += THREADS) L.cur[q] = 0u;  // cur and hist
+  if (TICKET) {
+    __syncthreads();
+    tile = (int)s_ticket;
+    if (tile >= nwg) {  // the ticket word was not armed: refuse to touch anything
+      if (tid == 0) atomicExch(errflag, 2);
+      return;
+    }
+  }
+  PP_STAMP(1);
   u64 *st = status + (int64_t)b * nwg;
-
-  int4 *cur = reinterpret_cast<int4 *>(cursor + (int64_t)b * ncells_pad) +
-              (int64_t)t * kScanThreads + tid;
-  const int4 c = *cur;
-  const u64 mine = ((u64)((unsigned)c.x + (unsigned)c.y + (unsigned)c.z + (unsigned)c.w) << 32) |
-                   (u64)((c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0));
-  // inclusive scan inside the wave
+  const int n = np.n[b];
+  const int nch = (n + kChunk - 1) / kChunk;
+  const int nwin = (nch + kWin - 1) / kWin;
+  const int2 *row = mat + ((int64_t)b * g.ntiles + tile) * nchunks_cap;
+  const int *ks = kslot + (int64_t)b * ncap;
+  const Rec *kp = kpts + (int64_t)b * ncap;
+  const unsigned qmask = (unsigned)TS - 1u;
+  // pass 1: population of the tile's cells (order-free); the first kCapT positions are cached
+  int ntile = 0;  // positions walked so far = points of the tile
+  for (int win = 0; win < nwin; ++win) {
+    __syncthreads();  // window arrays free (and cur/hist zeroed)
+    if (w == 0) {
+      const int G0 = tile_stage_window(row, nch, win, L, lane);
+      if (lane == 0) s_G = G0;
+    }
+    __syncthreads();
+    const int G = s_G;
+    for (int J = 0; J < G; J += kP1 * THREADS) {
+      int src[kP1], sl[kP1];
+#pragma unroll
+      for (int u = 0; u < kP1; ++u) {
+        const int j = J + u * THREADS + tid;
+        src[u] = (j < G) ? tile_find(L, j) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kP1; ++u) sl[u] = (src[u] >= 0) ? ks[src[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < kP1; ++u) {
+        if (src[u] >= 0) {
+          const unsigned q = (unsigned)sl[u] & qmask;
+          __hip_atomic_fetch_add(&L.cur[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int jg = ntile + J + u * THREADS + tid;
+          if (jg < kCapT) {
+            L.csrc[jg] = (unsigned)src[u];
+            L.cq[jg] = (unsigned short)q;
+          }
+        }
+      }
+    }
+    ntile += G;
+  }
+  __syncthreads();
+  PP_STAMP(2);
+  // prefix sums over the tile's cells: thread owns cpt consecutive cells
+  const int cpt = TS > THREADS ? TS / THREADS : 1;  // 1 .. 16
+  u64 mine = 0;
+  if (tid * cpt < TS)
+    for (int e = 0; e < cpt; ++e) {
+      const unsigned c = L.cur[tid * cpt + e];
+      mine += ((u64)c << 32) | (u64)(c > 0);
+    }
   u64 inc = mine;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
-    u64 o = shfl_up64(inc, d);
+    const u64 o = shfl_up64(inc, d);
     if (lane >= d) inc += o;
   }
-  if (lane == kWave - 1) s_wave[wv] = inc;
+  if (lane == kWave - 1) s_wave[w] = inc;
+  PP_STAMP(3);
   __syncthreads();
+  PP_STAMP(4);
   u64 wave_off = 0, agg = 0;
 #pragma unroll
-  for (int k = 0; k < kScanThreads / kWave; ++k) {
-    if (k < wv) wave_off += s_wave[k];
+  for (int k = 0; k < WAVES; ++k) {
+    if (k < w) wave_off += s_wave[k];
     agg += s_wave[k];
   }
-  // publish + look back (wave 0)
-  if (wv == 0) {
-    u64 excl = 0;
-    if (t == 0) {
-      if (lane == 0)
-        __hip_atomic_store(&st[0], st_pack(kFlagPre, agg), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (lane == 0)
-        __hip_atomic_store(&st[t], st_pack(kFlagAgg, agg), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      int base = t - 1;
-      bool failed = false;
-      while (true) {
-        const int j = base - lane;
-        u64 s = kFlagPre;  // virtual predecessor of tile 0: prefix 0
-        if (j >= 0) {
-          unsigned spins = 0;
-          do {
-            s = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((s >> 62) == 0 && ++spins < kSpinLimit);
-          if ((s >> 62) == 0) failed = true;
-        }
-        const u64 maskP = __ballot((s >> 62) == 2);
-        const int firstP = maskP ? (__ffsll((long long)maskP) - 1) : kWave;
-        const u64 val = (lane <= firstP) ? st_payload(s) : 0ull;
-        excl += wave_sum64(val);
-        if (maskP || __any(failed)) break;
-        base -= kWave;
+  // publish the tile's totals, sum those of ALL earlier tiles (no chain: every tile
+  // publishes as soon as its own counts are known)
+  if (w == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&st[tile], st_pack(kFlagAgg, agg), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    u64 acc = 0;
+    bool failed = false;
+    for (int j0 = lane; j0 < tile; j0 += 4 * kWave) {
+      u64 sv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k * kWave;
+        sv[k] = (j < tile) ? __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : kFlagAgg;
       }
-      if (__any(failed) && lane == 0) atomicExch(errflag, 1);
-      if (lane == 0)
-        __hip_atomic_store(&st[t], st_pack(kFlagPre, excl + agg), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k * kWave;
+        if (j < tile) {
+          unsigned spins = 0;
+          while ((sv[k] >> 62) == 0 && ++spins < spin_limit)
+            sv[k] = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((sv[k] >> 62) == 0) failed = true;
+          acc += st_payload(sv[k]);
+        }
+      }
     }
+    const u64 excl = wave_sum64(acc);
+    if (__any(failed) && lane == 0) atomicExch(errflag, 1);
     if (lane == 0) s_excl = excl;
   }
   __syncthreads();
-  const u64 base = s_excl + wave_off + (inc - mine);
-  int p = (int)(base & 0xFFFFFFFFull);
-  int s = (int)(base >> 32);
-  const int slot0 = (t * kScanThreads + tid) * 4;
-  const int vals[4] = {c.x, c.y, c.z, c.w};
-  int outv[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    outv[e] = s;
-    if (vals[e] > 0) {
-      if (p < P) pillar_meta[(int64_t)b * P + p] = make_int4(slot0 + e, s, vals[e], 0);
-      ++p;
-      s += vals[e];
-    }
-  }
-  *cur = make_int4(outv[0], outv[1], outv[2], outv[3]);  // cursor = bucket start
-  if (t == nwg - 1 && tid == 0) {
+  PP_STAMP(5);
+  if (tile == nwg - 1 && tid == 0) {
     const u64 tot = s_excl + agg;
     totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
   }
-}
-
-// ------------------------------------------------------------------------- //
-// k_fill: atomic-free CSR fill; also re-arms the scan's ticket/status words   //
-// ------------------------------------------------------------------------- //
-template <typename T> struct Rec4;
-template <> struct Rec4<float> { using type = float4; };
-template <> struct Rec4<double> { using type = double4; };
-
-template <typename T>
-__global__ __launch_bounds__(kBinThreads) void k_fill(
-    const T *__restrict__ pts, int64_t sweep_stride, const int2 *__restrict__ cell_rank,
-    int ncap, NPoints np, const int *__restrict__ cursor, int ncells_pad,
-    typename Rec4<T>::type *__restrict__ sorted_pts, int *__restrict__ sorted_idx,
-    u64 *status, int nwg_scan, unsigned *ticket) {
-  const int b = blockIdx.y;
-  if (blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < nwg_scan; i += kBinThreads)
-      status[(int64_t)b * nwg_scan + i] = 0ull;
-    if (threadIdx.x == 0) ticket[b] = 0u;
+  // descriptors of the tile's non-empty cells; the counters become bucket cursors
+  if (tid * cpt < TS) {
+    const u64 base = s_excl + wave_off + (inc - mine);
+    int p = (int)(base & 0xFFFFFFFFull);
+    unsigned s = (unsigned)(base >> 32);
+    for (int e = 0; e < cpt; ++e) {
+      const int q = tid * cpt + e;
+      const unsigned c = L.cur[q];
+      unsigned cur = kDropped;  // empty, or beyond max_pillars: its points are dropped
+      if (c > 0) {
+        if (p < P) {
+          pillar_meta[(int64_t)b * P + p] = make_int4(tile * TS + q, (int)s, (int)c, 0);
+          cur = s;
+        }
+        ++p;
+        s += c;
+      }
+      L.cur[q] = cur;
+    }
   }
-  const int i = blockIdx.x * kBinThreads + threadIdx.x;
-  if (i >= np.n[b]) return;
-  const int2 cr = cell_rank[(int64_t)b * ncap + i];
-  if (cr.x < 0) return;
-  const typename Rec4<T>::type rec =
-      reinterpret_cast<const typename Rec4<T>::type *>(pts + (int64_t)b * sweep_stride * 4)[i];
-  const int pos = cursor[(int64_t)b * ncells_pad + cr.x] + cr.y;  // bucket start + arrival rank
-  sorted_pts[(int64_t)b * ncap + pos] = rec;
-  sorted_idx[(int64_t)b * ncap + pos] = i;
+  PP_STAMP(6);
+  // pass 2: every point to bucket start + rank, rank in input order.  Rounds of THREADS
+  // consecutive positions, wave w takes positions [64w, 64w+64) of the round: a point's
+  // rank = cursor (earlier rounds) + points of its cell in earlier waves of the round
+  // (byte histogram column) + earlier lanes of its wave (ballots).
+  Rec *sp = sorted_pts + (int64_t)b * ncap;
+  const u64 below = lanes_below(lane);
+  unsigned char *histb = reinterpret_cast<unsigned char *>(L.hist);
+  unsigned wmask[HW];  // bytes of a column that belong to waves < w
+#pragma unroll
+  for (int i = 0; i < HW; ++i) {
+    const int nb = min(max(w - 4 * i, 0), 4);
+    wmask[i] = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+  }
+  auto place = [&](bool v, unsigned q, const Rec &rec) {
+    const u64 peers = wave_peers(q, g.tile_shift, v);
+    const int rank = __popcll(peers & below);
+    const bool leader = v && rank == 0;
+    if (leader) histb[q * WAVES + w] = (unsigned char)__popcll(peers);  // <= 64
+    __syncthreads();
+    unsigned before = 0, total = 0, old = kDropped;
+    if (v) {
+#pragma unroll
+      for (int i = 0; i < HW; ++i) {
+        const unsigned col = L.hist[q * HW + i];
+        before += byte_sum(col & wmask[i]);
+        total += byte_sum(col);
+      }
+      old = L.cur[q];
+    }
+    __syncthreads();
+    if (leader) {
+      histb[q * WAVES + w] = 0;                                    // self-cleaning
+      if (before == 0 && old != kDropped) L.cur[q] = old + total;  // first wave of the cell this round
+    }
+    if (v && old != kDropped) sp[old + before + (unsigned)rank] = rec;
+  };
+  // rounds [0, nrounds) of a list of `count` positions; fetch(j, q, rec) reads position j.
+  // kP2 rounds are fetched ahead of the one being placed.
+  auto run_rounds = [&](int count, auto &&fetch) {
+    bool v[kP2];
+    unsigned q[kP2];
+    Rec rec[kP2];
+#pragma unroll
+    for (int d = 0; d < kP2; ++d) {
+      const int j = d * THREADS + tid;
+      v[d] = j < count;
+      q[d] = 0;
+      rec[d].x = rec[d].y = rec[d].z = rec[d].w = 0;
+      if (v[d]) fetch(j, q[d], rec[d]);
+    }
+    for (int J = 0; J < count; J += kP2 * THREADS) {
+#pragma unroll
+      for (int d = 0; d < kP2; ++d) {
+        if (J + d * THREADS >= count) break;  // uniform
+        place(v[d], q[d], rec[d]);
+        const int j = J + (kP2 + d) * THREADS + tid;
+        v[d] = j < count;
+        if (v[d]) fetch(j, q[d], rec[d]);
+      }
+    }
+  };
+  if (ntile <= kCapT) {
+    __syncthreads();  // cursors written
+    run_rounds(ntile, [&](int j, unsigned &q, Rec &rec) {
+      q = L.cq[j];
+      rec = kp[L.csrc[j]];
+    });
+  } else {  // a crowded tile: walk it again
+    for (int win = 0; win < nwin; ++win) {
+      __syncthreads();
+      if (w == 0) {
+        const int G0 = tile_stage_window(row, nch, win, L, lane);
+        if (lane == 0) s_G = G0;
+      }
+      __syncthreads();
+      run_rounds(s_G, [&](int j, unsigned &q, Rec &rec) {
+        const int src = tile_find(L, j);
+        q = (unsigned)ks[src] & qmask;
+        rec = kp[src];
+      });
+    }
+  }
+  PP_STAMP(7);
 }
 
 // ------------------------------------------------------------------------- //
@@ -306,8 +581,7 @@ __global__ __launch_bounds__(kBinThreads) void k_fill(
 // ------------------------------------------------------------------------- //
 template <typename TIn>
 struct alignas(32) WaveLds {
-  int idx[CAPW];  // point indices as stored by k_fill (arrival order), 4-aligned buckets, INT_MAX pads
-  TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar
+  TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar, 4-aligned buckets
   union {
     double4 cq[CAPW];  // chain operands of one point: {n/(n+1), x/(n+1), y/(n+1), z/(n+1)}
     float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense / fused-net modes), aliases cq
@@ -323,12 +597,10 @@ struct EmitArgs {
   int P, N, ncap;
   const int4 *pillar_meta;  // [B][P] {slot, start, count, -}
   const int2 *totals;       // [B]    {cells, points}
-  const int *sorted_idx;    // [B][ncap] point index, CSR (bucket) order
-  const void *sorted_pts;   // [B][ncap] point record (x,y,z,r), CSR order
-  const int2 *cell_rank;    // [B][ncap] {slot, arrival rank} per input point
-  int *cursor;              // [B][ncells_pad], zeroed here for the next call
-  const void *pts;          // [B][sweep_stride][4] (contiguous rows)
-  int64_t sweep_stride;
+  const void *sorted_pts;   // [B][ncap] point record (x,y,z,r), CSR order, input order per bucket
+  u64 *status;              // [B][nwg_tile] look-back words of k_tile, re-armed here
+  unsigned *ticket;         // [B]
+  int nwg_tile;
   // dense mode
   float *out;          // [B][9][P][N]
   long long *idx_out;  // [B][P][3]
@@ -387,39 +659,31 @@ __device__ __forceinline__ void point_features(double x, double y, double z, dou
   f[8] = mean[2] - z;
 }
 
-// A pillar whose bucket does not fit the wave's LDS pool: re-scan the sweep's
-// cell ids in input order and compact the matches with ballot + popcount, so
-// the order is restored without sorting.  O(n_points/64) per such pillar.
+// A pillar whose bucket does not fit the wave's LDS pool: its bucket is streamed
+// 64 points at a time, in input order (k_tile left it that way).
 template <typename TIn, int MODE>
 __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k, int p,
                                 int lane, PfnAcc *acc = nullptr, float *rmax = nullptr,
                                 float *rmin = nullptr) {
-  const int slot = L.slot[k];
-  const int nb = a.np.n[b];
-  const TIn *pts = reinterpret_cast<const TIn *>(a.pts) + (int64_t)b * a.sweep_stride * 4;
-  const int2 *cell_rank = a.cell_rank + (int64_t)b * a.ncap;
-  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  using Rec = typename Rec4<TIn>::type;
+  const int cnt = L.cnt[k];
+  const Rec *sp = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + L.start[k];
   double m0 = 0, m1 = 0, m2 = 0;
-  int seen = 0;
-  for (int base = 0; base < nb; base += kWave) {
+  for (int base = 0; base < cnt; base += kWave) {
     const int i = base + lane;
-    const bool match = (i < nb) && (cell_rank[i].x == slot);
-    const u64 mask = __ballot(match);
-    if (!mask) continue;
-    const int rank = __popcll(mask & lt_mask);
-    if (match) {
-      const TIn x = pts[(int64_t)i * 4 + 0], y = pts[(int64_t)i * 4 + 1],
-                z = pts[(int64_t)i * 4 + 2];
-      const double n = (double)(seen + rank), den = n + 1;
-      L.px[rank] = x;
-      L.py[rank] = y;
-      L.pz[rank] = z;
-      L.u.cq[rank] = make_double4(n / den, (double)x / den, (double)y / den, (double)z / den);
+    if (i < cnt) {
+      const Rec rec = sp[i];
+      const double n = (double)i, den = n + 1;
+      L.px[lane] = rec.x;
+      L.py[lane] = rec.y;
+      L.pz[lane] = rec.z;
+      L.u.cq[lane] = make_double4(n / den, (double)rec.x / den, (double)rec.y / den,
+                                  (double)rec.z / den);
     }
     wave_sync();
-    const int c = __popcll(mask);
+    const int c = min(kWave, cnt - base);
     for (int t = 0; t < c; ++t) {  // uniform: every lane carries the chain
-      if (seen + t == 0) {
+      if (base + t == 0) {
         m0 = (double)L.px[0];
         m1 = (double)L.py[0];
         m2 = (double)L.pz[0];
@@ -430,33 +694,25 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
         m2 = m2 * o.x + o.w;
       }
     }
-    seen += c;
     wave_sync();
   }
   const double mean[3] = {m0, m1, m2};
   const double cx = L.cx[k], cy = L.cy[k];
   const int N = a.N;
   const int live = L.live[k];
-  seen = 0;
-  for (int base = 0; base < nb && seen < N; base += kWave) {
-    const int i = base + lane;
-    const bool match = (i < nb) && (cell_rank[i].x == slot);
-    const u64 mask = __ballot(match);
-    if (!mask) continue;
-    const int n = seen + __popcll(mask & lt_mask);
-    if (match && n < N) {
-      const TIn x = pts[(int64_t)i * 4 + 0], y = pts[(int64_t)i * 4 + 1],
-                z = pts[(int64_t)i * 4 + 2], r = pts[(int64_t)i * 4 + 3];
+  for (int base = 0; base < live; base += kWave) {
+    const int n = base + lane;
+    if (n < live) {
+      const Rec rec = sp[n];
       double f[9];
-      point_features((double)x, (double)y, (double)z, (double)r, cx, cy, mean, f);
+      point_features((double)rec.x, (double)rec.y, (double)rec.z, (double)rec.w, cx, cy, mean, f);
       if (MODE == kModeCompact) {
         double *o = a.feat_out + ((int64_t)b * a.ncap + L.start[k] + n) * 9;
 #pragma unroll
         for (int d = 0; d < 9; ++d) o[d] = f[d];
       } else if (MODE == kModePfn) {
-        const int t = __popcll(mask & lt_mask);  // position inside this chunk
 #pragma unroll
-        for (int d = 0; d < 9; ++d) L.u.feat[d][t] = (float)f[d];
+        for (int d = 0; d < 9; ++d) L.u.feat[d][lane] = (float)f[d];
       } else {
         float *o = a.out + (int64_t)b * 9 * a.P * N;
 #pragma unroll
@@ -466,7 +722,7 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
     if (MODE == kModePfn) {
       // every lane is a channel: fold this chunk's live points into its max/min
       wave_sync();
-      const int c = min(__popcll(mask), N - seen);
+      const int c = min(kWave, live - base);
       for (int t = 0; t < c; ++t) {
         float xv[9];
 #pragma unroll
@@ -477,7 +733,6 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
       }
       wave_sync();
     }
-    seen += __popcll(mask);
   }
   if (MODE == kModeDenseVec4) {
     // zero the tail of the 16-byte group that straddles `live`
@@ -491,27 +746,18 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
 }
 
 // Pooled pillars [kbeg,kend) of this wave: entries j (pooled bucket position)
-// were prefetched by the caller into registers (idx_r[it] / rec_r[it] for
-// j = lane + 64*it) straight from the CSR arrays.  Leaves the f32 features of
-// the live points in L.u.feat (dense vec4 mode) or stores them (other modes).
+// were prefetched by the caller into registers (rec_r[it] for j = lane + 64*it)
+// straight from the CSR array, where every bucket already is in input order.
+// Leaves the f32 features of the live points in L.u.feat (dense vec4 mode) or
+// stores them (other modes).
 template <typename TIn, int MODE>
 __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0,
-                                           int kbeg, int kend, int lane, const int idx_r[kPre],
+                                           int kbeg, int kend, int lane,
                                            const typename Rec4<TIn>::type rec_r[kPre],
                                            int segbeg[KW],
                                            int segpad[KW], int cntk[KW], int T) {
   const int N = a.N;
-  // bucket entries go to 4-aligned bucket starts; the up-to-3 pad entries compare as
-  // "not smaller" in the rank search below
-  if (lane < KW) {
-    int sp = 0, sc = 0;
-#pragma unroll
-    for (int kk = 0; kk < KW; ++kk) {
-      sp = (lane == kk) ? segpad[kk] : sp;
-      sc = (lane == kk) ? cntk[kk] : sc;
-    }
-    for (int e = sc; e < ((sc + 3) & ~3); ++e) L.idx[sp + e] = INT_MAX;
-  }
+  // LDS arrays use 4-aligned bucket starts (16-byte reads in the store pass)
 #pragma unroll
   for (int it = 0; it < kPre; ++it) {
     const int j = lane + it * kWave;
@@ -525,33 +771,9 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, i
         sb = (k == kk) ? segbeg[kk] : sb;
         sp = (k == kk) ? segpad[kk] : sp;
       }
-      L.idx[sp + (j - sb)] = idx_r[it];
-    }
-  }
-  wave_sync();
-  // restore input order: rank of every entry inside its bucket (counts are small)
-#pragma unroll
-  for (int it = 0; it < kPre; ++it) {
-    const int j = lane + it * kWave;
-    if (j < T) {
-      int k = 0;
-#pragma unroll
-      for (int kk = 1; kk < KW; ++kk) k = (j >= segbeg[kk] && cntk[kk] > 0) ? kk : k;
-      int sb = 0, sc = 0, sp = 0;
-#pragma unroll
-      for (int kk = 0; kk < KW; ++kk) {
-        sb = (k == kk) ? segbeg[kk] : sb;
-        sc = (k == kk) ? cntk[kk] : sc;
-        sp = (k == kk) ? segpad[kk] : sp;
-      }
-      const int my = idx_r[it];
       const typename Rec4<TIn>::type rec = rec_r[it];
-      int r = 0;
-      for (int g4 = 0; g4 < ((sc + 3) >> 2); ++g4) {  // 16-byte LDS reads, four compares each
-        const int4 v = *reinterpret_cast<const int4 *>(&L.idx[sp + 4 * g4]);
-        r += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
-      }
-      const int pos = sp + r;  // sorted arrays use 4-aligned bucket starts too
+      const int r = j - sb;  // position in the bucket = input order
+      const int pos = sp + r;
       L.px[pos] = rec.x;
       L.py[pos] = rec.y;
       L.pz[pos] = rec.z;
@@ -755,12 +977,10 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int N = a.N, P = a.P;
-  // (0) hand the count/cursor array back zeroed for the next call
-  {
-    int4 *c4 = reinterpret_cast<int4 *>(a.cursor + (int64_t)b * a.g.ncells_pad);
-    const int n4 = a.g.ncells_pad >> 2;
-    for (int i = blockIdx.x * kEmitThreads + tid; i < n4; i += gridDim.x * kEmitThreads)
-      c4[i] = make_int4(0, 0, 0, 0);
+  // (0) re-arm k_tile's look-back words for the next call (also after a failed one)
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < a.nwg_tile; i += kEmitThreads) a.status[(int64_t)b * a.nwg_tile + i] = 0ull;
+    if (tid == 0) a.ticket[b] = 0u;
   }
   WaveLds<TIn> &L = lds[w];
   // wave-uniform by construction; readfirstlane lets the compiler keep everything
@@ -811,23 +1031,16 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const bool pooled = (Tpad <= CAPW);
   // (2) the wave's pooled bucket in one coalesced read: consecutive pillars own
   //     consecutive CSR ranges
-  int idx_r[kPre];
   Rec rec_r[kPre];
 #pragma unroll
-  for (int it = 0; it < kPre; ++it) {
-    idx_r[it] = 0;
-    rec_r[it].x = rec_r[it].y = rec_r[it].z = rec_r[it].w = 0;
-  }
+  for (int it = 0; it < kPre; ++it) rec_r[it].x = rec_r[it].y = rec_r[it].z = rec_r[it].w = 0;
   if (pooled && T > 0) {
+    // the first occupied pillar's start (empty rows only follow occupied ones)
     const int start0 = __builtin_amdgcn_readfirstlane(L.start[0]);
-    const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + start0;
     const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + start0;
 #pragma unroll
     for (int it = 0; it < kPre; ++it)
-      if (lane + it * kWave < T) {
-        idx_r[it] = sidx[lane + it * kWave];
-        rec_r[it] = srec[lane + it * kWave];
-      }
+      if (lane + it * kWave < T) rec_r[it] = srec[lane + it * kWave];
   }
   // (3) scatter indices; dense modes: the zero padding that needs no point data
   float *outb = nullptr;
@@ -952,7 +1165,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     return;
   }
   if (pooled) {
-    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, idx_r, rec_r, segbeg, segpad, cnts, T);
+    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, rec_r, segbeg, segpad, cnts, T);
     if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn>(L, sg, rs, lane, segpad);
     if constexpr (MODE == kModePfn) {
 #pragma unroll
@@ -1011,15 +1224,11 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       for (int kk = 0; kk < KW; ++kk)
         if (ckg[kk] > 0) gmask |= 1u << kk;
       const int st = __builtin_amdgcn_readfirstlane(L.start[kb]);  // kb is occupied
-      const int *sidx = a.sorted_idx + (int64_t)b * a.ncap + st;
       const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + st;
 #pragma unroll
       for (int it = 0; it < kPre; ++it)
-        if (lane + it * kWave < graw) {
-          idx_r[it] = sidx[lane + it * kWave];
-          rec_r[it] = srec[lane + it * kWave];
-        }
-      emit_group<TIn, MODE>(L, a, b, p0, kb, k, lane, idx_r, rec_r, sbg, spg, ckg, graw);
+        if (lane + it * kWave < graw) rec_r[it] = srec[lane + it * kWave];
+      emit_group<TIn, MODE>(L, a, b, p0, kb, k, lane, rec_r, sbg, spg, ckg, graw);
       if constexpr (MODE == kModePfn) {
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk)
@@ -1102,12 +1311,21 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
   g->nx = (int)qx + 1;
   g->ny = (int)qy + 1;
   const long long nc = (long long)g->nx * g->ny;
-  if (nc >= (1ll << 30)) {
-    set_error("cell grid too large (%lld cells)", nc);
+  g->ncells = (int)nc;
+  // tiles: the smallest power-of-two run of slots that keeps the split at <= kTargetTiles bins;
+  // a k_tile workgroup holds its tile's cells in LDS, a k_split workgroup a byte histogram per bin
+  int ts = kMinTileSlots;
+  while ((nc + ts - 1) / ts > kTargetTiles && ts < kMaxTileSlots) ts *= 2;
+  const long long nt = (nc + ts - 1) / ts;
+  if (nt > kMaxTiles) {
+    set_error("cell grid too large (%lld cells; limit %d)", nc, kMaxTiles * kMaxTileSlots);
     return PP_ERR_VALUE;
   }
-  g->ncells = (int)nc;
-  g->ncells_pad = (int)((nc + kScanTile - 1) / kScanTile * kScanTile);
+  g->tile_shift = 0;
+  while ((1 << g->tile_shift) < ts) ++g->tile_shift;
+  g->ntiles = (int)nt;
+  g->tile_bits = 0;
+  while ((1ll << g->tile_bits) < nt) ++g->tile_bits;
   g->order = prm->order;
   g->mult = 1;
   g->mult_inv = 1;
@@ -1125,36 +1343,42 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
 namespace {
 
 struct VoxLayout {
-  size_t cursor, cell_rank, sorted_idx, sorted_pts, meta, status, ticket, totals, errflag, bytes;
-  int nwg_scan;
-  int ncap;
+  size_t kslot, kpts, mat, sorted_pts, meta, status, ticket, totals, errflag, stamps, bytes;
+  int nwg_tile;     // k_tile workgroups per sweep (one per tile) = status words per sweep
+  int ncap;         // point capacity per sweep, a multiple of the split chunk
+  int nchunks_cap;  // split chunks per sweep at capacity
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int rec_bytes) {
   VoxLayout l;
-  l.ncap = (int)align_up((size_t)std::max<int64_t>(max_points, 1), 64);
-  l.nwg_scan = g.ncells_pad / kScanTile;
+  l.ncap = (int)align_up((size_t)std::max<int64_t>(max_points, 1), kChunk);
+  l.nchunks_cap = l.ncap / kChunk;
+  l.nwg_tile = g.ntiles;
   size_t off = 0;
-  l.cursor = off;
-  off = align_up(off + (size_t)B * g.ncells_pad * 4, 256);
-  l.cell_rank = off;
-  off = align_up(off + (size_t)B * l.ncap * 8, 256);
-  l.sorted_idx = off;
+  l.kslot = off;
   off = align_up(off + (size_t)B * l.ncap * 4, 256);
+  l.kpts = off;
+  off = align_up(off + (size_t)B * l.ncap * rec_bytes, 256);
+  l.mat = off;
+  off = align_up(off + (size_t)B * g.ntiles * l.nchunks_cap * 8, 256);
   l.sorted_pts = off;
   off = align_up(off + (size_t)B * l.ncap * rec_bytes, 256);
   l.meta = off;
   off = align_up(off + (size_t)B * P * 16, 256);
   l.status = off;
-  off = align_up(off + (size_t)B * l.nwg_scan * 8, 256);
+  off = align_up(off + (size_t)B * l.nwg_tile * 8, 256);
   l.ticket = off;
   off = align_up(off + (size_t)B * 4, 256);
   l.totals = off;
   off = align_up(off + (size_t)B * 8, 256);
   l.errflag = off;
   off = align_up(off + 4, 256);
+  l.stamps = off;
+#ifdef PP_STAMPS
+  off = align_up(off + (size_t)B * l.nwg_tile * 16 * 64, 256);
+#endif
   l.bytes = off;
   return l;
 }
@@ -1175,20 +1399,22 @@ struct DeviceGuard {
   }
 };
 
-// Makes the workspace fit (B, max_points, grid, P) and guarantees the "clean"
-// invariant (cursor, status, ticket all zero) whenever the layout changed.
+// Makes the workspace fit (B, max_points, grid, P) and guarantees the "armed"
+// invariant (status, ticket, errflag all zero) whenever the layout changed.
+// Between calls k_emit re-arms the look-back words itself.
 int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
                const GridGeom &g, int P, int rec_bytes, VoxLayout *out) {
   VoxLayout l = vox_layout(B, max_points, g, P, rec_bytes);
   const unsigned long long key[6] = {(unsigned long long)B, (unsigned long long)l.ncap,
-                                     (unsigned long long)g.ncells_pad,
+                                     ((unsigned long long)g.ntiles << 8) | (unsigned)g.tile_shift,
                                      (unsigned long long)P, (unsigned long long)l.bytes,
                                      (unsigned long long)rec_bytes};
   bool grew = false;
   int rc = ctx->vox_ws.ensure(l.bytes, &grew);
   if (rc) return rc;
   if (grew || std::memcmp(key, ctx->vox_layout_key, sizeof key) != 0) {
-    PP_HIP_TRY(hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream));
+    char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+    PP_HIP_TRY(hipMemsetAsync(ws + l.status, 0, l.bytes - l.status, stream));
     std::memcpy(ctx->vox_layout_key, key, sizeof key);
   }
   *out = l;
@@ -1203,26 +1429,92 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr,
                     float *canvas = nullptr, int canvas_h = 0, int canvas_w = 0,
                     int canvas_nhwc = 0) {
+  using Rec = typename Rec4<TIn>::type;
   char *ws = static_cast<char *>(ctx->vox_ws.ptr);
-  int *cursor = reinterpret_cast<int *>(ws + l.cursor);
-  int2 *cell_rank = reinterpret_cast<int2 *>(ws + l.cell_rank);
-  int *sorted_idx = reinterpret_cast<int *>(ws + l.sorted_idx);
-  typename Rec4<TIn>::type *sorted_pts =
-      reinterpret_cast<typename Rec4<TIn>::type *>(ws + l.sorted_pts);
+  int *kslot = reinterpret_cast<int *>(ws + l.kslot);
+  Rec *kpts = reinterpret_cast<Rec *>(ws + l.kpts);
+  int2 *mat = reinterpret_cast<int2 *>(ws + l.mat);
+  Rec *sorted_pts = reinterpret_cast<Rec *>(ws + l.sorted_pts);
   int4 *meta = reinterpret_cast<int4 *>(ws + l.meta);
   u64 *status = reinterpret_cast<u64 *>(ws + l.status);
   unsigned *ticket = reinterpret_cast<unsigned *>(ws + l.ticket);
   int2 *totals = reinterpret_cast<int2 *>(ws + l.totals);
   int *errflag = reinterpret_cast<int *>(ws + l.errflag);
 
-  const dim3 grid_pts((unsigned)std::max(1, (maxn + kBinThreads - 1) / kBinThreads), (unsigned)B);
-  hipLaunchKernelGGL((k_bin_count<TIn>), grid_pts, dim3(kBinThreads), 0, stream, pts,
-                     sweep_stride, s0, s1, contig, np, g, cell_rank, l.ncap, cursor);
-  hipLaunchKernelGGL(k_scan, dim3((unsigned)l.nwg_scan, (unsigned)B), dim3(kScanThreads), 0,
-                     stream, cursor, g.ncells_pad, P, meta, status, ticket, totals, errflag);
-  hipLaunchKernelGGL((k_fill<TIn>), grid_pts, dim3(kBinThreads), 0, stream, pts, sweep_stride,
-                     cell_rank, l.ncap, np, cursor, g.ncells_pad, sorted_pts, sorted_idx, status,
-                     l.nwg_scan, ticket);
+  // k_tile geometry: waves per tile from the mean population of a tile
+  const long long per_tile = ((long long)maxn + g.ntiles - 1) / g.ntiles;
+  const int tw = ctx->force_tile_waves ? ctx->force_tile_waves
+                                       : (per_tile <= 320 ? 4 : per_tile <= 640 ? 8 : 16);
+  const int wi = tw == 4 ? 0 : tw == 8 ? 1 : 2;
+  const size_t lds_split = split_lds_bytes(g.ntiles);
+  const size_t lds_tile = tile_lds_bytes(1 << g.tile_shift, tw);
+  auto tile_fn = [&](bool with_ticket) -> const void * {
+    if (with_ticket)
+      return tw == 4 ? reinterpret_cast<const void *>(&k_tile<TIn, 4, true>)
+           : tw == 8 ? reinterpret_cast<const void *>(&k_tile<TIn, 8, true>)
+                     : reinterpret_cast<const void *>(&k_tile<TIn, 16, true>);
+    return tw == 4 ? reinterpret_cast<const void *>(&k_tile<TIn, 4, false>)
+         : tw == 8 ? reinterpret_cast<const void *>(&k_tile<TIn, 8, false>)
+                   : reinterpret_cast<const void *>(&k_tile<TIn, 16, false>);
+  };
+  // dynamic LDS beyond 64 KiB needs the attribute; set once per kernel instance and size
+  auto arm = [&](pp_ctx::TileKernelInfo &ki, const void *fn) -> int {
+    if (lds_tile > ki.lds_armed) {
+      PP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+      ki.lds_armed = lds_tile;
+    }
+    return PP_OK;
+  };
+  // The ticket (and its latency) is only needed when the grid cannot be resident all at
+  // once.  Resident capacity of the no-ticket instance: one block per CU below the
+  // occupancy query's answer (it can be one high, MI355X guide "Residency").
+  bool use_ticket = true;
+  if (!ctx->force_ticket) {
+    pp_ctx::TileKernelInfo &kn = ctx->tile_info[sizeof(TIn) == 8][wi][1];
+    int rc = arm(kn, tile_fn(false));
+    if (rc) return rc;
+    if (kn.capacity_lds != lds_tile) {
+      int per_cu = 0, cus = 0;
+      PP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tile_fn(false), tw * kWave, lds_tile));
+      PP_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+      kn.capacity = (long long)std::max(per_cu - 1, 0) * cus;
+      kn.capacity_lds = lds_tile;
+    }
+    use_ticket = (long long)l.nwg_tile * B > kn.capacity;
+  }
+  {
+    int rc = arm(ctx->tile_info[sizeof(TIn) == 8][wi][use_ticket ? 0 : 1], tile_fn(use_ticket));
+    if (rc) return rc;
+  }
+  if (lds_split > ctx->split_lds_armed[sizeof(TIn) == 8]) {
+    PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split<TIn>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
+    ctx->split_lds_armed[sizeof(TIn) == 8] = lds_split;
+  }
+  const int nchunks = std::max(1, (maxn + kChunk - 1) / kChunk);
+  hipLaunchKernelGGL((k_split<TIn>), dim3((unsigned)nchunks, (unsigned)B), dim3(kSplitThreads),
+                     lds_split, stream, pts, sweep_stride, s0, s1, contig, np, g, l.ncap,
+                     l.nchunks_cap, kslot, kpts, mat);
+  u64 *stamps = nullptr;
+#ifdef PP_STAMPS
+  stamps = reinterpret_cast<u64 *>(ws + l.stamps);
+  ctx->dbg_stamps_off = l.stamps;
+  ctx->dbg_stamps_bytes = (size_t)B * l.nwg_tile * 16 * 64;
+#endif
+  auto launch_tile = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)l.nwg_tile, (unsigned)B), dim3(tw * kWave), lds_tile,
+                       stream, np, g, P, l.ncap, l.nchunks_cap, kslot, kpts, mat, sorted_pts, meta,
+                       status, ticket, totals, errflag, ctx->scan_spin_limit, stamps);
+  };
+  if (use_ticket) {
+    if (tw == 4) launch_tile(&k_tile<TIn, 4, true>);
+    else if (tw == 8) launch_tile(&k_tile<TIn, 8, true>);
+    else launch_tile(&k_tile<TIn, 16, true>);
+  } else {
+    if (tw == 4) launch_tile(&k_tile<TIn, 4, false>);
+    else if (tw == 8) launch_tile(&k_tile<TIn, 8, false>);
+    else launch_tile(&k_tile<TIn, 16, false>);
+  }
   EmitArgs a;
   a.g = g;
   a.np = np;
@@ -1231,12 +1523,10 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.ncap = l.ncap;
   a.pillar_meta = meta;
   a.totals = totals;
-  a.sorted_idx = sorted_idx;
   a.sorted_pts = sorted_pts;
-  a.cell_rank = cell_rank;
-  a.cursor = cursor;
-  a.pts = pts;
-  a.sweep_stride = sweep_stride;
+  a.status = status;
+  a.ticket = ticket;
+  a.nwg_tile = l.nwg_tile;
   a.out = out;
   a.idx_out = idx_out;
   a.feat_out = feat_out;
@@ -1278,7 +1568,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-      // the self-cleaning invariant (counts, scan words zero) can no longer be assumed
+      // the armed invariant (look-back words zero) can no longer be assumed
       std::memset(ctx->vox_layout_key, 0, sizeof ctx->vox_layout_key);
       set_error("voxelizer launch failed: %s", hipGetErrorString(e));
       return PP_ERR_HIP;
@@ -1291,6 +1581,17 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
 }  // namespace pp
 
 using namespace pp;
+
+#ifdef PP_STAMPS
+// development builds only (tools/lab): k_tile's phase stamps of sweep 0, 8 per wave
+extern "C" int pp_debug_stamps(pp_ctx_t *ctx, unsigned long long *host, int cap) {
+  const size_t n = std::min((size_t)cap * 8, ctx->dbg_stamps_bytes);
+  if (hipMemcpy(host, static_cast<char *>(ctx->vox_ws.ptr) + ctx->dbg_stamps_off, n,
+                hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return (int)(n / 8);
+}
+#endif
 
 extern "C" int pp_voxelize_reserve(pp_ctx_t *ctx, int batch, int64_t max_points,
                                    const pp_voxel_params_t *prm) {
