@@ -12,7 +12,7 @@
 // Documented tightenings (same as the ctypes mirror, pillars.py): outputs must be genuine
 // writable float64 arrays (the reference's forcecast would write into a temporary and lose
 // the results), wrong corner winding raises ValueError instead of std::exit(1), pillar order
-// is deterministic (env PP_PILLAR_ORDER: 0 row-major, 1 scrambled), NaN points are dropped.
+// is deterministic (env PP_PILLAR_ORDER: 0 row-major, 1 scrambled = default), NaN points are dropped.
 // HIP is initialised on the first call, never at import (DataLoader workers: use spawn).
 
 #include <pybind11/numpy.h>
@@ -101,7 +101,7 @@ void create_pillars(in_array points, py::object tensor_o, py::object indices_o,
   prm.z_max = z_max;
   prm.canvas_height = canvas_height;
   const char *ord = std::getenv("PP_PILLAR_ORDER");
-  prm.order = ord ? std::atoi(ord) : PP_ORDER_ROW_MAJOR;
+  prm.order = ord ? std::atoi(ord) : PP_ORDER_SCRAMBLED;
   const int64_t ts[3] = {tensor.shape(0), tensor.shape(1), tensor.shape(2)};
   const int64_t tst[3] = {tensor.strides(0), tensor.strides(1), tensor.strides(2)};
   const int64_t is[2] = {indices.shape(0), indices.shape(1)};

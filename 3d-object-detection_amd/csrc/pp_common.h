@@ -52,6 +52,7 @@ struct GridGeom {
   int tile_bits;      // bits of a tile id
   int order;          // PP_ORDER_*
   unsigned long long mult, mult_inv;  // scrambled order: slot = cell*mult % ncells
+  unsigned long long barrett;         // floor(2^64 / ncells), for the device-side modulo
 };
 
 int make_grid(const pp_voxel_params_t *prm, GridGeom *g);

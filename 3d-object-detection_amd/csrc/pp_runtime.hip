@@ -3,6 +3,7 @@
 
 #include "pp_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 

@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace pp {
@@ -51,9 +52,12 @@ constexpr int kTargetTiles = 256;            // tiles (= k_tile workgroups, spli
 constexpr int kMaxTiles = 4096;              // split bins: byte histograms [16][T] must fit LDS
 constexpr int kEmitWaves = 4;                // waves per emit workgroup
 constexpr int kEmitThreads = kEmitWaves * kWave;
-constexpr int KW = 4;      // pillars per emit wave
+#ifndef PP_KW
+#define PP_KW 4
+#endif
+constexpr int KW = PP_KW;  // pillars per emit wave
 #ifndef PP_CAPW
-#define PP_CAPW 128
+#define PP_CAPW (PP_KW >= 2 ? 32 * PP_KW : 64)
 #endif
 constexpr int CAPW = PP_CAPW;  // pooled bucket capacity (points, 4-padded per pillar) per emit wave
 constexpr int kPre = CAPW / 64;  // bucket entries prefetched per lane
@@ -82,13 +86,21 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// x mod ncells for x < 2^60 without a 64-bit division: q = floor(x * floor(2^64/n) / 2^64)
+// is the quotient or one less (Barrett), so at most one correction.
+__device__ __forceinline__ int mod_ncells(u64 x, const GridGeom &g) {
+  const u64 q = __umul64hi(x, g.barrett);
+  u64 r = x - q * (u64)g.ncells;
+  if (r >= (u64)g.ncells) r -= (u64)g.ncells;
+  return (int)r;
+}
 __device__ __forceinline__ int cell_to_slot(int cell, const GridGeom &g) {
   if (g.order == PP_ORDER_ROW_MAJOR) return cell;
-  return (int)(((u64)cell * g.mult) % (u64)g.ncells);
+  return mod_ncells((u64)cell * g.mult, g);
 }
 __device__ __forceinline__ int slot_to_cell(int slot, const GridGeom &g) {
   if (g.order == PP_ORDER_ROW_MAJOR) return slot;
-  return (int)(((u64)slot * g.mult_inv) % (u64)g.ncells);
+  return mod_ncells((u64)slot * g.mult_inv, g);
 }
 
 template <typename T> struct Rec4;
@@ -143,6 +155,18 @@ __device__ __forceinline__ u64 wave_peers(unsigned key, int bits, bool valid) {
 
 __device__ __forceinline__ int shfl_up_i(int v, int d) { return __shfl_up(v, d, kWave); }
 
+#ifdef PP_STAMPS  // tools/lab builds: PP_STAMPS=1 stamps k_tile, =2 k_split (8 stamps per wave)
+#define PP_STAMP_AT(which, k)                                                        \
+  do {                                                                               \
+    if (PP_STAMPS == (which) && stamps && lane == 0)                                  \
+      stamps[(((size_t)blockIdx.y * stamp_nx + blockIdx.x) * 16 + w) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define PP_STAMP_AT(which, k) do {} while (0)
+#endif
+#define PP_STAMP(k) PP_STAMP_AT(1, k)
+#define PP_STAMP_S(k) PP_STAMP_AT(2, k)
+
 // LDS of k_split: byte histograms [kSplitWaves][Tp], bin offsets u16 [Tp], wave totals.
 __host__ __device__ inline int split_tp(int ntiles) { return (ntiles + 3) & ~3; }
 __host__ __device__ inline size_t split_lds_bytes(int ntiles) {
@@ -154,7 +178,7 @@ template <typename T>
 __global__ __launch_bounds__(kSplitThreads) void k_split(
     const T *__restrict__ pts, int64_t sweep_stride, int64_t s0, int64_t s1, int contig,
     NPoints np, GridGeom g, int ncap, int nchunks_cap, int *__restrict__ kslot,
-    typename Rec4<T>::type *__restrict__ kpts, int2 *__restrict__ mat) {
+    typename Rec4<T>::type *__restrict__ kpts, int2 *__restrict__ mat, u64 *stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char split_smem[];
   using Rec = typename Rec4<T>::type;
   const int b = blockIdx.y;
@@ -162,6 +186,8 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
   const int chunk = blockIdx.x;
   if (chunk * kChunk >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  [[maybe_unused]] const int stamp_nx = gridDim.x;
+  PP_STAMP_S(0);
   const int ntiles = g.ntiles;
   const int Tp = split_tp(ntiles);
   unsigned char *whist = split_smem;
@@ -183,9 +209,12 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
   const unsigned tile = valid ? (unsigned)slot >> g.tile_shift : 0u;
   const u64 peers = wave_peers(tile, g.tile_bits, valid);
   const int rank_w = __popcll(peers & lanes_below(lane));
+  PP_STAMP_S(1);
   __syncthreads();
+  PP_STAMP_S(2);
   if (valid && rank_w == 0) whist[w * Tp + tile] = (unsigned char)__popcll(peers);  // <= 64
   __syncthreads();
+  PP_STAMP_S(3);
   // bin totals over the 16 waves, exclusive scan over the bins (consecutive bins per thread)
   const int nb = (ntiles + kSplitThreads - 1) / kSplitThreads;  // <= kMaxTiles / 1024 = 4
   unsigned tot[4] = {0u, 0u, 0u, 0u};
@@ -208,6 +237,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
     if (lane >= d) inc += o;
   }
   if (lane == kWave - 1) wtot[w] = (unsigned)inc;
+  PP_STAMP_S(4);
   __syncthreads();
   unsigned base = (unsigned)inc - mine;
 #pragma unroll
@@ -223,7 +253,9 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
       base += tot[e];
     }
   }
+  PP_STAMP_S(5);
   __syncthreads();
+  PP_STAMP_S(6);
   if (valid) {
     unsigned pos = binoff[tile] + (unsigned)rank_w;
     for (int ww = 0; ww < w; ++ww) pos += whist[ww * Tp + tile];
@@ -231,6 +263,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
     kslot[dst] = slot;
     kpts[dst] = rec;
   }
+  PP_STAMP_S(7);
 }
 
 // ------------------------------------------------------------------------- //
@@ -309,20 +342,19 @@ __device__ __forceinline__ int tile_find(const TileLds &L, int j) {
 
 __device__ __forceinline__ unsigned byte_sum(unsigned v) { return __builtin_amdgcn_sad_u8(v, 0u, 0u); }
 
-#ifdef PP_STAMPS
-#define PP_STAMP(k)                                                                  \
-  do {                                                                               \
-    if (stamps && lane == 0)                                                          \
-      stamps[(((size_t)b * gridDim.x + blockIdx.x) * 16 + w) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define PP_STAMP(k) do {} while (0)
-#endif
-
 // One workgroup of WAVES waves per tile (1 << tile_shift consecutive slots, all of them
 // in LDS).  TICKET: tile ids are handed out by an atomic ticket, so that a workgroup only
 // ever waits for workgroups that have started; without it the tile is blockIdx.x, which
 // the launcher uses only when the whole grid is resident at once.
+//
+//   pass 1   population of the tile's cells (order-free LDS atomics); {source, cell} of
+//            the first kCapT positions stay in LDS
+//   scan     prefix sums over the cells -> bucket starts and pillar indices; the tile's
+//            totals are published, those of ALL earlier tiles summed (no chain)
+//   pass 2   every point to bucket start + rank, rank in input order: rounds of THREADS
+//            consecutive positions, wave w takes positions [64w, 64w+64) of the round; a
+//            point's rank = cursor (earlier rounds) + points of its cell in earlier waves of
+//            the round (byte histogram column) + earlier lanes of its wave (ballots)
 template <typename T, int WAVES, bool TICKET>
 __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     NPoints np, GridGeom g, int P, int ncap, int nchunks_cap, const int *__restrict__ kslot,
@@ -339,8 +371,9 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
   __shared__ u64 s_wave[WAVES];
   __shared__ u64 s_excl;
   const int b = blockIdx.y;
-  const int nwg = gridDim.x;  // = g.ntiles
+  const int nwg = g.ntiles;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  [[maybe_unused]] const int stamp_nx = g.ntiles;
   PP_STAMP(0);
   const int TS = 1 << g.tile_shift;
   TileLds L;
@@ -372,7 +405,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
   const int *ks = kslot + (int64_t)b * ncap;
   const Rec *kp = kpts + (int64_t)b * ncap;
   const unsigned qmask = (unsigned)TS - 1u;
-  // pass 1: population of the tile's cells (order-free); the first kCapT positions are cached
+  // pass 1
   int ntile = 0;  // positions walked so far = points of the tile
   for (int win = 0; win < nwin; ++win) {
     __syncthreads();  // window arrays free (and cur/hist zeroed)
@@ -491,10 +524,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     }
   }
   PP_STAMP(6);
-  // pass 2: every point to bucket start + rank, rank in input order.  Rounds of THREADS
-  // consecutive positions, wave w takes positions [64w, 64w+64) of the round: a point's
-  // rank = cursor (earlier rounds) + points of its cell in earlier waves of the round
-  // (byte histogram column) + earlier lanes of its wave (ballots).
+  // pass 2
   Rec *sp = sorted_pts + (int64_t)b * ncap;
   const u64 below = lanes_below(lane);
   unsigned char *histb = reinterpret_cast<unsigned char *>(L.hist);
@@ -527,7 +557,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     }
     if (v && old != kDropped) sp[old + before + (unsigned)rank] = rec;
   };
-  // rounds [0, nrounds) of a list of `count` positions; fetch(j, q, rec) reads position j.
+  // rounds over a list of `count` positions; fetch(j, q, rec) reads position j.
   // kP2 rounds are fetched ahead of the one being placed.
   auto run_rounds = [&](int count, auto &&fetch) {
     bool v[kP2];
@@ -1315,7 +1345,16 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
   // tiles: the smallest power-of-two run of slots that keeps the split at <= kTargetTiles bins;
   // a k_tile workgroup holds its tile's cells in LDS, a k_split workgroup a byte histogram per bin
   int ts = kMinTileSlots;
-  while ((nc + ts - 1) / ts > kTargetTiles && ts < kMaxTileSlots) ts *= 2;
+  static const int forced_tiles = [] {  // development knob
+    const char *e = getenv("PP_TARGET_TILES");
+    const int v = e ? atoi(e) : 0;
+    return v >= 16 && v <= kMaxTiles ? v : 0;
+  }();
+  // row-major tiles are strips of the plane and lidar clouds are centre-heavy: finer tiles
+  // bound the crowded ones; scrambled tiles are uniform and fewer, larger ones cost less
+  const int target_tiles = forced_tiles ? forced_tiles
+                         : prm->order == PP_ORDER_ROW_MAJOR ? kTargetTiles : kTargetTiles / 2;
+  while ((nc + ts - 1) / ts > target_tiles && ts < kMaxTileSlots) ts *= 2;
   const long long nt = (nc + ts - 1) / ts;
   if (nt > kMaxTiles) {
     set_error("cell grid too large (%lld cells; limit %d)", nc, kMaxTiles * kMaxTileSlots);
@@ -1329,6 +1368,8 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
   g->order = prm->order;
   g->mult = 1;
   g->mult_inv = 1;
+  g->barrett = nc > 1 ? ~0ull / (unsigned long long)nc : 0ull;  // floor((2^64-1)/n) = floor(2^64/n) unless n | 2^64
+  if (nc > 1 && (nc & (nc - 1)) == 0) g->barrett += 1;  // n a power of two: 2^64/n exactly
   if (prm->order == PP_ORDER_SCRAMBLED && nc > 2) {
     unsigned long long m = (unsigned long long)std::floor((double)nc * 0.6180339887498949);
     if (m < 1) m = 1;
@@ -1377,7 +1418,7 @@ VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int re
   off = align_up(off + 4, 256);
   l.stamps = off;
 #ifdef PP_STAMPS
-  off = align_up(off + (size_t)B * l.nwg_tile * 16 * 64, 256);
+  off = align_up(off + (size_t)B * std::max(l.nwg_tile, l.nchunks_cap) * 16 * 64, 256);
 #endif
   l.bytes = off;
   return l;
@@ -1444,7 +1485,8 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   // k_tile geometry: waves per tile from the mean population of a tile
   const long long per_tile = ((long long)maxn + g.ntiles - 1) / g.ntiles;
   const int tw = ctx->force_tile_waves ? ctx->force_tile_waves
-                                       : (per_tile <= 320 ? 4 : per_tile <= 640 ? 8 : 16);
+               : per_tile <= 320 ? 4
+               : (per_tile <= 640 || g.order != PP_ORDER_ROW_MAJOR) ? 8 : 16;
   const int wi = tw == 4 ? 0 : tw == 8 ? 1 : 2;
   const size_t lds_split = split_lds_bytes(g.ntiles);
   const size_t lds_tile = tile_lds_bytes(1 << g.tile_shift, tw);
@@ -1477,7 +1519,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
       int per_cu = 0, cus = 0;
       PP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tile_fn(false), tw * kWave, lds_tile));
       PP_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-      kn.capacity = (long long)std::max(per_cu - 1, 0) * cus;
+      kn.capacity = (long long)(per_cu >= 2 ? per_cu - 1 : per_cu) * cus;
       kn.capacity_lds = lds_tile;
     }
     use_ticket = (long long)l.nwg_tile * B > kn.capacity;
@@ -1492,15 +1534,15 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
     ctx->split_lds_armed[sizeof(TIn) == 8] = lds_split;
   }
   const int nchunks = std::max(1, (maxn + kChunk - 1) / kChunk);
-  hipLaunchKernelGGL((k_split<TIn>), dim3((unsigned)nchunks, (unsigned)B), dim3(kSplitThreads),
-                     lds_split, stream, pts, sweep_stride, s0, s1, contig, np, g, l.ncap,
-                     l.nchunks_cap, kslot, kpts, mat);
   u64 *stamps = nullptr;
 #ifdef PP_STAMPS
   stamps = reinterpret_cast<u64 *>(ws + l.stamps);
   ctx->dbg_stamps_off = l.stamps;
-  ctx->dbg_stamps_bytes = (size_t)B * l.nwg_tile * 16 * 64;
+  ctx->dbg_stamps_bytes = (size_t)B * (PP_STAMPS == 2 ? nchunks : l.nwg_tile) * 16 * 64;
 #endif
+  hipLaunchKernelGGL((k_split<TIn>), dim3((unsigned)nchunks, (unsigned)B), dim3(kSplitThreads),
+                     lds_split, stream, pts, sweep_stride, s0, s1, contig, np, g, l.ncap,
+                     l.nchunks_cap, kslot, kpts, mat, stamps);
   auto launch_tile = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3((unsigned)l.nwg_tile, (unsigned)B), dim3(tw * kWave), lds_tile,
                        stream, np, g, P, l.ncap, l.nchunks_cap, kslot, kpts, mat, sorted_pts, meta,

@@ -28,8 +28,9 @@ from . import _lib
 
 __all__ = ["create_pillars", "make_ious"]
 
-#: pillar emission order used by create_pillars (0 row-major, 1 scrambled)
-ORDER = int(os.environ.get("PP_PILLAR_ORDER", _lib.ORDER_ROW_MAJOR))
+#: pillar emission order used by create_pillars (0 row-major, 1 scrambled = default: the
+#: stand-in for the reference's hash-map iteration order, pillars.cpp:335)
+ORDER = int(os.environ.get("PP_PILLAR_ORDER", _lib.ORDER_SCRAMBLED))
 #: HIP device used by this module's lazily created context
 DEVICE = int(os.environ.get("PP_HIP_DEVICE", "0"))
 

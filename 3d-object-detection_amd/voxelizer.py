@@ -28,7 +28,11 @@ class VoxelConfig:
     y_max: float = 50.0
     z_max: float = 10.0
     canvas_height: int = 500
-    order: int = _lib.ORDER_ROW_MAJOR
+    # Pillar order.  The reference emits pillars in boost::unordered_map iteration order
+    # (pillars.cpp:335) and, with more occupied cells than max_pillars, drops whatever iterates
+    # last: a spatially scattered subset.  ORDER_SCRAMBLED is the deterministic stand-in for that
+    # (default); ORDER_ROW_MAJOR drops the rows with the largest canvas_y as one region.
+    order: int = _lib.ORDER_SCRAMBLED
 
     @staticmethod
     def reference_default():
@@ -36,7 +40,8 @@ class VoxelConfig:
         return VoxelConfig(200, 24000, .2, .2, -60, -60, -10, 60, 60, 10, 600)
 
     @staticmethod
-    def square(half, step, max_pillars, max_points, z_min=-10.0, z_max=10.0, order=0):
+    def square(half, step, max_pillars, max_points, z_min=-10.0, z_max=10.0,
+               order=_lib.ORDER_SCRAMBLED):
         n = int(round(2 * half / step))
         return VoxelConfig(max_points, max_pillars, step, step, -half, -half, z_min,
                            half, half, z_max, n, order)

@@ -100,7 +100,7 @@ def scramble_mult(ncells):
 
 def create_pillars(points, tensor, indices, max_points_per_pillar, max_pillars,
                    x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max,
-                   canvas_height, order=ORDER_ROW_MAJOR):
+                   canvas_height, order=ORDER_SCRAMBLED):
     """data/pillars.cpp:236-398 (positional signature of pillars.cpp:236-249).
 
     Returns the number of non-empty cells (the reference returns None)."""
@@ -178,7 +178,7 @@ def make_ious(a_corners, g_corners, a_centers, g_centers, ious):
 
 def dataset_voxel_stage(lidar_points, max_pillars, max_points, x_step, y_step,
                         x_min, y_min, z_min, x_max, y_max, z_max, canvas_height,
-                        order=ORDER_ROW_MAJOR, data_mean=None):
+                        order=ORDER_SCRAMBLED, data_mean=None):
     """np.zeros + create_pillars + transpose + f32 cast (+ the optional data_mean), exactly
     the work of data/dataset.py:89-106.  Returns
     (pillar[9,P,N] float32, indices[P,3] int64, num_cells)."""

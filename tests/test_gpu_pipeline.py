@@ -37,7 +37,7 @@ def test_pipeline_forward_equals_model_on_oracle_pillars(gpu, oracle):
     pipe.model.eval()
     pts = synth.lidar_like(15000, 16.0, 3)
     cl, rg = pipe.forward(torch.from_numpy(pts).to(gpu))
-    ref_p, ref_i, _ = oracle_stage(oracle, pts, 4000, 32, 16.0, 0.2)
+    ref_p, ref_i, _ = oracle_stage(oracle, pts, 4000, 32, 16.0, 0.2, order=cfg.order)
     with torch.no_grad():
         cl2, rg2 = pipe.model(torch.from_numpy(ref_p)[None].to(gpu), torch.from_numpy(ref_i)[None].to(gpu))
     assert cl.shape == (1, 18, 80, 80) and rg.shape == (1, 16, 80, 80)
@@ -241,7 +241,7 @@ def test_inference_chain_raw_rows_to_boxes(gpu, oracle):
     pipe = PillarPipeline(cfg, device=gpu, seed=3)
     pipe.model.eval()
     with torch.no_grad():      # make some anchors fire
-        pipe.model.det_head.cls.bias.fill_(-1.0)
+        pipe.model.det_head.cls.bias.fill_(-0.6)
     acfg = pipe.anchor_cfg
     anchors = boxes.make_anchors(acfg)
     H = cfg.canvas_height

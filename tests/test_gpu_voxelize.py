@@ -174,29 +174,47 @@ def test_batch_ragged_and_rerun_identical(gpu, oracle):
     assert np.array_equal(pil, pil2) and np.array_equal(idx, idx2) and np.array_equal(cnt, cnt2)
 
 
+@pytest.mark.parametrize("order", [0, 1], ids=["row_major", "scrambled"])
 @pytest.mark.parametrize("cfg", [C2, C5], ids=["config2", "config5"])
-def test_full_size_configs(gpu, oracle, cfg):
-    """BASELINE configs 2 and 5 at full size: oracle comparison plus the
-    size-independent properties (exactly min(cells,P) rows, counts per cell,
-    sortedness of the row-major order, points conserved)."""
+def test_full_size_configs(gpu, oracle, cfg, order):
+    """BASELINE configs 2 and 5 at full size, both pillar orders (scrambled is the default and
+    what bench.py runs): oracle comparison plus the size-independent properties (exactly
+    min(cells,P) rows, counts per cell, sortedness of the order, points conserved)."""
     from pp_amd import synth
     pts = synth.lidar_like(cfg["n"], cfg["half"], 0)
     P, N = cfg["P"], cfg["N"]
-    vox = _vox(gpu, cfg["half"], cfg["step"], P, N)
+    vox = _vox(gpu, cfg["half"], cfg["step"], P, N, order=order)
     pil, idx, cnt = _run(gpu, vox, pts)
     pil, idx = pil[0], idx[0]
     cc = oracle.cell_counts(pts.astype(np.float64), *grid_args(cfg["half"], cfg["step"]))
     assert cnt[0, 0] == len(cc) and cnt[0, 1] == cc[:, 2].sum()
     nrow = min(len(cc), P)
     assert idx[:nrow, 0].all() and not idx[nrow:].any()
-    # row-major order: (row, col) strictly increasing and equal to the first nrow cells
-    assert np.array_equal(idx[:nrow, 1], cc[:nrow, 0]) and np.array_equal(idx[:nrow, 2], cc[:nrow, 1])
-    key = idx[:nrow, 2] * 100000 + idx[:nrow, 1]
-    assert (np.diff(key) > 0).all()
+    if order == 0:
+        # row-major order: (row, col) strictly increasing and equal to the first nrow cells
+        assert np.array_equal(idx[:nrow, 1], cc[:nrow, 0]) and np.array_equal(idx[:nrow, 2], cc[:nrow, 1])
+        key = idx[:nrow, 2] * 100000 + idx[:nrow, 1]
+        assert (np.diff(key) > 0).all()
+        want = cc[:nrow, 2]
+    else:
+        # scrambled order: ascending (cell * mult) mod ncells over the occupied cells
+        nx = int(np.floor(2 * cfg["half"] / cfg["step"])) + 1
+        H = int(round(2 * cfg["half"] / cfg["step"]))
+        ncells = nx * nx
+        mult = oracle.scramble_mult(ncells)
+        # cell id = grid row from the top (canvas row + 1 guard row) * nx + col
+        cell = (idx[:nrow, 2] + (nx - H)) * nx + idx[:nrow, 1]
+        slot = (cell.astype(np.int64) * mult) % ncells
+        assert (np.diff(slot) > 0).all()
+        all_cell = (cc[:, 1] + (nx - H)) * nx + cc[:, 0]
+        all_slot = np.sort((all_cell.astype(np.int64) * mult) % ncells)
+        assert np.array_equal(slot, all_slot[:nrow])          # the first nrow occupied slots survive
+        lut = {(int(c), int(r)): int(k) for c, r, k in cc}
+        want = np.array([lut[(int(c), int(r))] for c, r in idx[:nrow, 1:]])
     # per-pillar live slot count == min(count, N); intensity channel (> 0 a.s.) marks live slots
     live = (pil[3] != 0).sum(axis=1)
-    assert np.array_equal(live[:nrow], np.minimum(cc[:nrow, 2], N))
-    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, cfg["half"], cfg["step"])
+    assert np.array_equal(live[:nrow], np.minimum(want, N))
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, cfg["half"], cfg["step"], order=order)
     assert _check_exact(pil, idx, ref_p, ref_i)
 
 

@@ -101,7 +101,7 @@ def test_orders_agree_as_sets_and_overflow_subset_rule(oracle):
         assert len(capped) == 500 and m == len(ref)
         assert all(np.array_equal(v, ref[k]) for k, v in capped.items())
     # row-major keeps the first P cells in (row, col) order
-    p, i, m = oracle.dataset_voxel_stage(pts, 500, 16, *g)
+    p, i, m = oracle.dataset_voxel_stage(pts, 500, 16, *g, order=oracle.ORDER_ROW_MAJOR)
     assert np.array_equal(i[:, 1:], cc[:500, :2])
 
 
