@@ -20,12 +20,14 @@ PP_ERR_NOMEM, PP_ERR_HIP, PP_ERR_INTERNAL = -5, -6, -7
 ORDER_ROW_MAJOR, ORDER_SCRAMBLED = 0, 1
 NUM_FEATURES = 9
 MAX_BATCH = 32
+KERNEL_SPLIT, KERNEL_TILE, KERNEL_EMIT = 0, 1, 2
 
 EXPORTS = [
     "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
     "pp_voxelize_reserve", "pp_voxelize_dev", "pp_subtract_mean_dev", "pp_voxelize_pfn_dev", "pp_voxelize_pfn_canvas_dev", "pp_pfn_dense_dev", "pp_scatter_canvas_dev", "pp_pfn_train_stats_dev", "pp_pfn_train_backward_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
     "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_ingest_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_relu_bn_train_fwd_dev", "pp_relu_bn_train_bwd_dev", "pp_ctx_set_timing",
-    "pp_ctx_read_emit_ms",
+    "pp_ctx_read_emit_ms", "pp_ctx_read_kernel_ms", "pp_voxelize_check", "pp_debug_set_scan_limit",
+    "pp_debug_poison_ticket",
 ]
 
 
@@ -169,6 +171,11 @@ def lib():
         L.pp_ctx_set_timing.argtypes = [vp, c_int]
         L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
                                           ctypes.POINTER(c_int)]
+        L.pp_ctx_read_kernel_ms.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_float), c_int,
+                                            ctypes.POINTER(c_int)]
+        L.pp_voxelize_check.argtypes = [vp, vp]
+        L.pp_debug_set_scan_limit.argtypes = [vp, ctypes.c_uint, c_int]
+        L.pp_debug_poison_ticket.argtypes = [vp, vp, c_int, ctypes.c_uint]
         for name in EXPORTS:
             fn = getattr(L, name)
             if name not in ("pp_last_error", "pp_version", "pp_ctx_destroy"):
@@ -225,7 +232,7 @@ class Context:
 
 
 def make_voxel_params(max_points_per_pillar, max_pillars, x_step, y_step, x_min, y_min, z_min,
-                      x_max, y_max, z_max, canvas_height, order=ORDER_ROW_MAJOR):
+                      x_max, y_max, z_max, canvas_height, order=ORDER_SCRAMBLED):
     return VoxelParams(int(max_points_per_pillar), int(max_pillars), float(x_step), float(y_step),
                        float(x_min), float(y_min), float(z_min), float(x_max), float(y_max),
                        float(z_max), float(canvas_height), int(order), 0)

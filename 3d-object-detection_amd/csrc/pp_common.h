@@ -74,6 +74,7 @@ struct pp_ctx {
   size_t split_lds_armed[2] = {0, 0};
   int force_tile_waves = 0;  // development knobs: PP_TILE_WAVES / PP_FORCE_TICKET in the environment
   int force_ticket = 0;
+  size_t ws_ticket_off = 0, ws_errflag_off = 0;  // where the current layout keeps them (pp_voxelize_check, test hooks)
   size_t dbg_stamps_off = 0, dbg_stamps_bytes = 0;  // PP_STAMPS builds (tools/lab)
   // host drop-in staging
   pp::DevBuf stage_in, stage_out, stage_out2;
@@ -84,7 +85,7 @@ struct pp_ctx {
   pp::DevBuf decode_ws;            // post-processing: sort keys + rocPRIM temporary storage
   pp::DevBuf pfn_ws;               // training feature net: per-workgroup partial sums
   // emit-kernel timing ring (bench.py)
-  std::vector<hipEvent_t> ev_start, ev_stop;
+  std::vector<hipEvent_t> ev_start[3], ev_stop[3];  // [PP_KERNEL_*][slot]
   int ev_slots = 0;
   int ev_next = 0;
   int ev_count = 0;

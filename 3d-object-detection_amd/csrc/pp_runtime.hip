@@ -136,8 +136,10 @@ extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
   ctx->pin_in.release();
   ctx->pin_out.release();
   ctx->pin_meta.release();
-  for (auto &e : ctx->ev_start) (void)hipEventDestroy(e);
-  for (auto &e : ctx->ev_stop) (void)hipEventDestroy(e);
+  for (int k = 0; k < 3; ++k) {
+    for (auto &e : ctx->ev_start[k]) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_stop[k]) (void)hipEventDestroy(e);
+  }
   if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
   delete ctx;
 }
@@ -150,45 +152,64 @@ extern "C" int pp_ctx_set_timing(pp_ctx_t *ctx, int slots) {
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != ctx->device) (void)hipSetDevice(ctx->device);
-  for (auto &e : ctx->ev_start) (void)hipEventDestroy(e);
-  for (auto &e : ctx->ev_stop) (void)hipEventDestroy(e);
-  ctx->ev_start.clear();
-  ctx->ev_stop.clear();
+  for (int k = 0; k < 3; ++k) {
+    for (auto &e : ctx->ev_start[k]) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_stop[k]) (void)hipEventDestroy(e);
+    ctx->ev_start[k].clear();
+    ctx->ev_stop[k].clear();
+  }
   ctx->ev_slots = 0;
   ctx->ev_next = 0;
   ctx->ev_count = 0;
   int rc = PP_OK;
   for (int i = 0; i < slots && rc == PP_OK; ++i) {
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-      set_error("hipEventCreate failed");
-      rc = PP_ERR_HIP;
-      break;
+    for (int k = 0; k < 3; ++k) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        set_error("hipEventCreate failed");
+        rc = PP_ERR_HIP;
+        break;
+      }
+      ctx->ev_start[k].push_back(a);
+      ctx->ev_stop[k].push_back(b);
     }
-    ctx->ev_start.push_back(a);
-    ctx->ev_stop.push_back(b);
   }
   if (rc == PP_OK) ctx->ev_slots = slots;
   if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
   return rc;
 }
 
-extern "C" int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count) {
-  if (!ctx || !ms || !count) {
-    set_error("pp_ctx_read_emit_ms: NULL argument");
+extern "C" int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int cap, int *count) {
+  if (!ctx || !ms || !count || which < 0 || which > 2) {
+    set_error("pp_ctx_read_kernel_ms: bad argument");
     return PP_ERR_VALUE;
   }
   const int n = ctx->ev_count < cap ? ctx->ev_count : cap;
-  // oldest first
-  int idx = (ctx->ev_next - ctx->ev_count + 2 * (ctx->ev_slots > 0 ? ctx->ev_slots : 1)) %
-            (ctx->ev_slots > 0 ? ctx->ev_slots : 1);
+  const int slots = ctx->ev_slots > 0 ? ctx->ev_slots : 1;
+  int idx = (ctx->ev_next - ctx->ev_count + 2 * slots) % slots;  // oldest first
   for (int i = 0; i < n; ++i) {
-    PP_HIP_TRY(hipEventSynchronize(ctx->ev_stop[idx]));
-    PP_HIP_TRY(hipEventElapsedTime(&ms[i], ctx->ev_start[idx], ctx->ev_stop[idx]));
-    idx = (idx + 1) % ctx->ev_slots;
+    PP_HIP_TRY(hipEventSynchronize(ctx->ev_stop[which][idx]));
+    PP_HIP_TRY(hipEventElapsedTime(&ms[i], ctx->ev_start[which][idx], ctx->ev_stop[which][idx]));
+    idx = (idx + 1) % slots;
   }
   *count = n;
-  ctx->ev_count = 0;
-  ctx->ev_next = 0;
+  if (which == PP_KERNEL_EMIT) {
+    ctx->ev_count = 0;
+    ctx->ev_next = 0;
+  }
+  return PP_OK;
+}
+
+extern "C" int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count) {
+  return pp_ctx_read_kernel_ms(ctx, PP_KERNEL_EMIT, ms, cap, count);
+}
+
+extern "C" int pp_debug_set_scan_limit(pp_ctx_t *ctx, unsigned polls, int force_ticket) {
+  if (!ctx) {
+    set_error("ctx is NULL");
+    return PP_ERR_VALUE;
+  }
+  ctx->scan_spin_limit = polls ? polls : (1u << 22);
+  ctx->force_ticket = force_ticket != 0;
   return PP_OK;
 }

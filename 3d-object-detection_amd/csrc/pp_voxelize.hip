@@ -1454,8 +1454,8 @@ int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
   int rc = ctx->vox_ws.ensure(l.bytes, &grew);
   if (rc) return rc;
   if (grew || std::memcmp(key, ctx->vox_layout_key, sizeof key) != 0) {
-    char *ws = static_cast<char *>(ctx->vox_ws.ptr);
-    PP_HIP_TRY(hipMemsetAsync(ws + l.status, 0, l.bytes - l.status, stream));
+    // everything: k_emit must find in-range descriptors even behind a k_tile that gave up
+    PP_HIP_TRY(hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream));
     std::memcpy(ctx->vox_layout_key, key, sizeof key);
   }
   *out = l;
@@ -1540,13 +1540,29 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   ctx->dbg_stamps_off = l.stamps;
   ctx->dbg_stamps_bytes = (size_t)B * (PP_STAMPS == 2 ? nchunks : l.nwg_tile) * 16 * 64;
 #endif
-  hipLaunchKernelGGL((k_split<TIn>), dim3((unsigned)nchunks, (unsigned)B), dim3(kSplitThreads),
-                     lds_split, stream, pts, sweep_stride, s0, s1, contig, np, g, l.ncap,
-                     l.nchunks_cap, kslot, kpts, mat, stamps);
+  ctx->ws_ticket_off = l.ticket;
+  ctx->ws_errflag_off = l.errflag;
+  // When the timing ring is armed every launch carries its own start/stop events
+  // (hipExtLaunchKernelGGL binds them to the dispatch packet, so a pair brackets the
+  // kernel alone, like a profiler's kernel trace, not the gaps around it).
+  hipEvent_t ev0[3] = {nullptr, nullptr, nullptr}, ev1[3] = {nullptr, nullptr, nullptr};
+  if (timed && ctx->ev_slots > 0) {
+    for (int k = 0; k < 3; ++k) {
+      ev0[k] = ctx->ev_start[k][ctx->ev_next];
+      ev1[k] = ctx->ev_stop[k][ctx->ev_next];
+    }
+    ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
+    ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
+  }
+  hipExtLaunchKernelGGL((k_split<TIn>), dim3((unsigned)nchunks, (unsigned)B), dim3(kSplitThreads),
+                        lds_split, stream, ev0[PP_KERNEL_SPLIT], ev1[PP_KERNEL_SPLIT], 0, pts,
+                        sweep_stride, s0, s1, contig, np, g, l.ncap, l.nchunks_cap, kslot, kpts, mat,
+                        stamps);
   auto launch_tile = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3((unsigned)l.nwg_tile, (unsigned)B), dim3(tw * kWave), lds_tile,
-                       stream, np, g, P, l.ncap, l.nchunks_cap, kslot, kpts, mat, sorted_pts, meta,
-                       status, ticket, totals, errflag, ctx->scan_spin_limit, stamps);
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)l.nwg_tile, (unsigned)B), dim3(tw * kWave), lds_tile,
+                          stream, ev0[PP_KERNEL_TILE], ev1[PP_KERNEL_TILE], 0, np, g, P, l.ncap,
+                          l.nchunks_cap, kslot, kpts, mat, sorted_pts, meta, status, ticket, totals,
+                          errflag, ctx->scan_spin_limit, stamps);
   };
   if (use_ticket) {
     if (tw == 4) launch_tile(&k_tile<TIn, 4, true>);
@@ -1579,32 +1595,22 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.canvas_w = canvas_w;
   a.canvas_nhwc = canvas_nhwc;
   const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
-  // When the timing ring is armed the emit launch carries its own start/stop events
-  // (hipExtLaunchKernelGGL binds them to the dispatch packet, so the pair brackets the
-  // kernel alone, like a profiler's kernel trace, not the gaps around it).
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (timed && ctx->ev_slots > 0) {
-    ev0 = ctx->ev_start[ctx->ev_next];
-    ev1 = ctx->ev_stop[ctx->ev_next];
-    ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
-    ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
-  }
   switch (mode) {
     case kModeDenseVec4:
       hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseVec4>), grid_emit, dim3(kEmitThreads), 0, stream,
-                            ev0, ev1, 0, a);
+                            ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
       break;
     case kModeDenseScalar:
       hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseScalar>), grid_emit, dim3(kEmitThreads), 0, stream,
-                            ev0, ev1, 0, a);
+                            ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
       break;
     case kModePfn:
-      hipExtLaunchKernelGGL((k_emit<TIn, kModePfn>), grid_emit, dim3(kEmitThreads), 0, stream, ev0,
-                            ev1, 0, a);
+      hipExtLaunchKernelGGL((k_emit<TIn, kModePfn>), grid_emit, dim3(kEmitThreads), 0, stream,
+                            ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
       break;
     default:
       hipExtLaunchKernelGGL((k_emit<TIn, kModeCompact>), grid_emit, dim3(kEmitThreads), 0, stream,
-                            ev0, ev1, 0, a);
+                            ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
       break;
   }
   {
@@ -1634,6 +1640,37 @@ extern "C" int pp_debug_stamps(pp_ctx_t *ctx, unsigned long long *host, int cap)
   return (int)(n / 8);
 }
 #endif
+
+extern "C" int pp_voxelize_check(pp_ctx_t *ctx, void *stream_) {
+  if (!ctx) {
+    set_error("ctx is NULL");
+    return PP_ERR_VALUE;
+  }
+  DeviceGuard guard(ctx->device);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PP_HIP_TRY(hipStreamSynchronize(stream));
+  if (!ctx->vox_ws.ptr || !ctx->ws_errflag_off) return PP_OK;  // nothing launched yet
+  int flag = 0;
+  char *fp = static_cast<char *>(ctx->vox_ws.ptr) + ctx->ws_errflag_off;
+  PP_HIP_TRY(hipMemcpy(&flag, fp, 4, hipMemcpyDeviceToHost));
+  if (!flag) return PP_OK;
+  PP_HIP_TRY(hipMemset(fp, 0, 4));
+  set_error(flag == 2 ? "voxelizer: a tile ticket was out of range (workspace not armed); the call's outputs are invalid"
+                      : "voxelizer: a tile timed out waiting for an earlier tile's totals; the call's outputs are invalid");
+  return PP_ERR_INTERNAL;
+}
+
+extern "C" int pp_debug_poison_ticket(pp_ctx_t *ctx, void *stream_, int sweep, unsigned value) {
+  if (!ctx || !ctx->vox_ws.ptr || !ctx->ws_ticket_off || sweep < 0 || sweep >= PP_MAX_BATCH) {
+    set_error("pp_debug_poison_ticket: no voxelizer workspace yet (or bad sweep)");
+    return PP_ERR_VALUE;
+  }
+  DeviceGuard guard(ctx->device);
+  PP_HIP_TRY(hipMemcpyAsync(static_cast<char *>(ctx->vox_ws.ptr) + ctx->ws_ticket_off + 4 * (size_t)sweep,
+                            &value, 4, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream_)));
+  PP_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
+  return PP_OK;
+}
 
 extern "C" int pp_voxelize_reserve(pp_ctx_t *ctx, int batch, int64_t max_points,
                                    const pp_voxel_params_t *prm) {

@@ -108,10 +108,13 @@ class PillarPipeline:
         utils/box_utils.py:19-32)."""
         return self.assigner._gt_to_device(g["centers"], g["wlh"], g["yaw"], g["classes"])
 
-    def train_forward_backward(self, points, gts, n_points=None):
+    def train_forward_backward(self, points, gts, n_points=None, shard_ctx=None):
         """train.py:139-147 without the optimizer: voxel stage, target stage, forward,
         loss, backward.  ``gts`` is a list (one per sweep) of dicts with
-        centers / wlh / yaw / classes in canvas space."""
+        centers / wlh / yaw / classes in canvas space.  With a multi-rank ``shard_ctx`` the
+        back-propagated loss is ``shard.global_batch_loss`` (this rank's share of the ONE loss
+        the reference computes over the gathered batch); the returned scalars stay the local
+        PPLoss values."""
         pillars, indices = self.voxelize(points, n_points)
         # a ground-truth entry is either the dict of host arrays or the device tuple of
         # upload_ground_truth() (what a prefetching loader hands over: no H2D copy, no sync)
@@ -121,5 +124,11 @@ class PillarPipeline:
         reg_t = torch.stack([t[1] for t in targets])
         cls, reg = self.model(pillars, indices)
         p, cls_loss, reg_loss, ort_loss, total = self.loss(cls, reg, cls_t, reg_t)
-        total.backward()
+        if shard_ctx is not None and shard_ctx.distributed:
+            from . import shard
+            n_pos = (reg_t[..., 0] == 1).sum()
+            shard.global_batch_loss(shard_ctx, self.loss, cls_loss, reg_loss, ort_loss, n_pos).backward()
+        else:
+            total.backward()
+        self._pfn_params = None   # the feature net is about to change under forward_fused
         return cls_loss.detach(), reg_loss.detach(), ort_loss.detach(), total.detach()

@@ -22,6 +22,21 @@ class ShardContext:
         return self.world_size > 1
 
 
+def private_miopen_cache(local_rank, root=None):
+    """Give this process its own MIOpen user database / kernel cache directory.  N ranks that
+    start together on a fresh box would otherwise run their first convolutions' find/compile
+    step against ONE shared user find-db and write it concurrently.  Must run before the first
+    convolution of the process; explicit MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR win."""
+    root = root or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pp_miopen_{os.getuid()}")
+    d = os.path.join(root, f"rank{int(local_rank)}")
+    for var, sub in (("MIOPEN_USER_DB_PATH", "udb"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+        if var not in os.environ:
+            path = os.path.join(d, sub)
+            os.makedirs(path, exist_ok=True)
+            os.environ[var] = path
+    return d
+
+
 def init_from_env(backend=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract); a
     single process without those variables is world_size 1, no process group."""
@@ -31,10 +46,14 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
+            # bind the communicator to this rank's GPU up front (no lazy device guess at the
+            # first collective, no barrier-on-wrong-device warning)
+            kw["device_id"] = torch.device("cuda", local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return ShardContext(rank, world, local, backend)
 
 
@@ -59,16 +78,49 @@ def reduce_loss_scalars(ctx, cls_loss, reg_loss, ort_loss, total, n_local, devic
     return buf[:4] / buf[4].clamp_min(1.0)
 
 
+def global_batch_loss(ctx, loss, cls_loss, reg_loss, ort_loss, n_pos_local):
+    """The loss to back-propagate on this rank so that AVERAGING the ranks' gradients
+    (allreduce_gradients) gives the gradient of the reference's one loss over the gathered
+    batch (nn.DataParallel, train.py:88-89,144-147).
+
+    PPLoss's classification term is a mean over all anchors: equal sweeps per rank make the
+    average of the ranks' means the global mean.  The regression and orientation terms are
+    means over the POSITIVE anchors (model/loss.py:53-62): rank r's term must be weighted by
+    n_pos_r * world / n_pos_global -- one all-reduce of the positive counts, before the
+    backward.  A rank without positives contributes zero (its local mean over an empty
+    selection is NaN in the reference too; there only if the WHOLE batch has none -- with no
+    positive anywhere this returns a finite loss where the reference returns NaN).
+    ``loss`` is the PPLoss module (its b_cls / b_reg / b_ort)."""
+    n_local = torch.as_tensor(n_pos_local, dtype=torch.float32, device=cls_loss.device).reshape(1)
+    n_global = n_local.clone()
+    if ctx.distributed:
+        dist.all_reduce(n_global, op=dist.ReduceOp.SUM)
+    scale = (n_local * float(ctx.world_size) / n_global.clamp_min(1.0)).reshape(())
+    have = n_local.reshape(()) > 0
+    zero = torch.zeros((), dtype=cls_loss.dtype, device=cls_loss.device)
+    reg = torch.where(have, reg_loss, zero) * scale
+    ort = torch.where(have, ort_loss, zero) * scale
+    return loss.b_cls * cls_loss + loss.b_reg * reg + loss.b_ort * ort
+
+
 def allreduce_gradients(ctx, parameters, bucket_bytes=32 << 20):
-    """Average the gradients over all ranks: what the reference's ``nn.DataParallel`` does
-    implicitly (train.py:88-89: one loss over the gathered batch, gradients reduced onto GPU 0).
-    The gradients are packed into flat buckets (one all-reduce per ``bucket_bytes``; the whole
-    network is 19 MB of f32, i.e. ONE ring all-reduce over xGMI), summed and divided by the
-    world size.  Every rank ends with identical gradients, so identical optimizer steps keep the
-    replicas in sync without ever broadcasting weights."""
+    """Average the gradients over all ranks: with ``global_batch_loss`` as each rank's loss this
+    is the reference's ``nn.DataParallel`` step (train.py:88-89: one loss over the gathered
+    batch, gradients reduced onto GPU 0).  The gradients are packed into flat buckets (one
+    all-reduce per ``bucket_bytes``; the whole network is 19 MB of f32, i.e. ONE ring
+    all-reduce over xGMI), summed and divided by the world size.  EVERY parameter takes part
+    (a missing gradient counts as zeros), so all ranks issue the same collectives whatever
+    their local graph touched.  Every rank ends with identical gradients, so identical
+    optimizer steps keep the replicas in sync without ever broadcasting weights."""
     if not ctx.distributed:
         return 0
-    grads = [p.grad for p in parameters if p.grad is not None]
+    grads = []
+    for p in parameters:
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        grads.append(p.grad)
     n_calls, i = 0, 0
     while i < len(grads):
         bucket, size = [], 0

@@ -101,12 +101,23 @@ class PillarVoxelizer:
     def set_timing(self, slots):
         _lib.check(_lib.lib().pp_ctx_set_timing(self._ctx.handle, int(slots)), "pp_ctx_set_timing")
 
-    def read_emit_ms(self, cap=4096):
+    def read_kernel_ms(self, which, cap=4096):
+        """Durations (ms, oldest first) of kernel ``which`` (_lib.KERNEL_SPLIT / _TILE / _EMIT)
+        of the calls since ``set_timing``; reading KERNEL_EMIT empties the ring."""
         buf = (ctypes.c_float * cap)()
         cnt = ctypes.c_int()
-        _lib.check(_lib.lib().pp_ctx_read_emit_ms(self._ctx.handle, buf, cap, ctypes.byref(cnt)),
-                   "pp_ctx_read_emit_ms")
+        _lib.check(_lib.lib().pp_ctx_read_kernel_ms(self._ctx.handle, int(which), buf, cap, ctypes.byref(cnt)),
+                   "pp_ctx_read_kernel_ms")
         return [buf[i] for i in range(cnt.value)]
+
+    def read_emit_ms(self, cap=4096):
+        return self.read_kernel_ms(_lib.KERNEL_EMIT, cap)
+
+    def check(self):
+        """Synchronises the current stream and raises if a voxelizer launch on this context
+        failed since the last check (a tile's bounded wait ran out): pp_voxelize_check."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().pp_voxelize_check(self._ctx.handle, ctypes.c_void_p(stream)), "pp_voxelize_check")
 
     def _prep(self, points, n_points):
         if points.dim() == 2:

@@ -12,12 +12,21 @@ random backbone weights.  Multi-GPU: one process per GPU, every rank owns its
 own sweeps (seed = global sweep id), no data-path collective ("weak" scaling).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     the dominant hand-written kernel (k_emit, the dense [9,P,N] store):
-               algorithmic bytes per launch / its mean duration, timed live with
-               HIP events on the launch stream during the timed steps
-  cpu_baseline the CPU oracle's reference-style voxel stage (hash map of heap
-               nodes + the caller's np.zeros/transpose/.float() glue,
-               data/dataset.py:89-106) timed on this host, 1 core
+  roofline      the dominant hand-written kernel (k_emit, the dense [9,P,N] store):
+                algorithmic bytes per launch / its mean duration, timed live with HIP
+                events bound to the dispatch packets during the timed steps; beside it
+                `pipeline`: the same bytes over the SUM of the voxelizer's three kernels
+                (k_split + k_tile + k_emit) -> pipeline_frac, and their mean durations
+  voxelizer_only   wall time of the voxelizer launches alone (default = scrambled order,
+                and the row-major order beside it)
+  fused_feature_net  SURVEY 8f rank 1 measured beside the headline
+  train_c3      BASELINE configs[2] (and the RCCL leg of configs[3] when N > 1): HIP target
+                assignment + loss forward/backward + gradient and loss-scalar all-reduces
+  stress_c5     BASELINE configs[4] shapes on one GPU: 200k points, 1000x1000 grid, P=30000,
+                voxelizer only, with its own roofline / pipeline fractions
+  cpu_baseline  the CPU oracle's reference-style voxel stage (hash map of heap nodes + the
+                caller's np.zeros/transpose/.float() glue, data/dataset.py:89-106) timed on
+                this host, 1 core, at configs[1]'s grid and (`c1`) at configs[0]'s 100x100 grid
 """
 import argparse
 import json
@@ -32,13 +41,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import pp_amd  # noqa: E402
-from pp_amd import shard, synth  # noqa: E402
+from pp_amd import _lib, shard, synth  # noqa: E402
 from pp_amd.pipeline import PillarPipeline  # noqa: E402
-from pp_amd.voxelizer import VoxelConfig  # noqa: E402
+from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig  # noqa: E402
 
 METRIC = "lidar sweeps/sec end-to-end fwd (pillarize+backbone), 60k pts, 500×500 BEV"
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md:36
 N_POINTS, HALF, STEP, P, N = 60000, 50.0, 0.2, 12000, 100
+C5 = dict(n=200000, half=100.0, step=0.2, P=30000, N=100)   # BASELINE configs[4] shapes
+C1 = dict(n=60000, half=50.0, step=1.0, P=12000, N=100)     # BASELINE configs[0]: 100x100 grid
 
 
 _CPU_WORKER = r"""
@@ -59,14 +70,11 @@ print(k / (time.perf_counter() - t0))
 """
 
 
-def cpu_baseline(seconds_budget=12.0, workers=4, worker_budget=6.0):
-    """Reference-style CPU voxel stage (oracle, ORDER_HASH): one core, and `workers` processes
-    side by side like the reference's DataLoader (num_workers = 4, config.py:139)."""
-    import subprocess
+def _cpu_voxel_stage(n, half, step, p, nn, seconds_budget):
+    """median seconds per call of the oracle's reference-style voxel stage on one core"""
     from oracle import oracle as O
-    O.build()
-    pts = synth.lidar_like(N_POINTS, HALF, 0).astype(np.float64)  # dataset.py:82 hands over f64
-    args = (P, N, STEP, STEP, -HALF, -HALF, -10.0, HALF, HALF, 10.0, int(2 * HALF / STEP))
+    pts = synth.lidar_like(n, half, 0).astype(np.float64)  # dataset.py:82 hands over f64
+    args = (p, nn, step, step, -half, -half, -10.0, half, half, 10.0, int(round(2 * half / step)))
     for _ in range(2):
         O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
     times = []
@@ -75,12 +83,26 @@ def cpu_baseline(seconds_budget=12.0, workers=4, worker_budget=6.0):
         t0 = time.perf_counter()
         O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
         times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+    return float(np.median(times)), len(times)
+
+
+def cpu_baseline(seconds_budget=10.0, workers=4, worker_budget=5.0, c1_budget=5.0):
+    """Reference-style CPU voxel stage (oracle, ORDER_HASH): one core, and `workers` processes
+    side by side like the reference's DataLoader (num_workers = 4, config.py:139)."""
+    import subprocess
+    from oracle import oracle as O
+    O.build()
+    med, calls = _cpu_voxel_stage(N_POINTS, HALF, STEP, P, N, seconds_budget)
     out = {"value": 1.0 / med, "unit": "sweeps/s", "cores": 1, "kind": "port",
-           "sample": f"{len(times)} calls of the voxel stage only (np.zeros + create_pillars "
+           "sample": f"{calls} calls of the voxel stage only (np.zeros + create_pillars "
                      f"[reference-style hash map of heap nodes] + transpose + f32 cast, "
                      f"dataset.py:89-106) on one {N_POINTS}-pt cloud, median {med * 1e3:.1f} ms; "
                      f"host has {os.cpu_count()} cores; the backbone is not part of this leg"}
+    # BASELINE configs[0]: the same cloud on the 100x100 grid (1 m cells), CPU path only
+    med1, calls1 = _cpu_voxel_stage(C1["n"], C1["half"], C1["step"], C1["P"], C1["N"], c1_budget)
+    out["c1"] = {"value": 1.0 / med1, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                 "sample": f"configs[0]: {calls1} calls, one {C1['n']}-pt cloud, 100x100 grid "
+                           f"(step {C1['step']} m), P={C1['P']} N={C1['N']}, median {med1 * 1e3:.1f} ms"}
     # the reference's loader runs num_workers = 4 such processes (config.py:139): fresh child
     # processes (never a fork of this GPU-initialised one), CPU only
     try:
@@ -98,6 +120,53 @@ def cpu_baseline(seconds_budget=12.0, workers=4, worker_budget=6.0):
     return out
 
 
+def kernel_means_us(vox):
+    """mean duration (us) of the voxelizer's three kernels over the calls since set_timing"""
+    ms = {k: vox.read_kernel_ms(w) for k, w in
+          (("k_split", _lib.KERNEL_SPLIT), ("k_tile", _lib.KERNEL_TILE))}
+    ms["k_emit"] = vox.read_kernel_ms(_lib.KERNEL_EMIT)      # last: empties the ring
+    return {k: (float(np.mean(v)) * 1e3 if v else float("nan")) for k, v in ms.items()}, len(ms["k_emit"])
+
+
+def roofline_record(kern_us, launches, bytes_per_launch, traffic=None, traffic_source=None):
+    emit_s = kern_us["k_emit"] * 1e-6
+    total_s = sum(kern_us.values()) * 1e-6
+    achieved = bytes_per_launch / emit_s / 1e9
+    return {"bound": "hbm", "kernel": "pp::k_emit<float,0>", "achieved": achieved,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "bytes_per_launch": bytes_per_launch, "avg_launch_us": kern_us["k_emit"],
+            "launches_timed": launches,
+            "pipeline": {"kernels_us": kern_us, "sum_us": total_s * 1e6,
+                         "achieved": bytes_per_launch / total_s / 1e9,
+                         "what": "the same algorithmic bytes over the SUM of the three kernels of one "
+                                 "voxelizer call (k_split, k_tile: binning, no output bytes; k_emit: the "
+                                 "dense store)"},
+            "pipeline_frac": bytes_per_launch / total_s / HBM_PEAK}
+
+
+def voxelizer_wall(vox, points, out, iters=200, warm=20):
+    for _ in range(warm):
+        vox(points, out=out)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(iters):
+        vox(points, out=out)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t1) / iters
+
+
+def static_traffic(batch):
+    """HBM bytes per k_emit launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs); a constant read from profiles/, NOT measured in this run"""
+    tpath = os.path.join(ROOT, "profiles", "emit_traffic.json")
+    try:
+        t = json.load(open(tpath))
+        return t.get(f"batch{batch}"), t.get("source", "profiles/emit_traffic.json (static)")
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,10 +175,13 @@ def main():
     ap.add_argument("--batch", type=int, default=4,
                     help="sweeps per GPU per step (default: the reference's BATCH_SIZE, config.py:137)")
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
-                    help="fwd: BASELINE metric (configs[1]); train: configs[2] -- adds HIP target "
-                         "assignment, loss forward/backward and the loss-scalar all-reduce")
+                    help="fwd: BASELINE metric (configs[1]); train: the headline itself becomes "
+                         "configs[2] (HIP target assignment, loss forward/backward, all-reduces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-feature-net side measurement")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the train_c3 sub-record")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress_c5 sub-record")
+    ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the contract); gloo only to rehearse the multi-rank "
                          "code path on a box with fewer GPUs than ranks (all ranks share device 0)")
@@ -117,6 +189,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # every rank searches / compiles its convolutions against its own MIOpen user db
+        shard.private_miopen_cache(int(os.environ.get("LOCAL_RANK", "0")))
     ctx = shard.init_from_env(a.backend)
     if ctx.world_size != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world_size}: launch with "
@@ -130,23 +206,27 @@ def main():
     # for a 3 % faster step.
     torch.backends.cudnn.benchmark = (a.mode == "fwd")
 
-    cfg = VoxelConfig.square(HALF, STEP, P, N)
+    cfg = VoxelConfig.square(HALF, STEP, P, N)          # default pillar order (scrambled)
     pipe = PillarPipeline(cfg, device=dev, seed=0, with_targets=(a.mode == "train"))
     pipe.model.eval() if a.mode == "fwd" else pipe.model.train()
     sweep_ids = [ctx.rank * a.batch + i for i in range(a.batch)]
     clouds = np.stack([synth.lidar_like(N_POINTS, HALF, s) for s in sweep_ids])
     points = torch.from_numpy(clouds).to(dev)          # resident in HBM before timing
-    gts = [synth.gt_boxes(40, cfg.canvas_height, s) for s in sweep_ids]
+    gts_host = [synth.gt_boxes(40, cfg.canvas_height, s) for s in sweep_ids]
+    gts = gts_host
     if a.mode == "train":   # boxes resident on the device like the points (a loader would prefetch them)
-        gts = [pipe.upload_ground_truth(g) for g in gts]
+        gts = [pipe.upload_ground_truth(g) for g in gts_host]
+
+    def train_step(p_, gts_):
+        p_.model.zero_grad(set_to_none=True)
+        losses = p_.train_forward_backward(points, gts_, shard_ctx=ctx)
+        shard.allreduce_gradients(ctx, p_.model.parameters())     # DataParallel's gradient reduction
+        return shard.reduce_loss_scalars(ctx, *losses, n_local=a.batch, device=dev)
 
     def step():
         if a.mode == "fwd":
             return pipe.forward(points)
-        pipe.model.zero_grad(set_to_none=True)
-        losses = pipe.train_forward_backward(points, gts)
-        shard.allreduce_gradients(ctx, pipe.model.parameters())     # DataParallel's gradient reduction
-        return shard.reduce_loss_scalars(ctx, *losses, n_local=a.batch, device=dev)
+        return train_step(pipe, gts)
 
     for _ in range(a.warmup):
         step()
@@ -161,19 +241,18 @@ def main():
     shard.barrier(ctx)
     torch.cuda.synchronize()
     elapsed = shard.max_over_ranks(ctx, time.perf_counter() - t0, device=dev)
-    emit_ms = pipe.voxelizer.read_emit_ms(4096)
+    kern_us, launches = kernel_means_us(pipe.voxelizer)
     pipe.voxelizer.set_timing(0)
 
-    # voxelizer alone (same resident inputs), for the per-stage picture
-    vox_steps = 200
-    for _ in range(20):
-        pipe.voxelize(points)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(vox_steps):
-        pipe.voxelize(points)
-    torch.cuda.synchronize()
-    vox_dt = (time.perf_counter() - t1) / vox_steps
+    # voxelizer alone (same resident inputs), for the per-stage picture: wall time per call,
+    # in the default order and in the row-major one
+    vox_dt = voxelizer_wall(pipe.voxelizer, points, pipe._buffers(a.batch))
+    vox_rm = PillarVoxelizer(VoxelConfig.square(HALF, STEP, P, N, order=_lib.ORDER_ROW_MAJOR), device=dev)
+    vox_rm.set_timing(64)
+    vox_rm_dt = voxelizer_wall(vox_rm, points, pipe._buffers(a.batch), iters=64, warm=10)
+    rm_us, _ = kernel_means_us(vox_rm)
+    vox_rm.set_timing(0)
+    del vox_rm
 
     # next row: the feature net fused into the voxelizer -- the dense
     # [9,P,N] tensor is never built.  Reported beside the headline, not as it.
@@ -195,18 +274,83 @@ def main():
                          "the HIP voxelizer (pp_voxelize_pfn_canvas_dev, channels-last canvas); outputs equal "
                          "the headline path's within 1e-4"}
 
+    # BASELINE configs[2] (and configs[3]'s collectives when N > 1): target assignment + loss
+    # forward/backward + the gradient and loss-scalar all-reduces, every rank, timed like the headline
+    train = None
+    if a.mode == "fwd" and not a.no_train_leg:
+        torch.backends.cudnn.benchmark = False          # immediate mode, see above
+        tp = PillarPipeline(cfg, device=dev, seed=0, with_targets=True)
+        tp.model.train()
+        tg = [tp.upload_ground_truth(g) for g in gts_host]
+        for _ in range(3):
+            train_step(tp, tg)
+        torch.cuda.synchronize()
+        shard.barrier(ctx)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(a.train_steps):
+            train_step(tp, tg)
+        torch.cuda.synchronize()
+        shard.barrier(ctx)
+        torch.cuda.synchronize()
+        tr_el = shard.max_over_ranks(ctx, time.perf_counter() - t3, device=dev)
+        # the pieces, on this rank: target assignment of the batch, the two all-reduces
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            for g in tg:
+                tp.assigner.assign_device(*g)
+        e1.record()
+        torch.cuda.synchronize()
+        assign_us = e0.elapsed_time(e1) * 1e3 / (20 * len(tg))
+        e0.record()
+        for _ in range(10):
+            shard.allreduce_gradients(ctx, tp.model.parameters())
+            shard.reduce_loss_scalars(ctx, 0.0, 0.0, 0.0, 0.0, n_local=a.batch, device=dev)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 10
+        nbytes = sum(p_.numel() * p_.element_size() for p_ in tp.model.parameters() if p_.requires_grad)
+        train = {"value": a.train_steps * a.batch * ctx.world_size / tr_el, "unit": "sweeps/s",
+                 "ms_per_step": tr_el / a.train_steps * 1e3, "steps": a.train_steps,
+                 "target_assign_us_per_sweep": assign_us,
+                 "allreduce_ms": ar_ms if ctx.distributed else 0.0,
+                 "collectives": {"backend": ctx.backend if ctx.distributed else None,
+                                 "world_size": torch.distributed.get_world_size() if ctx.distributed else 1,
+                                 "per_step": "1 all-reduce of the positive-anchor counts (4 B), 1 flat gradient "
+                                             f"all-reduce ({nbytes / 1e6:.1f} MB f32), 1 all-reduce of the four "
+                                             "loss scalars + sweep count (20 B)" if ctx.distributed else "none (N=1)"},
+                 "what": "configs[2]: HIP voxelizer + HIP rotated-IoU target assignment (2 anchors/cell, "
+                         "G=40 boxes, A=125000) + network forward + focal/smooth-L1 loss + backward, f32, "
+                         "BatchNorm in training mode; MIOpen immediate mode"}
+        del tp, tg
+        torch.cuda.empty_cache()
+
+    # BASELINE configs[4] shapes (stress): voxelizer only, one GPU's share
+    stress = None
+    if not a.no_stress and ctx.world_size == 1:
+        c5 = VoxelConfig.square(C5["half"], C5["step"], C5["P"], C5["N"])
+        v5 = PillarVoxelizer(c5, device=dev)
+        pts5 = torch.from_numpy(np.stack([synth.lidar_like(C5["n"], C5["half"], s) for s in sweep_ids])).to(dev)
+        out5 = (torch.empty((a.batch, 9, C5["P"], C5["N"]), dtype=torch.float32, device=dev),
+                torch.empty((a.batch, C5["P"], 3), dtype=torch.int64, device=dev))
+        v5.set_timing(100)
+        dt5 = voxelizer_wall(v5, pts5, out5, iters=100, warm=10)
+        k5, n5 = kernel_means_us(v5)
+        v5.set_timing(0)
+        b5 = c5.algorithmic_bytes(C5["n"]) * a.batch
+        stress = {"workload": f"configs[4] shapes on one GPU: {a.batch} x {C5['n']}-pt clouds, 1000x1000 grid, "
+                              f"P={C5['P']} N={C5['N']}, voxelizer only",
+                  "sweeps_per_s": a.batch / dt5, "us_per_step": dt5 * 1e6,
+                  "wall_frac": b5 / dt5 / HBM_PEAK,
+                  "roofline": roofline_record(k5, n5, b5)}
+        del v5, pts5, out5
+        torch.cuda.empty_cache()
+
     if ctx.rank == 0:
         total_sweeps = a.steps * a.batch * ctx.world_size
         bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
-        emit_s = float(np.mean(emit_ms)) * 1e-3 if emit_ms else float("nan")
-        achieved = bytes_per_launch / emit_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "emit_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"batch{a.batch}")
-            except Exception:
-                traffic = None
+        traffic, tsrc = static_traffic(a.batch)
         out = {
             "metric": METRIC, "value": total_sweeps / elapsed, "unit": "sweeps/s",
             "n_gpus": ctx.world_size, "steps": a.steps, "warmup": a.warmup,
@@ -215,21 +359,28 @@ def main():
             "config": {"workload": "configs[1]: HIP pillarizer + PPFeatureNet + scatter + backbone + "
                                    "head fwd, 60k-pt lidar-like clouds, 500x500 grid, P=12000 N=100 D=9, "
                                    "random weights" + ("; configs[2] additions: HIP target assign "
-                                                       "(2 anchors/cell, G=40), loss fwd/bwd, loss-scalar "
-                                                       "all-reduce" if a.mode == "train" else ""),
+                                                       "(2 anchors/cell, G=40), loss fwd/bwd, gradient and "
+                                                       "loss-scalar all-reduces" if a.mode == "train" else ""),
                        "mode": a.mode, "sweeps_per_gpu_per_step": a.batch,
                        "global_batch": a.batch * ctx.world_size,
+                       "pillar_order": "scrambled (default; stand-in for the reference's hash-map order)",
                        "voxelizer_arithmetic": "f64 binning/mean, f32 features",
                        "parallelism": f"1 sweep-shard per GPU x{ctx.world_size}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "pp::k_emit<float,0>", "achieved": achieved,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-                         "traffic": traffic, "bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": emit_s * 1e6, "launches_timed": len(emit_ms)},
+            "roofline": roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc),
             "voxelizer_only": {"sweeps_per_s": a.batch / vox_dt, "us_per_step": vox_dt * 1e6,
-                               "pipeline_GBps": bytes_per_launch / vox_dt / 1e9},
+                               "pipeline_GBps": bytes_per_launch / vox_dt / 1e9,
+                               "wall_frac": bytes_per_launch / vox_dt / HBM_PEAK,
+                               "row_major_order": {"sweeps_per_s": a.batch / vox_rm_dt,
+                                                   "us_per_step": vox_rm_dt * 1e6,
+                                                   "wall_frac": bytes_per_launch / vox_rm_dt / HBM_PEAK,
+                                                   "kernels_us": rm_us}},
         }
         if fused is not None:
             out["fused_feature_net"] = fused
+        if train is not None:
+            out["train_c3"] = train
+        if stress is not None:
+            out["stress_c5"] = stress
         if not a.no_cpu_baseline and ctx.world_size == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

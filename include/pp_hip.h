@@ -368,13 +368,47 @@ int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev,
                              const float *invstd_dev, float *dz_dev, float *dgamma_dev,
                              float *dbeta_dev, float *dbias_dev);
 
-/* Timing hooks for bench.py: with a ring of `slots` HIP event pairs
- * (slots = 0 disables), every pp_voxelize_dev call records an event pair on its
- * stream around the k_emit launch.  pp_ctx_read_emit_ms synchronises on the
- * recorded stop events, returns up to `cap` elapsed times (oldest first, in
- * milliseconds) and empties the ring. */
+/*
+ * Failure flag of the voxelizer launches on this context since the last check.  k_tile
+ * workgroups exchange their tiles' totals through status words; every wait is bounded, and a
+ * wait that ran out (or a ticket word that was not armed) sets a sticky flag instead of
+ * producing a wrong prefix silently.  pp_voxelize_check synchronises `stream`, returns
+ * PP_ERR_INTERNAL (and clears the flag) if any launch since the last check failed, else
+ * PP_OK.  The workspace re-arms itself on every call (k_emit zeroes the status words), so the
+ * call after a failed one is valid again.  pp_create_pillars_f64 checks by itself.
+ * (The reference's only analogue is to fail loudly: pillars.cpp:166-169.)
+ */
+int pp_voxelize_check(pp_ctx_t *ctx, void *stream);
+
+/*
+ * Limits of the voxelizer entry points (PP_ERR_VALUE beyond them):
+ *   batch                  <= PP_MAX_BATCH (32) sweeps per call
+ *   points per sweep       <  2^30
+ *   cell grid              <= 32768 cells per axis and <= 16 777 216 cells in all (a tile of
+ *                             up to 4096 cells lives in LDS, at most 4096 tiles)
+ *   max_points_per_pillar  <= 65536; dense output: max_pillars * max_points_per_pillar <= 1e8
+ *   fused feature net      exactly 64 output channels (model/model.py:28)
+ * One context per HIP stream: calls on one context must be stream-ordered.
+ */
+
+/* Timing hooks for bench.py: with a ring of `slots` HIP event pairs per kernel
+ * (slots = 0 disables), every pp_voxelize*_dev call brackets each of its three launches
+ * (PP_KERNEL_SPLIT, PP_KERNEL_TILE, PP_KERNEL_EMIT) with an event pair bound to the dispatch
+ * packet.  pp_ctx_read_kernel_ms synchronises on the recorded stop events and returns up to
+ * `cap` elapsed times of kernel `which` (oldest first, in milliseconds); reading
+ * PP_KERNEL_EMIT empties the ring.  pp_ctx_read_emit_ms = the PP_KERNEL_EMIT row. */
+#define PP_KERNEL_SPLIT 0
+#define PP_KERNEL_TILE 1
+#define PP_KERNEL_EMIT 2
 int pp_ctx_set_timing(pp_ctx_t *ctx, int slots);
+int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int cap, int *count);
 int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count);
+
+/* Test hooks (tests/test_gpu_voxelize.py): bound of a status-word wait in polls (0 = default),
+ * force the ticketed k_tile, and disarm sweep `sweep`'s ticket word so that the next call's
+ * k_tile must report through pp_voxelize_check instead of hanging or corrupting. */
+int pp_debug_set_scan_limit(pp_ctx_t *ctx, unsigned polls, int force_ticket);
+int pp_debug_poison_ticket(pp_ctx_t *ctx, void *stream, int sweep, unsigned value);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,57 @@
+"""bench.py's multi-rank path on one GPU: two ranks over gloo sharing device 0 (RCCL needs
+one GPU per rank; the driver runs that on the 8-GPU node).  Exercises what the N > 1 run does
+that N = 1 does not: the process group, per-rank MIOpen directories, sweep sharding, barrier +
+max-over-ranks timing, and -- in the train_c3 leg / --mode train -- the positive-count, gradient
+and loss-scalar all-reduces of BASELINE configs[2]/[3] (/root/reference train.py:88-89,120-121)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fwd", "train"])
+def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--train-steps", "2", "--backend", "gloo", "--mode", mode, "--no-cpu-baseline", "--no-stress"]
+    env = dict(os.environ, TMPDIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["config"]["global_batch"] == 2 * out["config"]["sweeps_per_gpu_per_step"]
+    assert out["value"] > 0 and abs(out["value"] - 3 * out["config"]["global_batch"] /
+                                    (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1 and 0 < rf["pipeline_frac"] <= rf["frac"]
+    assert set(rf["pipeline"]["kernels_us"]) == {"k_split", "k_tile", "k_emit"}
+    if mode == "fwd":
+        tr = out["train_c3"]
+        assert tr["collectives"]["world_size"] == 2 and tr["collectives"]["backend"] == "gloo"
+        assert tr["allreduce_ms"] > 0 and tr["ms_per_step"] > 0
+        assert "cpu_baseline" not in out and "stress_c5" not in out     # N = 1 legs only
+    # every rank used its own MIOpen directories under TMPDIR
+    roots = [d for d in os.listdir(tmp_path) if d.startswith("pp_miopen_")]
+    assert roots and sorted(os.listdir(os.path.join(tmp_path, roots[0]))) == ["rank0", "rank1"]

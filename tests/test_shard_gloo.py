@@ -74,3 +74,81 @@ def test_single_process_is_world_one(monkeypatch):
     assert (ctx.rank, ctx.world_size, ctx.distributed) == (0, 1, False)
     red = shard.reduce_loss_scalars(ctx, 1.0, 2.0, 3.0, 4.0, n_local=2)
     assert red.tolist() == [1.0, 2.0, 3.0, 4.0] and shard.max_over_ranks(ctx, 0.5) == 0.5
+
+
+def _dp_inputs(zero_pos_rank=None):
+    """Two 'sweeps' per rank of a toy head: cls [B,2*9,H,W], reg [B,2*8,H,W] from one shared
+    weight; targets with a different number of positives per rank."""
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Ac = 2, 3, 4, 2
+    x = [torch.randn(B, 5, H, W, generator=g) for _ in range(2)]
+    cls_t = [(torch.rand(B, H * W * Ac, 9, generator=g) > 0.8).float() for _ in range(2)]
+    reg_t = []
+    for r in range(2):
+        t = torch.randn(B, H * W * Ac, 9, generator=g)
+        t[..., 0] = (torch.rand(B, H * W * Ac, generator=g) > (0.5 if r == 0 else 0.9)).float()
+        t[..., 8] = (t[..., 8] > 0).float()
+        if zero_pos_rank == r:
+            t[..., 0] = 0
+        reg_t.append(t)
+    return x, cls_t, reg_t
+
+
+def _toy_head():
+    torch.manual_seed(3)
+    return torch.nn.Conv2d(5, 2 * 9 + 2 * 8, 1)
+
+
+def _dp_worker(rank, world, port, q, zero_pos_rank):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from pp_amd import shard
+    from pp_amd.loss import PPLoss
+    ctx = shard.init_from_env("gloo")
+    x, cls_t, reg_t = _dp_inputs(zero_pos_rank)
+    head, loss = _toy_head(), PPLoss(b_ort=0.5)
+    y = head(x[rank])
+    _, c, r, o, _ = loss(y[:, :18], y[:, 18:], cls_t[rank], reg_t[rank])
+    n_pos = (reg_t[rank][..., 0] == 1).sum()
+    shard.global_batch_loss(ctx, loss, c, r, o, n_pos).backward()
+    shard.allreduce_gradients(ctx, head.parameters())
+    q.put((rank, [p.grad.tolist() for p in head.parameters()]))
+    shard.barrier(ctx)
+    shard.shutdown(ctx)
+
+
+def _run_dp(zero_pos_rank):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, zero_pos_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the reference: ONE loss over the gathered batch (nn.DataParallel, train.py:88-89,144-147)
+    from pp_amd.loss import PPLoss
+    x, cls_t, reg_t = _dp_inputs(zero_pos_rank)
+    head, loss = _toy_head(), PPLoss(b_ort=0.5)
+    y = head(torch.cat(x))
+    loss(y[:, :18], y[:, 18:], torch.cat(cls_t), torch.cat(reg_t))[4].backward()
+    for rank, grads in res:
+        for g, p in zip(grads, head.parameters()):
+            assert torch.isfinite(torch.tensor(g)).all()
+            assert torch.allclose(torch.tensor(g), p.grad, rtol=1e-5, atol=1e-6), rank
+
+
+def test_sharded_gradients_equal_the_gathered_batch_loss():
+    """Ranks with different positive counts: weighting the positives' means by
+    n_pos_local * world / n_pos_global makes the averaged gradients those of the reference's
+    single loss over the gathered batch (plain averaging mis-weights them)."""
+    _run_dp(None)
+
+
+def test_rank_without_positives_contributes_zero_not_nan():
+    _run_dp(1)
