@@ -11,16 +11,15 @@
 // published CPU kernel: boxes in decreasing score order, a box is dropped when its
 // IoU with an already kept box exceeds the threshold, areas/intersections in f32.
 //
-// Kernels: k_score (one lane per anchor -> 44-bit sort key or sentinel), rocPRIM
-// device radix sort of the keys (library utility; keys are unique, so the order is
-// deterministic), k_nms (one workgroup, 256-candidate chunks: kept-list test, then
-// an in-chunk suppression matrix resolved serially), k_decode (one lane per kept box).
+// Kernels: k_score (one lane per anchor; the anchors above the threshold are compacted by
+// wave ballots into a candidate list of unique 50-bit keys {1 - score bits, anchor}), k_nms
+// (one workgroup: bitonic sort of the candidates -- in LDS up to 2048 of them, the usual
+// case, else in place in global memory -- then 256-candidate chunks: kept-list test, an
+// in-chunk suppression matrix resolved serially, and the box decode of the survivors).
 
 #include <cstring>
 
 #include "pp_common.h"
-
-#include <rocprim/rocprim.hpp>
 
 namespace pp {
 
@@ -28,6 +27,7 @@ using u64 = unsigned long long;
 constexpr u64 kSentinel = ~0ull;
 constexpr int kNmsThreads = 256;
 constexpr int kMaxOut = 1024;
+constexpr int kSortLds = 2048;  // candidates sorted in LDS; beyond that in place in global memory
 
 struct DecodeArgs {
   // element (channel ch, cell) of cls / reg at [ch*stride_c + cell*stride_pix]: NCHW planes
@@ -40,7 +40,9 @@ struct DecodeArgs {
   float pos_thresh, nms_thresh;
   int max_out;
   double canvas_height, x_step, y_step, x_min, y_min;
-  u64 *keys;
+  u64 *keys;      // candidate keys, capacity pow2 >= A (k_score appends, k_nms sorts)
+  int *ncand;     // number of candidates; zeroed again by k_nms
+  int cap;        // capacity of keys (power of two)
   int *kept;      // [max_out] anchor ids in keep order
   int *count;     // number kept
   double *boxes;  // [max_out][9] x,y,z,w,l,h,yaw,score,class
@@ -65,17 +67,24 @@ __device__ __forceinline__ void anchor_score(const DecodeArgs &d, int a, float &
 
 __global__ __launch_bounds__(256) void k_score(DecodeArgs d) {
   const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= d.A) return;
-  float s;
+  float s = 0.0f;
   int c;
-  anchor_score(d, a, s, c);
-  u64 key = kSentinel;
-  if (s > d.pos_thresh) {  // evaluate.py:237 (strict >)
+  if (a < d.A) anchor_score(d, a, s, c);
+  const bool cand = a < d.A && s > d.pos_thresh;  // evaluate.py:237 (strict >)
+  // compaction: one returning atomic per wave, ranks from the ballot
+  const u64 m = __ballot(cand);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(d.ncand, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (cand) {
     // decreasing score, then increasing anchor id; s in (0,1] so its bit pattern orders like s
+    // (30 significant bits of 0x3F800000 - bits(s), 20 bits of anchor id: unique 50-bit keys)
     const unsigned sb = (unsigned)__float_as_int(s);
-    key = ((u64)(0x3F800000u - sb) << 20) | (u64)a;
+    const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    d.keys[base + __popcll(m & lt)] = ((u64)(0x3F800000u - sb) << 20) | (u64)a;
   }
-  d.keys[a] = key;
 }
 
 struct NmsBox {
@@ -152,16 +161,41 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
   __shared__ int s_id[kNmsThreads];
   __shared__ int s_keptid[kMaxOut];
   __shared__ int s_nkept, s_done;
+  __shared__ u64 s_sort[kSortLds];
   const int t = threadIdx.x;
   if (t == 0) {
     s_nkept = 0;
     s_done = 0;
   }
   for (int i = t; i < d.max_out; i += kNmsThreads) s_keptid[i] = -1;
+  // the candidates in increasing key order = decreasing score (torchvision nms's order)
+  const int M = min(*d.ncand, d.cap);
+  int n2 = 1;
+  while (n2 < M) n2 <<= 1;
+  const bool in_lds = n2 <= kSortLds;
+  u64 *buf = in_lds ? s_sort : d.keys;
+  for (int i = t; i < n2; i += kNmsThreads) {
+    if (in_lds) s_sort[i] = i < M ? d.keys[i] : kSentinel;
+    else if (i >= M) d.keys[i] = kSentinel;
+  }
   __syncthreads();
-  for (int c0 = 0; c0 < d.A; c0 += kNmsThreads) {
+  if (t == 0) *d.ncand = 0;  // armed for the next call
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < (n2 >> 1); i += kNmsThreads) {
+        const int lo = 2 * i - (i & (j - 1));  // element index with bit j clear
+        const int hi = lo + j;
+        const u64 x = buf[lo], y = buf[hi];
+        if ((x > y) == ((lo & k) == 0)) {
+          buf[lo] = y;
+          buf[hi] = x;
+        }
+      }
+      __syncthreads();  // same workgroup, same CU: global writes are visible behind it too
+    }
+  for (int c0 = 0; c0 < M; c0 += kNmsThreads) {
     const int nk = s_nkept;
-    const u64 key = (c0 + t < d.A) ? d.keys[c0 + t] : kSentinel;
+    const u64 key = (c0 + t < M) ? buf[c0 + t] : kSentinel;
     const bool valid = key != kSentinel;
     const int a = (int)(key & 0xFFFFFull);
     NmsBox b = {0, 0, 0, 0, 0};
@@ -258,16 +292,14 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
       if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
     }
   } restore{prev, ctx->device};
-  size_t tmp_bytes = 0;
-  u64 *null_keys = nullptr;
-  if (rocprim::radix_sort_keys(nullptr, tmp_bytes, null_keys, null_keys, (size_t)A, 0, 44, stream) !=
-      hipSuccess) {
-    set_error("rocprim::radix_sort_keys size query failed");
-    return PP_ERR_HIP;
-  }
-  const size_t keys_bytes = ((size_t)A * 8 + 255) / 256 * 256;
-  int rc = ctx->decode_ws.ensure(2 * keys_bytes + tmp_bytes + 256);
+  size_t cap = 1;
+  while (cap < (size_t)A) cap <<= 1;
+  const size_t keys_bytes = cap * 8;
+  bool grew = false;
+  int rc = ctx->decode_ws.ensure(keys_bytes + 256, &grew);
   if (rc) return rc;
+  if (grew)  // the candidate counter starts at zero; k_nms leaves it at zero
+    PP_HIP_TRY(hipMemsetAsync(static_cast<char *>(ctx->decode_ws.ptr) + ctx->decode_ws.bytes - 256, 0, 256, stream));
   char *ws = static_cast<char *>(ctx->decode_ws.ptr);
   DecodeArgs d;
   d.cls = cls_dev;
@@ -293,17 +325,12 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
   d.x_min = prm->x_min;
   d.y_min = prm->y_min;
   d.keys = reinterpret_cast<u64 *>(ws);
-  u64 *sorted = reinterpret_cast<u64 *>(ws + keys_bytes);
+  d.ncand = reinterpret_cast<int *>(ws + ctx->decode_ws.bytes - 256);
+  d.cap = (int)cap;
   d.kept = kept_out;
   d.count = count_out;
   d.boxes = boxes_out;
   hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, stream, d);
-  if (rocprim::radix_sort_keys(ws + 2 * keys_bytes, tmp_bytes, d.keys, sorted, (size_t)A, 0, 44,
-                               stream) != hipSuccess) {
-    set_error("rocprim::radix_sort_keys failed");
-    return PP_ERR_HIP;
-  }
-  d.keys = sorted;
   hipLaunchKernelGGL(k_nms, dim3(1), dim3(kNmsThreads), 0, stream, d);  // + box decode
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;

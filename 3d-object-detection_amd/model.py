@@ -32,7 +32,9 @@ class _Epilogue:
         self._table = None
 
     def table(self, bias, bn):
-        ts = (bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        # num_batches_tracked: the fused training kernels update running_mean / running_var
+        # through raw pointers (no version bump), but every such step bumps the counter
+        ts = (bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)
         key = tuple((t.data_ptr(), t._version) for t in ts if t is not None)
         if key != self._key:
             with torch.no_grad():
@@ -111,7 +113,10 @@ def _weight_like(x, weight, cache):
 
 
 def _use_fused_epilogue(module, x):
-    return (not module.training) and module.fused_epilogue and x.is_cuda and x.dtype == torch.float32
+    # the epilogue kernels work in place through raw pointers: autograd never sees them, so
+    # they are for no-grad inference only (eval-mode fine-tuning / saliency take the modules)
+    return ((not module.training) and module.fused_epilogue and x.is_cuda and x.dtype == torch.float32
+            and not torch.is_grad_enabled())
 
 
 def _hip_ctx(dev):
@@ -309,9 +314,7 @@ class PPFeatureNet(nn.Module):
         ctx = _Epilogue._ctx.get(dev.index)
         if ctx is None:
             ctx = _Epilogue._ctx[dev.index] = _lib.Context(dev.index)
-        tab = self._params.get((self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
-                                self.bn1.running_mean, self.bn1.running_var),
-                               lambda: self.fused_params().to(dev))
+        tab = self.fused_table(dev)
         out = torch.empty((B, 64, P), dtype=torch.float32, device=dev)
         rc = _lib.lib().pp_pfn_dense_dev(
             ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
@@ -319,6 +322,15 @@ class PPFeatureNet(nn.Module):
             ctypes.c_void_p(out.data_ptr()))
         _lib.check(rc, "pp_pfn_dense_dev")
         return out
+
+    def fused_table(self, dev):
+        """``fused_params()`` on ``dev``, rebuilt whenever a weight or BatchNorm statistic of the
+        feature net changed (optimizer step, load_state_dict, a training forward: the fused
+        training kernels update the running statistics through raw pointers but bump
+        num_batches_tracked)."""
+        return self._params.get((self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
+                                 self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked),
+                                lambda: self.fused_params().to(dev))
 
     @torch.no_grad()
     def fused_params(self):
@@ -495,7 +507,8 @@ class PPDetectionHead(nn.Module):
         self._merged = _LayoutCache()
 
     def forward(self, x):
-        if self.training or not self.merge_heads or not x.is_cuda or not _is_nhwc(x):
+        if (self.training or not self.merge_heads or not x.is_cuda or not _is_nhwc(x)
+                or torch.is_grad_enabled()):   # the merged weights are built under no_grad
             return self.cls(x), self.reg(x)
         w, b = self._merged.get(
             (self.cls.weight, self.cls.bias, self.reg.weight, self.reg.bias),

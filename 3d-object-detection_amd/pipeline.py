@@ -40,7 +40,6 @@ class PillarPipeline:
         self._bufs = None
         self._fbufs = None
         self._cbuf = None
-        self._pfn_params = None
         #: forward_fused also fuses PPScatter and runs the backbone channels-last
         self.fused_scatter = True
 
@@ -73,8 +72,7 @@ class PillarPipeline:
         if self.voxelizer.data_mean is not None:
             # a data mean makes the zero-padded slots non-zero: nothing to skip, use the dense path
             return self.forward(points, n_points)
-        if self._pfn_params is None:
-            self._pfn_params = self.model.feature_net.fused_params().to(self.device)
+        pfn_params = self.model.feature_net.fused_table(self.device)   # tracks the weights' versions
         if points.dim() == 2:
             points = points.unsqueeze(0)
         B = points.shape[0]
@@ -86,10 +84,10 @@ class PillarPipeline:
             # ... and PPScatter too: the emit kernel writes each pillar's 64 features to its
             # channels-last canvas pixel
             H, W = self.model.scatter.h, self.model.scatter.w
-            canvas, _ = self.voxelizer.pfn_canvas(points, self._pfn_params, (H, W), n_points=n_points,
+            canvas, _ = self.voxelizer.pfn_canvas(points, pfn_params, (H, W), n_points=n_points,
                                                   out=(self._canvas(B, H, W), self._fbufs[1]))
             return self.model.forward_canvas(canvas)
-        feats, indices = self.voxelizer.pfn(points, self._pfn_params, n_points=n_points, out=self._fbufs)
+        feats, indices = self.voxelizer.pfn(points, pfn_params, n_points=n_points, out=self._fbufs)
         return self.model.forward_features(feats, indices)
 
     def _canvas(self, B, H, W):
@@ -99,8 +97,8 @@ class PillarPipeline:
         return self._cbuf
 
     def invalidate_fused_params(self):
-        """Call after changing the feature net's weights / BN statistics."""
-        self._pfn_params = None
+        """Kept for callers of the first release: the fused table now follows the weights'
+        versions by itself (PPFeatureNet.fused_table)."""
 
     def upload_ground_truth(self, g):
         """Host box arrays (centers / wlh / yaw / classes, canvas space) -> the device tuple
@@ -130,5 +128,4 @@ class PillarPipeline:
             shard.global_batch_loss(shard_ctx, self.loss, cls_loss, reg_loss, ort_loss, n_pos).backward()
         else:
             total.backward()
-        self._pfn_params = None   # the feature net is about to change under forward_fused
         return cls_loss.detach(), reg_loss.detach(), ort_loss.detach(), total.detach()

@@ -265,3 +265,92 @@ def test_inference_chain_raw_rows_to_boxes(gpu, oracle):
     assert n == len(ref_k) and n > 0
     assert np.array_equal(k_f.cpu().numpy()[:n], ref_k.astype(np.int32))
     assert np.allclose(b_f.cpu().numpy()[:n], ref_b, rtol=1e-5, atol=1e-5)
+
+
+def test_eval_mode_gradients_do_not_go_through_the_raw_pointer_kernels(gpu):
+    """model.eval() with autograd ON (frozen-BN fine-tuning, saliency): the in-place epilogue /
+    merged-head inference shortcuts must step aside, or the backward would differentiate a bare
+    convolution.  Gradients must equal those of the plain modules."""
+    import copy
+    import torch
+    import pp_amd.model as M
+    torch.manual_seed(11)
+    bb = M.PPBackbone(16, up3_op=M.up3_output_padding(64)).to(gpu).eval()
+    head = M.PPDetectionHead(96, 18, 16).to(gpu).eval()
+    with torch.no_grad():
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.normal_(0, 1.0)
+    ref_bb, ref_head = copy.deepcopy(bb), copy.deepcopy(head)
+    for m in list(ref_bb.modules()) + list(ref_head.modules()):
+        for flag in ("fused_epilogue", "merge_heads"):
+            if hasattr(m, flag):
+                setattr(m, flag, False)
+    x = torch.randn(2, 16, 64, 64, device=gpu).contiguous(memory_format=torch.channels_last)
+
+    def grads(b, h):
+        xx = x.clone().requires_grad_(True)
+        c, r = h(b(xx))
+        (c.square().sum() + r.sum()).backward()
+        return [xx.grad] + [p.grad for p in list(b.parameters()) + list(h.parameters())]
+
+    got, want = grads(bb, head), grads(ref_bb, ref_head)
+    assert all(g is not None for g in got)        # conv bias, BN affine and both heads get gradients
+    for g, w in zip(got, want):
+        assert torch.allclose(g, w, rtol=1e-4, atol=1e-5 * max(1.0, w.abs().max().item()))
+    with torch.no_grad():                          # and the shortcuts are still what inference runs
+        c1, r1 = head(bb(x))
+        c0, r0 = ref_head(ref_bb(x))
+    assert (c1 - c0).abs().max().item() <= 2e-4 * max(1.0, c0.abs().max().item())
+
+
+def test_fused_tables_follow_the_weights(gpu):
+    """The fused feature-net table and the per-block epilogue tables are caches: after an
+    optimizer step, a load_state_dict or a training forward (whose HIP kernels update the
+    running statistics through raw pointers) inference must see the NEW values."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    cfg = VoxelConfig.square(12.0, 0.2, 2500, 32)
+    pipe = PillarPipeline(cfg, device=gpu, seed=1, with_targets=True)
+    pts = torch.from_numpy(synth.lidar_like(9000, 12.0, 2)).to(gpu).unsqueeze(0)
+
+    def fused_vs_plain():
+        pipe.model.eval()
+        cf, rf = pipe.forward_fused(pts)
+        flags = []
+        for m in pipe.model.modules():             # the plain modules, no cache anywhere
+            for f in ("fused_epilogue", "merge_heads", "hip_eval", "fast_eval", "channels_last_inference"):
+                if hasattr(m, f):
+                    flags.append((m, f, getattr(m, f)))
+                    setattr(m, f, False)
+        cd, rd = pipe.forward(pts)
+        for m, f, v in flags:
+            setattr(m, f, v)
+        tol = 2e-4 * max(1.0, cd.abs().max().item())
+        assert (cf - cd).abs().max().item() <= tol and (rf - rd).abs().max().item() <= tol
+        return cf.clone()
+
+    a = fused_vs_plain()
+    # 1. a training step through the HIP training kernels + optimizer step
+    opt = torch.optim.SGD(pipe.model.parameters(), lr=0.05)
+    g = synth.gt_boxes(6, cfg.canvas_height, 0, margin=20.0)
+    pipe.model.train()
+    opt.zero_grad()
+    pipe.train_forward_backward(pts, [g])
+    opt.step()
+    b = fused_vs_plain()
+    assert (a - b).abs().max().item() > 0          # the step did change the network
+    # 2. BatchNorm recalibration only: training-mode forwards under no_grad, parameters untouched
+    pipe.model.train()
+    with torch.no_grad():
+        for _ in range(3):
+            pipe.model(*pipe.voxelize(pts))
+    c = fused_vs_plain()
+    assert (b - c).abs().max().item() > 0
+    # 3. load_state_dict
+    sd = {k: (v * 1.05 if v.dtype.is_floating_point else v) for k, v in pipe.model.state_dict().items()}
+    pipe.model.load_state_dict(sd)
+    fused_vs_plain()

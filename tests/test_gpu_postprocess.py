@@ -76,3 +76,26 @@ def test_postprocess_on_channels_last_slices(gpu, oracle):
     for b, k, n in ((b1, k1, n1), (b2, k2, n2)):
         assert torch.equal(k, k0) and torch.equal(n, n0) and torch.equal(b, b0)
     assert np.array_equal(k1.cpu().numpy()[:len(ref_k)], ref_k.astype(np.int32))
+
+
+@pytest.mark.parametrize("fm,bias,thresh", [(20, -4.5, 0.02), (30, -4.0, 0.05), (120, -1.0, 0.01)])
+def test_postprocess_low_score_thresholds(gpu, oracle, fm, bias, thresh):
+    """Scores at or below 0.25 need more than 24 bits of the key's score field: the candidates
+    must still come out in decreasing score order (the first release sorted 44 of the
+    50 key bits and mis-ordered them).  The (120, -1.0, 0.01) case has > 2048 candidates: the
+    in-place global-memory sort."""
+    import torch
+    from pp_amd.postprocess import Detector
+    anchors, acfg, cls, reg, H, _ = _setup(gpu, fm, 11, bias)
+    det = Detector(anchors, acfg, H, 0.2, 0.2, -0.1 * H, -0.1 * H, pos_thresh=thresh, device=gpu)
+    for _ in range(2):      # twice: the candidate counter must be armed again by the first call
+        boxes_d, kept_d, count_d = det(torch.from_numpy(cls).to(gpu), torch.from_numpy(reg).to(gpu))
+    torch.cuda.synchronize()
+    ref_b, ref_k = oracle.postprocess(cls, reg, anchors["centers"], anchors["wlh"], anchors["yaw"],
+                                      anchors["xy"], H, 0.2, 0.2, -0.1 * H, -0.1 * H, pos_thresh=thresh)
+    n = int(count_d.item())
+    assert n == len(ref_k) and n > 0
+    if fm <= 30:
+        assert n < 100 and (ref_b[:, 7] <= 0.25).any()      # low scores do make it into the output
+    assert np.array_equal(kept_d.cpu().numpy()[:n], ref_k.astype(np.int32))
+    assert np.allclose(boxes_d.cpu().numpy()[:n], ref_b, rtol=1e-5, atol=1e-5)
