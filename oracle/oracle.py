@@ -200,49 +200,91 @@ def dataset_voxel_stage(lidar_points, max_pillars, max_points, x_step, y_step,
 # boxes: lyft_dataset_sdk Box.bottom_corners (absent third-party, RECALLED)    #
 # --------------------------------------------------------------------------- #
 
+def _one_box_bottom_corners_xy(cx, cy, w, l, yaw):
+    """One yaw-only lyft Box: the SDK builds the corner template in the box frame
+    (x along the length, y along the width), rotates it with the orientation matrix and adds
+    the centre; bottom_corners() are template columns 2,3,7,6 = (+l/2,-w/2), (+l/2,+w/2),
+    (-l/2,+w/2), (-l/2,-w/2).  Scalar arithmetic, one corner at a time (deliberately not the
+    vectorised formula of the product's boxes.py: two derivations, one result)."""
+    import math
+    rot = ((math.cos(yaw), -math.sin(yaw)), (math.sin(yaw), math.cos(yaw)))   # Rz(yaw), xy block
+    out = []
+    for sx, sy in ((1.0, -1.0), (1.0, 1.0), (-1.0, 1.0), (-1.0, -1.0)):
+        bx, by = sx * l / 2.0, sy * w / 2.0
+        out.append((rot[0][0] * bx + rot[0][1] * by + cx, rot[1][0] * bx + rot[1][1] * by + cy))
+    return out
+
+
 def box_bottom_corners_xy(center, wlh, yaw):
-    """xy of Box.bottom_corners() for a yaw-only box: corners
-    (+l/2,-w/2), (+l/2,+w/2), (-l/2,+w/2), (-l/2,-w/2) rotated by yaw, plus the
-    centre -> counter-clockwise in a y-up frame.  lyft_dataset_sdk is not in the
-    image (call sites utils/box_utils.py:27,149): this is its published layout,
-    recalled and unverified."""
+    """xy of Box.bottom_corners() for yaw-only boxes -> [...,4,2], counter-clockwise in a y-up
+    frame.  lyft_dataset_sdk is not in the image (call sites utils/box_utils.py:27,149): this is
+    its published layout, recalled.  One independent pin exists in the reference itself:
+    make_anchor_boxes takes corners [2],[0] of an unrotated and [1],[3] of a 90-degree anchor as
+    (top-left, bottom-right) of the NMS rectangle (box_utils.py:152-155, evaluate.py:127-139),
+    which is only a valid x1<x2, y1<y2 box for this corner order (tests/test_host_logic.py)."""
     center = np.asarray(center, np.float64)
     wlh = np.asarray(wlh, np.float64)
     yaw = np.asarray(yaw, np.float64)
-    w, l = wlh[..., 0], wlh[..., 1]
-    lx = np.stack([l / 2, l / 2, -l / 2, -l / 2], -1)
-    ly = np.stack([-w / 2, w / 2, w / 2, -w / 2], -1)
-    c, s = np.cos(yaw)[..., None], np.sin(yaw)[..., None]
-    x = c * lx - s * ly + center[..., 0:1]
-    y = s * lx + c * ly + center[..., 1:2]
-    return np.stack([x, y], -1)
+    shape = np.broadcast_shapes(center.shape[:-1], wlh.shape[:-1], yaw.shape)
+    c2 = np.broadcast_to(center, shape + (center.shape[-1],)).reshape(-1, center.shape[-1])
+    w2 = np.broadcast_to(wlh, shape + (wlh.shape[-1],)).reshape(-1, wlh.shape[-1])
+    y2 = np.broadcast_to(yaw, shape).reshape(-1)
+    out = np.empty((c2.shape[0], 4, 2))
+    for i in range(c2.shape[0]):
+        out[i] = _one_box_bottom_corners_xy(float(c2[i, 0]), float(c2[i, 1]), float(w2[i, 0]),
+                                            float(w2[i, 1]), float(y2[i]))
+    return out.reshape(shape + (4, 2))
 
 
 def boxes_to_image_space(centers, wlh, yaw, canvas_height):
-    """utils/box_utils.py:19-32: flip y into image rows."""
-    centers = np.array(centers, np.float64, copy=True)
-    corners = box_bottom_corners_xy(centers, wlh, yaw)
-    centers[..., 1] = (canvas_height - 1) - centers[..., 1]
-    corners[..., 1] = (canvas_height - 1) - corners[..., 1]
+    """utils/box_utils.py:19-32: per box, corners = bottom_corners xy, then BOTH the centre's
+    and the corners' y become (CANVAS_HEIGHT - 1) - y (image rows)."""
+    centers = np.array(centers, np.float64, copy=True).reshape(-1, 3)
+    wlh = np.asarray(wlh, np.float64).reshape(-1, 3)
+    yaw = np.asarray(yaw, np.float64).reshape(-1)
+    corners = np.empty((centers.shape[0], 4, 2))
+    for i in range(centers.shape[0]):                                     # box_utils.py:24
+        bc = _one_box_bottom_corners_xy(centers[i, 0], centers[i, 1], wlh[i, 0], wlh[i, 1], yaw[i])
+        for k in range(4):
+            corners[i, k, 0] = bc[k][0]
+            corners[i, k, 1] = (canvas_height - 1) - bc[k][1]             # box_utils.py:29
+        centers[i, 1] = (canvas_height - 1) - centers[i, 1]               # box_utils.py:30
     return centers, corners
 
 
 def make_anchor_boxes(fm_height, fm_width, fm_scale, anchor_dims, anchor_yaws_deg,
                       anchor_zs):
-    """utils/box_utils.py:111-159: anchors ordered (y, x, d); returns
+    """utils/box_utils.py:111-159, loop for loop: anchors ordered (y, x, d); returns
     corners[A,4,2], centers[A,3], wlh[A,3], yaw[A] (radians)."""
-    dims = np.asarray(anchor_dims, np.float64)
-    nd = dims.shape[0]
-    yy, xx, dd = np.meshgrid(np.arange(fm_height), np.arange(fm_width), np.arange(nd),
-                             indexing="ij")
-    xc = (xx.reshape(-1) + 0.5) / fm_scale
-    yc = (yy.reshape(-1) + 0.5) / fm_scale
-    d = dd.reshape(-1)
-    centers = np.stack([xc, yc, np.asarray(anchor_zs, np.float64)[d]], -1)
-    wlh = dims[d]
-    yaw = np.deg2rad(np.asarray(anchor_yaws_deg, np.float64))[d]
-    corners = box_bottom_corners_xy(centers, wlh, yaw)
+    import math
+    nd = len(anchor_dims)
+    A = fm_height * fm_width * nd
+    corners, centers = np.empty((A, 4, 2)), np.empty((A, 3))
+    wlh, yaw = np.empty((A, 3)), np.empty(A)
+    i = 0
+    for y in range(fm_height):                                            # box_utils.py:133
+        for x in range(fm_width):                                         # :134
+            for d in range(nd):                                           # :135
+                xc, yc, zc = (x + 0.5) / fm_scale, (y + 0.5) / fm_scale, float(anchor_zs[d])  # :136-139
+                w, l, h = (float(v) for v in anchor_dims[d])              # :140-142
+                th = math.radians(float(anchor_yaws_deg[d]))              # :143-144 Quaternion(degrees=)
+                corners[i] = _one_box_bottom_corners_xy(xc, yc, w, l, th)  # :149-150
+                centers[i] = (xc, yc, zc)                                 # :151
+                wlh[i] = (w, l, h)
+                yaw[i] = th
+                i += 1
     return corners, centers, wlh, yaw
+
+
+def anchor_xy_rows(corners, anchor_yaws_deg):
+    """utils/box_utils.py:152-155: the (x1,y1,x2,y2) rows of anchor_xy.pkl -- corners 1 and 3 of
+    a rotated anchor (yaw > 0), corners 2 and 0 otherwise."""
+    nd = len(anchor_yaws_deg)
+    out = np.empty((corners.shape[0], 4))
+    for i in range(corners.shape[0]):
+        a, b = (1, 3) if anchor_yaws_deg[i % nd] > 0 else (2, 0)
+        out[i] = (*corners[i, a], *corners[i, b])
+    return out
 
 
 # --------------------------------------------------------------------------- #

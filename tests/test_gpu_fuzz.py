@@ -112,7 +112,8 @@ def test_random_target_assignment(gpu, oracle, case):
         gt["centers"][2] = anchors["centers"][i]
         gt["wlh"][2] = anchors["wlh"][i]
         gt["yaw"][2] = anchors["yaw"][i]
-    c_img, k_img = oracle.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
+    from pp_amd import boxes as _boxes   # same input arrays on both sides (see test_gpu_targets.py)
+    c_img, k_img = _boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
     ref_c, ref_r, _ = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
                                            anchors["yaw"], gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], H,
                                            pos_thresh=0.6)

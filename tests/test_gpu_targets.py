@@ -12,7 +12,11 @@ REG_TOL = 1e-6
 
 
 def _oracle_targets(O, anchors, gt, H, thresh=0.6):
-    c_img, k_img = O.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
+    # the SAME image-space box arrays the device path derives (pp_amd.boxes, pinned by hand-computed
+    # values and against the oracle's loop restatement in tests/test_host_logic.py): the bit-exact
+    # comparisons below are about the kernels, not about 1-ulp differences of two cos() routines
+    from pp_amd import boxes
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
     return O.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
                            anchors["yaw"], gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], H,
                            pos_thresh=thresh)
