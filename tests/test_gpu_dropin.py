@@ -136,3 +136,53 @@ def test_make_ious_host_dropin(gpu, oracle, pillars):
     with pytest.raises(ValueError):
         pillars.make_ious(anchors["corners"], k_img[:, ::-1].copy(), anchors["centers"], c_img,
                           np.zeros((A, G)))
+
+
+_DATA_PILLARS_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])              # the reference checkout's root: `data` is a package
+import data.pillars as pillars               # data/dataset.py:6
+assert pillars.__doc__ == "point pillars data prep functions" and pillars.__file__.startswith(sys.argv[1])
+assert "pp_amd" not in sys.modules and "torch" not in sys.modules     # nothing but the two .so files
+pts = np.array([[1.1, 2.1, 0.0, 10], [0.5, 0.5, 0, 1], [1.2, 2.2, 0.1, 11], [1.3, 2.3, 0.2, 12],
+                [4.0, 1, 0, 0], [1, 1, 1.0, 0], [-0.001, 1, 0, 0], [1.5, 2.5, 0.3, 13],
+                [0.25, 0.75, 0.5, 2], [1.8, 2.8, 0.4, 14]])
+lidar_points = np.asfortranarray(pts)        # an F-order view like dataset.py:88
+T, I = np.zeros((4, 3, 9)), np.zeros((4, 3)) # dataset.py:89-90
+assert pillars.create_pillars(lidar_points, T, I, 3, 4, 1, 1, 0, 0, -1, 4, 4, 1, np.int32(4)) is None
+assert np.allclose(T[0, 0], [1.1, 2.1, 0, 10, -0.1, -1.1, 0.28, 0.28, 0.2], atol=1e-12)   # SURVEY 8c V1
+assert np.allclose(T[0, :, 0], [1.1, 1.2, 1.3]) and T[1, 0, 5] == 2.5 and not T[2:].any()
+assert I.tolist() == [[1, 1, 1], [1, 0, 3], [0, 0, 0], [0, 0, 0]]
+a = np.array([[[7., 3], [7, 7], [3, 7], [3, 3]]])           # 4x4 anchor, counter-clockwise
+g = a[:, ::-1].copy()                                       # the same quad clockwise
+ious = np.full((1, 1), -1.0)
+pillars.make_ious(a, g, np.array([[5., 5, 0]]), np.array([[5., 5, 0]]), ious)             # box_utils.py:182
+assert ious[0, 0] == 1.0
+print("data.pillars ok")
+"""
+
+
+def test_import_as_data_pillars_in_the_reference_layout(gpu, tmp_path):
+    """INTEGRATION.md section 2 / install_mods.sh:8-10: the built module is MOVED into the
+    reference checkout's data/ package, next to libpp_hip.so, and the reference imports it as
+    ``data.pillars`` (data/dataset.py:6, utils/box_utils.py:11).  A fresh child process with
+    nothing of this repo on its path must be able to do exactly that: the $ORIGIN rpath of the
+    extension module finds libpp_hip.so beside it."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    import sys
+    import pp_amd
+    mod = pp_amd._lib.build_pybind_module()
+    data = tmp_path / "data"
+    data.mkdir()
+    (data / "__init__.py").write_text("")
+    shutil.copy(mod, data / os.path.basename(mod))
+    shutil.copy(pp_amd._lib.LIB_PATH, data / "libpp_hip.so")
+    assert len(glob.glob(str(data / "pillars*.so"))) == 1
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "PP_HIP_LIB", "LD_LIBRARY_PATH")}
+    r = subprocess.run([sys.executable, "-c", _DATA_PILLARS_CHILD, str(tmp_path)], cwd=str(tmp_path),
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "data.pillars ok" in r.stdout, r.stderr[-2000:]
