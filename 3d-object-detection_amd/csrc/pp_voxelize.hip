@@ -44,7 +44,10 @@ namespace pp {
 // constants                                                                  //
 // ------------------------------------------------------------------------- //
 constexpr int kWave = 64;
-constexpr int kChunk = 1024;                 // points per split workgroup, one per thread
+#ifndef PP_CHUNK
+#define PP_CHUNK 1024
+#endif
+constexpr int kChunk = PP_CHUNK;             // points per split workgroup, one per thread
 constexpr int kSplitThreads = kChunk;
 constexpr int kSplitWaves = kSplitThreads / kWave;
 constexpr int kMinTileSlots = 256, kMaxTileSlots = 4096;  // a tile's cells live in LDS (20 B each)

@@ -156,13 +156,13 @@ def voxelizer_wall(vox, points, out, iters=200, warm=20):
     return (time.perf_counter() - t1) / iters
 
 
-def static_traffic(batch):
+def static_traffic(key):
     """HBM bytes per k_emit launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate runs); a constant read from profiles/, NOT measured in this run"""
     tpath = os.path.join(ROOT, "profiles", "emit_traffic.json")
     try:
         t = json.load(open(tpath))
-        return t.get(f"batch{batch}"), t.get("source", "profiles/emit_traffic.json (static)")
+        return t.get(key), "static: " + t.get("source", "profiles/emit_traffic.json")
     except Exception:
         return None, None
 
@@ -343,14 +343,14 @@ def main():
                               f"P={C5['P']} N={C5['N']}, voxelizer only",
                   "sweeps_per_s": a.batch / dt5, "us_per_step": dt5 * 1e6,
                   "wall_frac": b5 / dt5 / HBM_PEAK,
-                  "roofline": roofline_record(k5, n5, b5)}
+                  "roofline": roofline_record(k5, n5, b5, *static_traffic(f"c5_batch{a.batch}"))}
         del v5, pts5, out5
         torch.cuda.empty_cache()
 
     if ctx.rank == 0:
         total_sweeps = a.steps * a.batch * ctx.world_size
         bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
-        traffic, tsrc = static_traffic(a.batch)
+        traffic, tsrc = static_traffic(f"batch{a.batch}")
         out = {
             "metric": METRIC, "value": total_sweeps / elapsed, "unit": "sweeps/s",
             "n_gpus": ctx.world_size, "steps": a.steps, "warmup": a.warmup,

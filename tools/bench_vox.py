@@ -19,7 +19,7 @@ ap.add_argument("--P", type=int, default=12000)
 ap.add_argument("--N", type=int, default=100)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=200)
-ap.add_argument("--order", type=int, default=0)
+ap.add_argument("--order", type=int, default=1)
 a = ap.parse_args()
 
 cfg = VoxelConfig.square(a.half, 0.2, a.P, a.N, order=a.order)
