@@ -344,3 +344,42 @@ def test_failed_tile_wait_is_reported_and_the_next_call_is_clean(gpu, oracle):
         _lib.check(L.pp_debug_set_scan_limit(vox._ctx.handle, 0, 0))
     ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 20.0, 0.2, order=1)
     assert _check_exact(again[0][0], again[1][0], ref_p, ref_i)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_more_than_one_window_of_chunks_in_a_tile(gpu, oracle, order):
+    """300 000 points on a 9x9-cell grid: a single tile whose run list spans 293 split chunks,
+    i.e. two windows of 256 in k_tile, all of it through the crowded-tile path (rounds fetched
+    from the split arrays, nothing cached), buckets of thousands of points in k_emit."""
+    rng = np.random.default_rng(42 + order)
+    n = 300000
+    pts = np.empty((n, 4), np.float32)
+    pts[:, 0] = rng.uniform(-0.8, 0.8, n)
+    pts[:, 1] = rng.uniform(-0.8, 0.8, n)
+    pts[:, 2] = rng.uniform(-1, 1, n)
+    pts[:, 3] = rng.uniform(0.1, 1, n)
+    pts[::7, 0] = 5.0                      # out of range rows in between
+    P, N = 40, 12
+    vox = _vox(gpu, 0.8, 0.2, P, N, order=order)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 0.8, 0.2, order=order)
+    assert cnt[0, 0] == m == 64 and cnt[0, 1] == n - len(pts[::7])
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+
+
+def test_maximum_batch(gpu, oracle):
+    """PP_MAX_BATCH = 32 sweeps in one call (grid.y), ragged."""
+    from pp_amd import synth
+    B = 32
+    clouds = np.stack([synth.lidar_like(3000, 8.0, 100 + i) for i in range(B)])
+    ns = [3000 - 37 * i for i in range(B)]
+    P, N = 700, 16
+    vox = _vox(gpu, 8.0, 0.2, P, N, order=1)
+    pil, idx, cnt = _run(gpu, vox, clouds, n_points=ns)
+    for b in (0, 1, 15, 30, 31):
+        ref_p, ref_i, m = oracle_stage(oracle, clouds[b][:ns[b]], P, N, 8.0, 0.2, order=1)
+        assert cnt[b, 0] == m
+        assert _check_exact(pil[b], idx[b], ref_p, ref_i), b
+    with pytest.raises(ValueError):
+        import torch
+        vox(torch.zeros((33, 8, 4), device=gpu))
