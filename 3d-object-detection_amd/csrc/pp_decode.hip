@@ -12,11 +12,14 @@
 // IoU with an already kept box exceeds the threshold, areas/intersections in f32.
 //
 // Kernels: k_score (one lane per anchor; the anchors above the threshold are compacted by
-// wave ballots into a candidate list of unique 50-bit keys {1 - score bits, anchor}), k_nms
-// (one workgroup: bitonic sort of the candidates -- in LDS up to 2048 of them, the usual
-// case, else in place in global memory -- then 256-candidate chunks: kept-list test, an
+// wave ballots into a candidate list of unique 50-bit keys {1 - score bits, anchor}),
+// k_sort_runs (runs of 16384 candidates, one workgroup each, bitonic sort in LDS), k_nms (one
+// workgroup: consumes the candidates in key order -- one run directly, up to eight runs
+// through an on-the-fly merge of their next 256 entries each, more than that after an
+// in-place bitonic sort in global memory -- in 256-candidate chunks: kept-list test, an
 // in-chunk suppression matrix resolved serially, and the box decode of the survivors).
 
+#include <algorithm>
 #include <cstring>
 
 #include "pp_common.h"
@@ -25,9 +28,12 @@ namespace pp {
 
 using u64 = unsigned long long;
 constexpr u64 kSentinel = ~0ull;
-constexpr int kNmsThreads = 256;
+constexpr int kNmsThreads = 1024;  // k_nms: four threads per candidate of a chunk
+constexpr int kChunkN = 256;      // candidates per NMS chunk
 constexpr int kMaxOut = 1024;
-constexpr int kSortLds = 2048;  // candidates sorted in LDS; beyond that in place in global memory
+constexpr int kRun = 16384;      // candidates per sorted run (128 KiB of LDS in k_sort_runs)
+constexpr int kSortThreads = 1024;
+constexpr int kMaxRuns = 8;       // runs k_nms merges on the fly (kMaxRuns * 256 keys in LDS)
 
 struct DecodeArgs {
   // element (channel ch, cell) of cls / reg at [ch*stride_c + cell*stride_pix]: NCHW planes
@@ -43,6 +49,7 @@ struct DecodeArgs {
   u64 *keys;      // candidate keys, capacity pow2 >= A (k_score appends, k_nms sorts)
   int *ncand;     // number of candidates; zeroed again by k_nms
   int cap;        // capacity of keys (power of two)
+  int run;        // candidates per sorted run = min(kRun, cap)
   int *kept;      // [max_out] anchor ids in keep order
   int *count;     // number kept
   double *boxes;  // [max_out][9] x,y,z,w,l,h,yaw,score,class
@@ -85,6 +92,41 @@ __global__ __launch_bounds__(256) void k_score(DecodeArgs d) {
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     d.keys[base + __popcll(m & lt)] = ((u64)(0x3F800000u - sb) << 20) | (u64)a;
   }
+}
+
+// ascending bitonic sort of buf[0..n2) (n2 a power of two) by one workgroup of T threads;
+// LDS or global memory of that workgroup (same CU: visible behind the barrier)
+template <int T>
+__device__ __forceinline__ void bitonic_sort(u64 *buf, int n2, int t) {
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < (n2 >> 1); i += T) {
+        const int lo = 2 * i - (i & (j - 1));  // element index with bit j clear
+        const int hi = lo + j;
+        const u64 x = buf[lo], y = buf[hi];
+        if ((x > y) == ((lo & k) == 0)) {
+          buf[lo] = y;
+          buf[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// run r = candidates [r*run, (r+1)*run): sorted in LDS, written back padded with sentinels
+__global__ __launch_bounds__(kSortThreads) void k_sort_runs(DecodeArgs d, int run) {
+  extern __shared__ __attribute__((aligned(16))) u64 s_run[];
+  const int M = min(*d.ncand, d.cap);
+  const int base = blockIdx.x * run;
+  if (base >= M || M > kMaxRuns * run) return;  // nothing here / too many runs: k_nms sorts in place
+  const int n = min(run, M - base);
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  const int t = threadIdx.x;
+  for (int i = t; i < n2; i += kSortThreads) s_run[i] = i < n ? d.keys[base + i] : kSentinel;
+  __syncthreads();
+  bitonic_sort<kSortThreads>(s_run, n2, t);
+  for (int i = t; i < run; i += kSortThreads) d.keys[base + i] = i < n2 ? s_run[i] : kSentinel;
 }
 
 struct NmsBox {
@@ -152,50 +194,62 @@ __device__ void decode_row(const DecodeArgs &d, int i, int a) {
   o[8] = (double)klass;
 }
 
+// One workgroup; chunks of kChunkN = 256 candidates in key order, four threads per candidate.
 __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
   __shared__ NmsBox s_kept[kMaxOut];
-  __shared__ NmsBox s_chunk[kNmsThreads];
-  __shared__ u64 s_mask[kNmsThreads][kNmsThreads / 64];  // s_mask[i]: later chunk members i suppresses
-  __shared__ int s_alive[kNmsThreads];
-  __shared__ u64 s_alive_mask[kNmsThreads / 64];  // the same as wave ballots, for the serial pass
-  __shared__ int s_id[kNmsThreads];
+  __shared__ NmsBox s_chunk[kChunkN];
+  __shared__ u64 s_mask[kChunkN][kChunkN / 64];  // s_mask[i]: later chunk members i suppresses
+  __shared__ int s_alive[kChunkN];
+  __shared__ u64 s_alive_mask[kChunkN / 64];     // the same as ballots, for the serial pass
+  __shared__ int s_id[kChunkN];
   __shared__ int s_keptid[kMaxOut];
-  __shared__ int s_nkept, s_done;
-  __shared__ u64 s_sort[kSortLds];
+  __shared__ int s_nkept, s_done, s_full;
+  __shared__ u64 s_merge[kMaxRuns * kChunkN];
+  __shared__ int s_head[kMaxRuns];
   const int t = threadIdx.x;
+  const int c = t >> 2, sub = t & 3;             // candidate of the chunk, quarter of its work
   if (t == 0) {
     s_nkept = 0;
     s_done = 0;
   }
+  if (t < kMaxRuns) s_head[t] = 0;
   for (int i = t; i < d.max_out; i += kNmsThreads) s_keptid[i] = -1;
   // the candidates in increasing key order = decreasing score (torchvision nms's order)
   const int M = min(*d.ncand, d.cap);
-  int n2 = 1;
-  while (n2 < M) n2 <<= 1;
-  const bool in_lds = n2 <= kSortLds;
-  u64 *buf = in_lds ? s_sort : d.keys;
-  for (int i = t; i < n2; i += kNmsThreads) {
-    if (in_lds) s_sort[i] = i < M ? d.keys[i] : kSentinel;
-    else if (i >= M) d.keys[i] = kSentinel;
-  }
+  const int run = d.run;
+  const int nruns = (M + run - 1) / run;
   __syncthreads();
   if (t == 0) *d.ncand = 0;  // armed for the next call
-  for (int k = 2; k <= n2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < (n2 >> 1); i += kNmsThreads) {
-        const int lo = 2 * i - (i & (j - 1));  // element index with bit j clear
-        const int hi = lo + j;
-        const u64 x = buf[lo], y = buf[hi];
-        if ((x > y) == ((lo & k) == 0)) {
-          buf[lo] = y;
-          buf[hi] = x;
-        }
-      }
-      __syncthreads();  // same workgroup, same CU: global writes are visible behind it too
-    }
-  for (int c0 = 0; c0 < M; c0 += kNmsThreads) {
+  if (nruns > kMaxRuns) {    // k_sort_runs left it alone: one in-place sort of everything
+    int n2 = 1;
+    while (n2 < M) n2 <<= 1;
+    for (int i = M + t; i < n2; i += kNmsThreads) d.keys[i] = kSentinel;
+    __syncthreads();
+    bitonic_sort<kNmsThreads>(d.keys, n2, t);
+  }
+  const bool merging = nruns > 1 && nruns <= kMaxRuns;
+  int m2 = 1;
+  while (m2 < nruns * kChunkN) m2 <<= 1;
+  for (int c0 = 0; c0 < M; c0 += kChunkN) {
     const int nk = s_nkept;
-    const u64 key = (c0 + t < M) ? buf[c0 + t] : kSentinel;
+    u64 key;
+    if (merging) {
+      // the next 256 keys overall are among the next 256 of every run: sort those (run id
+      // in the low 4 bits; keys are unique, so the order of the keys proper is unchanged)
+      for (int i = t; i < m2; i += kNmsThreads) {
+        const int r = i / kChunkN, idx = s_head[min(r, kMaxRuns - 1)] + (i % kChunkN);
+        u64 k0 = kSentinel;
+        if (r < nruns && idx < run) k0 = d.keys[(size_t)r * run + idx];
+        s_merge[i] = k0 == kSentinel ? kSentinel : (k0 << 4) | (u64)r;
+      }
+      __syncthreads();
+      bitonic_sort<kNmsThreads>(s_merge, m2, t);
+      const u64 k1 = s_merge[c];
+      key = k1 == kSentinel ? kSentinel : k1 >> 4;
+      if (sub == 0 && k1 != kSentinel) atomicAdd(&s_head[(int)(k1 & 15ull)], 1);
+    } else {
+      key = (c0 + c < M) ? d.keys[c0 + c] : kSentinel;
+    }
     const bool valid = key != kSentinel;
     const int a = (int)(key & 0xFFFFFull);
     NmsBox b = {0, 0, 0, 0, 0};
@@ -203,34 +257,52 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
     if (valid) {
       b = load_box(d, a);
       alive = 1;
-      for (int k = 0; k < nk && alive; ++k)
+      for (int k = sub; k < nk && alive; k += 4)   // this thread's quarter of the kept list
         if (suppresses(s_kept[k], b, d.nms_thresh)) alive = 0;
     }
-    s_chunk[t] = b;
-    s_alive[t] = alive;
-    s_id[t] = a;
     {
+      // a candidate is alive when all four quarters say so (the four threads are adjacent lanes)
       const u64 bal = __ballot(alive != 0);
-      if ((t & 63) == 0) s_alive_mask[t >> 6] = bal;
+      const int lane = t & 63;
+      alive = ((bal >> (lane & ~3)) & 0xFull) == 0xFull;
+      if (sub == 0) {
+        s_chunk[c] = b;
+        s_alive[c] = alive;
+        s_id[c] = a;
+      }
     }
+    if (t == kNmsThreads - 1) s_full = valid;       // the chunk's last candidate exists
     __syncthreads();
-    // suppression matrix inside the chunk: bit j of s_mask[t] = (j > t and t suppresses j)
+    if (t < kChunkN / 64) {
+      u64 m = 0;
+      for (int i = 0; i < 64; ++i) m |= (u64)(s_alive[t * 64 + i] != 0) << i;
+      s_alive_mask[t] = m;
+    }
+    // suppression matrix inside the chunk: bit j of s_mask[c] = (j > c and c suppresses j);
+    // the four threads of a row take every fourth column and OR their words together
     {
-      u64 m[kNmsThreads / 64] = {0, 0, 0, 0};
+      u64 m[kChunkN / 64] = {0, 0, 0, 0};
       if (alive) {
-        for (int j = t + 1; j < kNmsThreads; ++j)
+        for (int j = c + 1 + sub; j < kChunkN; j += 4)
           if (s_alive[j] && suppresses(b, s_chunk[j], d.nms_thresh)) m[j >> 6] |= 1ull << (j & 63);
       }
 #pragma unroll
-      for (int w = 0; w < kNmsThreads / 64; ++w) s_mask[t][w] = m[w];
+      for (int w = 0; w < kChunkN / 64; ++w) {
+        unsigned lo = (unsigned)m[w], hi = (unsigned)(m[w] >> 32);
+        lo |= __shfl_xor(lo, 1, 64);
+        hi |= __shfl_xor(hi, 1, 64);
+        lo |= __shfl_xor(lo, 2, 64);
+        hi |= __shfl_xor(hi, 2, 64);
+        if (sub == 0) s_mask[c][w] = ((u64)hi << 32) | lo;
+      }
     }
     __syncthreads();
     if (t == 0) {
       // greedy pass in score order over the ALIVE members only (ballot words, lowest bit first)
-      u64 removed[kNmsThreads / 64] = {0, 0, 0, 0};
+      u64 removed[kChunkN / 64] = {0, 0, 0, 0};
       int n = s_nkept;
 #pragma unroll
-      for (int w0 = 0; w0 < kNmsThreads / 64; ++w0) {
+      for (int w0 = 0; w0 < kChunkN / 64; ++w0) {
         u64 pend = s_alive_mask[w0];
         while (pend && n < d.max_out) {
           const int bpos = __builtin_ctzll(pend);
@@ -241,15 +313,14 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
           s_keptid[n] = s_id[i];
           ++n;
 #pragma unroll
-          for (int w = 0; w < kNmsThreads / 64; ++w) removed[w] |= s_mask[i][w];
+          for (int w = 0; w < kChunkN / 64; ++w) removed[w] |= s_mask[i][w];
         }
       }
       s_nkept = n;
-      // sorted keys: the first sentinel ends the candidates
       s_done = (n >= d.max_out) ? 1 : 0;
     }
     __syncthreads();
-    if (s_done || !__syncthreads_or(valid && t == kNmsThreads - 1)) break;
+    if (s_done || !s_full) break;  // enough boxes, or the candidates ran out inside this chunk
   }
   __syncthreads();
   if (t == 0) *d.count = s_nkept;
@@ -331,6 +402,17 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
   d.count = count_out;
   d.boxes = boxes_out;
   hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, stream, d);
+  d.run = (int)std::min<size_t>(kRun, cap);
+  {
+    static thread_local bool armed = false;  // 128 KiB of dynamic LDS needs the attribute
+    if (!armed) {
+      PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_runs),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kRun * 8));
+      armed = true;
+    }
+  }
+  const unsigned nrun_wgs = (unsigned)std::min<size_t>(kMaxRuns, cap / d.run);
+  hipLaunchKernelGGL(k_sort_runs, dim3(nrun_wgs), dim3(kSortThreads), (size_t)d.run * 8, stream, d, d.run);
   hipLaunchKernelGGL(k_nms, dim3(1), dim3(kNmsThreads), 0, stream, d);  // + box decode
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;

@@ -24,4 +24,5 @@ for _ in range(50):
     out = [det(cls[i], reg[i]) for i in range(4)]
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 200
-print(f"decode: {dt*1e6:.1f} us per sample; candidates kept {[int(o[2].item()) for o in out]}")
+ncand = [int((torch.sigmoid(cls[i].float()).reshape(acfg.per_cell, 9, -1).amax(1) > 0.2).sum().item()) for i in range(4)]
+print(f"decode: {dt*1e6:.1f} us per sample; candidates {ncand}, kept {[int(o[2].item()) for o in out]}")
