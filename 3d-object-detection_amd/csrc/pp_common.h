@@ -64,17 +64,10 @@ struct pp_ctx {
   // voxelizer scratch, laid out by VoxWorkspace (pp_voxelize.hip)
   pp::DevBuf vox_ws;
   unsigned long long vox_layout_key[6] = {0, 0, 0, 0, 0, 0};
-  unsigned scan_spin_limit = 1u << 22;  // polls of one status word before k_tile gives up
-  // per k_tile instance [f64 input][4/8/16 waves][ticket, no ticket]: dynamic-LDS attribute set
-  // so far; the no-ticket instances also cache their resident capacity for that LDS size
-  struct TileKernelInfo {
-    size_t lds_armed = 0, capacity_lds = 0;
-    long long capacity = 0;
-  } tile_info[2][3][2];
+  // dynamic-LDS attribute set so far, per kernel instance: k_tile [f64 input][4/8/16 waves], k_split [f64 input]
+  size_t tile_lds_armed[2][3] = {{0, 0, 0}, {0, 0, 0}};
   size_t split_lds_armed[2] = {0, 0};
-  int force_tile_waves = 0;  // development knobs: PP_TILE_WAVES / PP_FORCE_TICKET in the environment
-  int force_ticket = 0;
-  size_t ws_ticket_off = 0, ws_errflag_off = 0;  // where the current layout keeps them (pp_voxelize_check, test hooks)
+  int force_tile_waves = 0;  // development knob: PP_TILE_WAVES in the environment
   size_t dbg_stamps_off = 0, dbg_stamps_bytes = 0;  // PP_STAMPS builds (tools/lab)
   // host drop-in staging
   pp::DevBuf stage_in, stage_out, stage_out2;

@@ -116,7 +116,6 @@ extern "C" int pp_ctx_create(int device, pp_ctx_t **out) {
     const int v = atoi(e);
     if (v == 4 || v == 8 || v == 16) c->force_tile_waves = v;
   }
-  if (const char *e = getenv("PP_FORCE_TICKET")) c->force_ticket = atoi(e) != 0;
   *out = c;
   return PP_OK;
 }
@@ -202,14 +201,4 @@ extern "C" int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int ca
 
 extern "C" int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count) {
   return pp_ctx_read_kernel_ms(ctx, PP_KERNEL_EMIT, ms, cap, count);
-}
-
-extern "C" int pp_debug_set_scan_limit(pp_ctx_t *ctx, unsigned polls, int force_ticket) {
-  if (!ctx) {
-    set_error("ctx is NULL");
-    return PP_ERR_VALUE;
-  }
-  ctx->scan_spin_limit = polls ? polls : (1u << 22);
-  ctx->force_ticket = force_ticket != 0;
-  return PP_OK;
 }

@@ -71,17 +71,6 @@ struct NPoints {
   int n[PP_MAX_BATCH];
 };
 
-// status word of the look-back scan: [63:62] flag, [61:31] points, [30:0] pillars
-constexpr u64 kFlagAgg = 1ull << 62;
-constexpr u64 kFlagPre = 2ull << 62;
-__device__ __forceinline__ u64 st_pack(u64 flag, u64 v) {
-  // v = points << 32 | pillars
-  return flag | ((v >> 32) << 31) | (v & 0x7FFFFFFFull);
-}
-__device__ __forceinline__ u64 st_payload(u64 s) {
-  return (((s >> 31) & 0x7FFFFFFFull) << 32) | (s & 0x7FFFFFFFull);
-}
-
 __device__ __forceinline__ void wave_sync() {
   // LDS operations of one wave execute in program order; this only stops the
   // compiler from moving LDS accesses across a cross-lane hand-off.
@@ -311,11 +300,13 @@ __host__ __device__ inline size_t tile_lds_bytes(int tile_slots, int waves) {
 
 // Stages window `win` of the tile's row (ONE wave); returns the number of positions in it.
 __device__ __forceinline__ int tile_stage_window(const int2 *__restrict__ row, int nch, int win,
-                                                 const TileLds &L, int lane) {
+                                                 const TileLds &L, int lane, unsigned *offsets) {
   const int c0 = win * kWin + 4 * lane;
   int2 e[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) e[i] = (c0 + i < nch) ? row[c0 + i] : make_int2(0, 0);
+  // the runs' offsets in their chunks = points of all earlier tiles in those chunks
+  *offsets = (unsigned)(wave_sum64((u64)(unsigned)(e[0].x + e[1].x + e[2].x + e[3].x)) & 0xFFFFFFFFull);
   const int loc = e[0].y + e[1].y + e[2].y + e[3].y;
   int incl = loc;
 #pragma unroll
@@ -346,35 +337,36 @@ __device__ __forceinline__ int tile_find(const TileLds &L, int j) {
 __device__ __forceinline__ unsigned byte_sum(unsigned v) { return __builtin_amdgcn_sad_u8(v, 0u, 0u); }
 
 // One workgroup of WAVES waves per tile (1 << tile_shift consecutive slots, all of them
-// in LDS).  TICKET: tile ids are handed out by an atomic ticket, so that a workgroup only
-// ever waits for workgroups that have started; without it the tile is blockIdx.x, which
-// the launcher uses only when the whole grid is resident at once.
+// in LDS).  Tiles need nothing from each other:
 //
 //   pass 1   population of the tile's cells (order-free LDS atomics); {source, cell} of
-//            the first kCapT positions stay in LDS
-//   scan     prefix sums over the cells -> bucket starts and pillar indices; the tile's
-//            totals are published, those of ALL earlier tiles summed (no chain)
+//            the first kCapT positions stay in LDS.  The tile's first place in the CSR array
+//            comes for free: k_split stored, per chunk, the number of points of all EARLIER
+//            tiles (the run's offset in the chunk), so the sum of the tile's offsets over the
+//            chunks is the number of points before the tile
+//   scan     prefix sums over the cells -> bucket starts, descriptors {slot, start, count} of
+//            the occupied cells in a tile-local list, {points, occupied cells} of the tile
+//            (k_emit prefix-sums the latter over the tiles: the pillar index of a cell is the
+//            only thing that depends on other tiles, and only k_emit needs it)
 //   pass 2   every point to bucket start + rank, rank in input order: rounds of THREADS
 //            consecutive positions, wave w takes positions [64w, 64w+64) of the round; a
 //            point's rank = cursor (earlier rounds) + points of its cell in earlier waves of
 //            the round (byte histogram column) + earlier lanes of its wave (ballots)
-template <typename T, int WAVES, bool TICKET>
+template <typename T, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void k_tile(
-    NPoints np, GridGeom g, int P, int ncap, int nchunks_cap, const int *__restrict__ kslot,
+    NPoints np, GridGeom g, int ncap, int nchunks_cap, const int *__restrict__ kslot,
     const typename Rec4<T>::type *__restrict__ kpts, const int2 *__restrict__ mat,
-    typename Rec4<T>::type *__restrict__ sorted_pts, int4 *__restrict__ pillar_meta,
-    u64 *status, unsigned *ticket, int2 *__restrict__ totals, int *errflag,
-    unsigned spin_limit, u64 *stamps) {
+    typename Rec4<T>::type *__restrict__ sorted_pts, int4 *__restrict__ tile_meta,
+    u64 *__restrict__ tile_agg, u64 *stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned tile_smem[];
   using Rec = typename Rec4<T>::type;
   constexpr int THREADS = WAVES * kWave;
   constexpr int HW = WAVES / 4;  // dwords of a cell's per-wave byte counts
-  __shared__ unsigned s_ticket;
   __shared__ int s_G;
+  __shared__ unsigned s_before;  // points of all earlier tiles
   __shared__ u64 s_wave[WAVES];
-  __shared__ u64 s_excl;
   const int b = blockIdx.y;
-  const int nwg = g.ntiles;
+  const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   [[maybe_unused]] const int stamp_nx = g.ntiles;
   PP_STAMP(0);
@@ -386,21 +378,9 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
   L.srcb = L.pre + kWin;
   L.csrc = L.srcb + kWin;
   L.cq = reinterpret_cast<unsigned short *>(L.csrc + kCapT);
-  int tile = blockIdx.x;
-  if (TICKET) {
-    if (tid == 0) s_ticket = atomicAdd(&ticket[b], 1u);
-  }
   for (int q = tid; q < (1 + HW) * TS; q += THREADS) L.cur[q] = 0u;  // cur and hist
-  if (TICKET) {
-    __syncthreads();
-    tile = (int)s_ticket;
-    if (tile >= nwg) {  // the ticket word was not armed: refuse to touch anything
-      if (tid == 0) atomicExch(errflag, 2);
-      return;
-    }
-  }
+  if (tid == 0) s_before = 0u;
   PP_STAMP(1);
-  u64 *st = status + (int64_t)b * nwg;
   const int n = np.n[b];
   const int nch = (n + kChunk - 1) / kChunk;
   const int nwin = (nch + kWin - 1) / kWin;
@@ -413,8 +393,12 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
   for (int win = 0; win < nwin; ++win) {
     __syncthreads();  // window arrays free (and cur/hist zeroed)
     if (w == 0) {
-      const int G0 = tile_stage_window(row, nch, win, L, lane);
-      if (lane == 0) s_G = G0;
+      unsigned offs = 0;
+      const int G0 = tile_stage_window(row, nch, win, L, lane, &offs);
+      if (lane == 0) {
+        s_G = G0;
+        s_before += offs;
+      }
     }
     __syncthreads();
     const int G = s_G;
@@ -468,65 +452,23 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     if (k < w) wave_off += s_wave[k];
     agg += s_wave[k];
   }
-  // publish the tile's totals, sum those of ALL earlier tiles (no chain: every tile
-  // publishes as soon as its own counts are known)
-  if (w == 0) {
-    if (lane == 0)
-      __hip_atomic_store(&st[tile], st_pack(kFlagAgg, agg), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    u64 acc = 0;
-    bool failed = false;
-    for (int j0 = lane; j0 < tile; j0 += 4 * kWave) {
-      u64 sv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = j0 + k * kWave;
-        sv[k] = (j < tile) ? __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                           : kFlagAgg;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = j0 + k * kWave;
-        if (j < tile) {
-          unsigned spins = 0;
-          while ((sv[k] >> 62) == 0 && ++spins < spin_limit)
-            sv[k] = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((sv[k] >> 62) == 0) failed = true;
-          acc += st_payload(sv[k]);
-        }
-      }
-    }
-    const u64 excl = wave_sum64(acc);
-    if (__any(failed) && lane == 0) atomicExch(errflag, 1);
-    if (lane == 0) s_excl = excl;
-  }
-  __syncthreads();
-  PP_STAMP(5);
-  if (tile == nwg - 1 && tid == 0) {
-    const u64 tot = s_excl + agg;
-    totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
-  }
-  // descriptors of the tile's non-empty cells; the counters become bucket cursors
+  if (tid == 0) tile_agg[(int64_t)b * g.ntiles + tile] = agg;  // {points << 32 | occupied cells}
+  // descriptors of the tile's occupied cells (tile-local list); the counters become cursors
+  const unsigned sbase = s_before;
   if (tid * cpt < TS) {
-    const u64 base = s_excl + wave_off + (inc - mine);
-    int p = (int)(base & 0xFFFFFFFFull);
-    unsigned s = (unsigned)(base >> 32);
+    const u64 base = wave_off + (inc - mine);
+    int k = (int)(base & 0xFFFFFFFFull);
+    unsigned st = sbase + (unsigned)(base >> 32);
+    int4 *tm = tile_meta + ((int64_t)b * g.ntiles + tile) * TS;
     for (int e = 0; e < cpt; ++e) {
       const int q = tid * cpt + e;
       const unsigned c = L.cur[q];
-      unsigned cur = kDropped;  // empty, or beyond max_pillars: its points are dropped
-      if (c > 0) {
-        if (p < P) {
-          pillar_meta[(int64_t)b * P + p] = make_int4(tile * TS + q, (int)s, (int)c, 0);
-          cur = s;
-        }
-        ++p;
-        s += c;
-      }
-      L.cur[q] = cur;
+      if (c > 0) tm[k++] = make_int4(tile * TS + q, (int)st, (int)c, 0);
+      L.cur[q] = st;
+      st += c;
     }
   }
-  PP_STAMP(6);
+  PP_STAMP(5);
   // pass 2
   Rec *sp = sorted_pts + (int64_t)b * ncap;
   const u64 below = lanes_below(lane);
@@ -543,7 +485,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     const bool leader = v && rank == 0;
     if (leader) histb[q * WAVES + w] = (unsigned char)__popcll(peers);  // <= 64
     __syncthreads();
-    unsigned before = 0, total = 0, old = kDropped;
+    unsigned before = 0, total = 0, old = 0;
     if (v) {
 #pragma unroll
       for (int i = 0; i < HW; ++i) {
@@ -555,10 +497,10 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     }
     __syncthreads();
     if (leader) {
-      histb[q * WAVES + w] = 0;                                    // self-cleaning
-      if (before == 0 && old != kDropped) L.cur[q] = old + total;  // first wave of the cell this round
+      histb[q * WAVES + w] = 0;                 // self-cleaning
+      if (before == 0) L.cur[q] = old + total;  // first wave of the cell this round
     }
-    if (v && old != kDropped) sp[old + before + (unsigned)rank] = rec;
+    if (v) sp[old + before + (unsigned)rank] = rec;
   };
   // rounds over a list of `count` positions; fetch(j, q, rec) reads position j.
   // kP2 rounds are fetched ahead of the one being placed.
@@ -595,7 +537,8 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     for (int win = 0; win < nwin; ++win) {
       __syncthreads();
       if (w == 0) {
-        const int G0 = tile_stage_window(row, nch, win, L, lane);
+        unsigned offs = 0;
+        const int G0 = tile_stage_window(row, nch, win, L, lane, &offs);
         if (lane == 0) s_G = G0;
       }
       __syncthreads();
@@ -628,12 +571,11 @@ struct EmitArgs {
   GridGeom g;
   NPoints np;
   int P, N, ncap;
-  const int4 *pillar_meta;  // [B][P] {slot, start, count, -}
-  const int2 *totals;       // [B]    {cells, points}
+  const int4 *tile_meta;    // [B][tiles][tile slots] {slot, start, count, -} of a tile's occupied cells
+  const u64 *tile_agg;      // [B][tiles] {points << 32 | occupied cells}
+  int4 *pillar_meta;        // [B][P] the same descriptors in pillar order (written in compact mode: host path)
+  int2 *totals;             // [B] {cells, points}, written here
   const void *sorted_pts;   // [B][ncap] point record (x,y,z,r), CSR order, input order per bucket
-  u64 *status;              // [B][nwg_tile] look-back words of k_tile, re-armed here
-  unsigned *ticket;         // [B]
-  int nwg_tile;
   // dense mode
   float *out;          // [B][9][P][N]
   long long *idx_out;  // [B][P][3]
@@ -1010,21 +952,80 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int N = a.N, P = a.P;
-  // (0) re-arm k_tile's look-back words for the next call (also after a failed one)
-  if (blockIdx.x == 0) {
-    for (int i = tid; i < a.nwg_tile; i += kEmitThreads) a.status[(int64_t)b * a.nwg_tile + i] = 0ull;
-    if (tid == 0) a.ticket[b] = 0u;
-  }
   WaveLds<TIn> &L = lds[w];
   // wave-uniform by construction; readfirstlane lets the compiler keep everything
   // derived from it (slab geometry, line masks, buffer offsets) in SGPRs
   const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kEmitWaves + w) * KW);
   if (p0 >= P) return;
   const int kw_eff = min(KW, P - p0);
-  // (1) pillar descriptors (one lane per pillar)
-  const int2 tot = a.totals[b];
+  // (1) pillar descriptors.  The pillar index of a cell = occupied cells of all earlier
+  //     tiles + its place in its tile's list; k_tile left the former open, so every wave
+  //     prefix-sums the tiles' totals itself (lane l owns nv consecutive tiles: no LDS, no
+  //     barrier) and finds the tiles of its KW pillars with ballots.
+  const int ntiles = a.g.ntiles;
+  const int nv = (ntiles + kWave - 1) / kWave;  // tiles per lane, <= 64
+  const u64 *agg = a.tile_agg + (int64_t)b * ntiles;
+  u64 mine = 0;
+  unsigned cv[4] = {0u, 0u, 0u, 0u};  // the lane's tiles' occupied-cell counts (all of them when nv <= 4)
+  for (int e = 0; e < nv; ++e) {
+    const int t = lane * nv + e;
+    if (t < ntiles) {
+      const u64 v = agg[t];
+      mine += v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e == i) cv[i] = (unsigned)(v & 0xFFFFFFFFull);
+    }
+  }
+  u64 inc = mine;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const u64 o = shfl_up64(inc, d);
+    if (lane >= d) inc += o;
+  }
+  const u64 tot = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(inc >> 32), kWave - 1) << 32) |
+                  (unsigned)__builtin_amdgcn_readlane((int)(inc & 0xFFFFFFFFull), kWave - 1);
+  const unsigned lane_excl = (unsigned)((inc - mine) & 0xFFFFFFFFull);  // occupied cells before my tiles
+  if (blockIdx.x == 0 && w == 0 && lane == 0)
+    a.totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
+  const int npil = min((int)(tot & 0xFFFFFFFFull), P);
   int4 m = make_int4(-1, 0, 0, 0);
-  if (lane < KW && p0 + lane < P) m = a.pillar_meta[(int64_t)b * P + p0 + lane];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const unsigned p = (unsigned)(p0 + k);
+    if ((int)p >= npil) break;  // uniform
+    // the last lane whose first tile starts at or before p holds p's tile
+    const int owner = __popcll(__ballot(lane_excl <= p)) - 1;
+    int tile_k = 0;
+    unsigned before_k = 0;
+    if (lane == owner) {
+      unsigned run = lane_excl;
+      tile_k = lane * nv;
+      for (int e = 0; e < nv; ++e) {
+        const int t = lane * nv + e;
+        unsigned c = 0;
+        if (e < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (e == i) c = cv[i];
+        } else if (t < ntiles) {
+          c = (unsigned)(agg[t] & 0xFFFFFFFFull);
+        }
+        if (run + c > p) {
+          tile_k = t;
+          break;
+        }
+        run += c;
+      }
+      before_k = run;
+    }
+    tile_k = __shfl(tile_k, owner, kWave);
+    before_k = (unsigned)__shfl((int)before_k, owner, kWave);
+    if (lane == k) {
+      m = a.tile_meta[((int64_t)b * ntiles + tile_k) * (1 << a.g.tile_shift) + (p - before_k)];
+      if (MODE == kModeCompact) a.pillar_meta[(int64_t)b * P + p] = m;
+    }
+  }
   SlabGeom sg;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       (void *)(a.out + (int64_t)b * 9 * P * N), 0,
@@ -1038,9 +1039,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     sg.aligned = ((((int64_t)P * sg.N4) & 7) == 0) && (KW * sg.N4 / 8 + 2 <= 64);
     sg.late_lines = 0;
   }
-  const int npil = min(tot.x, P);
   if (lane < KW) {
-    if (p0 + lane >= npil) m = make_int4(-1, 0, 0, 0);  // rows beyond the occupied cells hold stale descriptors
     L.slot[lane] = m.x;
     L.start[lane] = m.y;
     L.cnt[lane] = m.z;
@@ -1387,8 +1386,7 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
 namespace {
 
 struct VoxLayout {
-  size_t kslot, kpts, mat, sorted_pts, meta, status, ticket, totals, errflag, stamps, bytes;
-  int nwg_tile;     // k_tile workgroups per sweep (one per tile) = status words per sweep
+  size_t kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, meta, totals, stamps, bytes;
   int ncap;         // point capacity per sweep, a multiple of the split chunk
   int nchunks_cap;  // split chunks per sweep at capacity
 };
@@ -1399,7 +1397,7 @@ VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int re
   VoxLayout l;
   l.ncap = (int)align_up((size_t)std::max<int64_t>(max_points, 1), kChunk);
   l.nchunks_cap = l.ncap / kChunk;
-  l.nwg_tile = g.ntiles;
+  const size_t ts = (size_t)1 << g.tile_shift;
   size_t off = 0;
   l.kslot = off;
   off = align_up(off + (size_t)B * l.ncap * 4, 256);
@@ -1409,19 +1407,17 @@ VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int re
   off = align_up(off + (size_t)B * g.ntiles * l.nchunks_cap * 8, 256);
   l.sorted_pts = off;
   off = align_up(off + (size_t)B * l.ncap * rec_bytes, 256);
-  l.meta = off;
+  l.tile_meta = off;  // a tile's list has at most min(tile slots, points) entries; sized for the former
+  off = align_up(off + (size_t)B * g.ntiles * ts * 16, 256);
+  l.tile_agg = off;
+  off = align_up(off + (size_t)B * g.ntiles * 8, 256);
+  l.meta = off;       // compact mode only (host drop-in)
   off = align_up(off + (size_t)B * P * 16, 256);
-  l.status = off;
-  off = align_up(off + (size_t)B * l.nwg_tile * 8, 256);
-  l.ticket = off;
-  off = align_up(off + (size_t)B * 4, 256);
   l.totals = off;
   off = align_up(off + (size_t)B * 8, 256);
-  l.errflag = off;
-  off = align_up(off + 4, 256);
   l.stamps = off;
 #ifdef PP_STAMPS
-  off = align_up(off + (size_t)B * std::max(l.nwg_tile, l.nchunks_cap) * 16 * 64, 256);
+  off = align_up(off + (size_t)B * std::max(g.ntiles, l.nchunks_cap) * 16 * 64, 256);
 #endif
   l.bytes = off;
   return l;
@@ -1443,9 +1439,8 @@ struct DeviceGuard {
   }
 };
 
-// Makes the workspace fit (B, max_points, grid, P) and guarantees the "armed"
-// invariant (status, ticket, errflag all zero) whenever the layout changed.
-// Between calls k_emit re-arms the look-back words itself.
+// Makes the workspace fit (B, max_points, grid, P); zeroed whenever the layout changed
+// (nothing depends on it: every array is written before it is read within one call).
 int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
                const GridGeom &g, int P, int rec_bytes, VoxLayout *out) {
   VoxLayout l = vox_layout(B, max_points, g, P, rec_bytes);
@@ -1457,7 +1452,6 @@ int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
   int rc = ctx->vox_ws.ensure(l.bytes, &grew);
   if (rc) return rc;
   if (grew || std::memcmp(key, ctx->vox_layout_key, sizeof key) != 0) {
-    // everything: k_emit must find in-range descriptors even behind a k_tile that gave up
     PP_HIP_TRY(hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream));
     std::memcpy(ctx->vox_layout_key, key, sizeof key);
   }
@@ -1479,11 +1473,10 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   Rec *kpts = reinterpret_cast<Rec *>(ws + l.kpts);
   int2 *mat = reinterpret_cast<int2 *>(ws + l.mat);
   Rec *sorted_pts = reinterpret_cast<Rec *>(ws + l.sorted_pts);
+  int4 *tile_meta = reinterpret_cast<int4 *>(ws + l.tile_meta);
+  u64 *tile_agg = reinterpret_cast<u64 *>(ws + l.tile_agg);
   int4 *meta = reinterpret_cast<int4 *>(ws + l.meta);
-  u64 *status = reinterpret_cast<u64 *>(ws + l.status);
-  unsigned *ticket = reinterpret_cast<unsigned *>(ws + l.ticket);
   int2 *totals = reinterpret_cast<int2 *>(ws + l.totals);
-  int *errflag = reinterpret_cast<int *>(ws + l.errflag);
 
   // k_tile geometry: waves per tile from the mean population of a tile
   const long long per_tile = ((long long)maxn + g.ntiles - 1) / g.ntiles;
@@ -1493,43 +1486,16 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   const int wi = tw == 4 ? 0 : tw == 8 ? 1 : 2;
   const size_t lds_split = split_lds_bytes(g.ntiles);
   const size_t lds_tile = tile_lds_bytes(1 << g.tile_shift, tw);
-  auto tile_fn = [&](bool with_ticket) -> const void * {
-    if (with_ticket)
-      return tw == 4 ? reinterpret_cast<const void *>(&k_tile<TIn, 4, true>)
-           : tw == 8 ? reinterpret_cast<const void *>(&k_tile<TIn, 8, true>)
-                     : reinterpret_cast<const void *>(&k_tile<TIn, 16, true>);
-    return tw == 4 ? reinterpret_cast<const void *>(&k_tile<TIn, 4, false>)
-         : tw == 8 ? reinterpret_cast<const void *>(&k_tile<TIn, 8, false>)
-                   : reinterpret_cast<const void *>(&k_tile<TIn, 16, false>);
-  };
   // dynamic LDS beyond 64 KiB needs the attribute; set once per kernel instance and size
-  auto arm = [&](pp_ctx::TileKernelInfo &ki, const void *fn) -> int {
-    if (lds_tile > ki.lds_armed) {
-      PP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
-      ki.lds_armed = lds_tile;
-    }
-    return PP_OK;
-  };
-  // The ticket (and its latency) is only needed when the grid cannot be resident all at
-  // once.  Resident capacity of the no-ticket instance: one block per CU below the
-  // occupancy query's answer (it can be one high, MI355X guide "Residency").
-  bool use_ticket = true;
-  if (!ctx->force_ticket) {
-    pp_ctx::TileKernelInfo &kn = ctx->tile_info[sizeof(TIn) == 8][wi][1];
-    int rc = arm(kn, tile_fn(false));
-    if (rc) return rc;
-    if (kn.capacity_lds != lds_tile) {
-      int per_cu = 0, cus = 0;
-      PP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tile_fn(false), tw * kWave, lds_tile));
-      PP_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-      kn.capacity = (long long)(per_cu >= 2 ? per_cu - 1 : per_cu) * cus;
-      kn.capacity_lds = lds_tile;
-    }
-    use_ticket = (long long)l.nwg_tile * B > kn.capacity;
-  }
   {
-    int rc = arm(ctx->tile_info[sizeof(TIn) == 8][wi][use_ticket ? 0 : 1], tile_fn(use_ticket));
-    if (rc) return rc;
+    size_t &armed = ctx->tile_lds_armed[sizeof(TIn) == 8][wi];
+    if (lds_tile > armed) {
+      const void *fn = tw == 4 ? reinterpret_cast<const void *>(&k_tile<TIn, 4>)
+                     : tw == 8 ? reinterpret_cast<const void *>(&k_tile<TIn, 8>)
+                               : reinterpret_cast<const void *>(&k_tile<TIn, 16>);
+      PP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+      armed = lds_tile;
+    }
   }
   if (lds_split > ctx->split_lds_armed[sizeof(TIn) == 8]) {
     PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split<TIn>),
@@ -1541,10 +1507,8 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
 #ifdef PP_STAMPS
   stamps = reinterpret_cast<u64 *>(ws + l.stamps);
   ctx->dbg_stamps_off = l.stamps;
-  ctx->dbg_stamps_bytes = (size_t)B * (PP_STAMPS == 2 ? nchunks : l.nwg_tile) * 16 * 64;
+  ctx->dbg_stamps_bytes = (size_t)B * (PP_STAMPS == 2 ? nchunks : g.ntiles) * 16 * 64;
 #endif
-  ctx->ws_ticket_off = l.ticket;
-  ctx->ws_errflag_off = l.errflag;
   // When the timing ring is armed every launch carries its own start/stop events
   // (hipExtLaunchKernelGGL binds them to the dispatch packet, so a pair brackets the
   // kernel alone, like a profiler's kernel trace, not the gaps around it).
@@ -1562,32 +1526,24 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                         sweep_stride, s0, s1, contig, np, g, l.ncap, l.nchunks_cap, kslot, kpts, mat,
                         stamps);
   auto launch_tile = [&](auto kern) {
-    hipExtLaunchKernelGGL(kern, dim3((unsigned)l.nwg_tile, (unsigned)B), dim3(tw * kWave), lds_tile,
-                          stream, ev0[PP_KERNEL_TILE], ev1[PP_KERNEL_TILE], 0, np, g, P, l.ncap,
-                          l.nchunks_cap, kslot, kpts, mat, sorted_pts, meta, status, ticket, totals,
-                          errflag, ctx->scan_spin_limit, stamps);
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)g.ntiles, (unsigned)B), dim3(tw * kWave), lds_tile,
+                          stream, ev0[PP_KERNEL_TILE], ev1[PP_KERNEL_TILE], 0, np, g, l.ncap,
+                          l.nchunks_cap, kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, stamps);
   };
-  if (use_ticket) {
-    if (tw == 4) launch_tile(&k_tile<TIn, 4, true>);
-    else if (tw == 8) launch_tile(&k_tile<TIn, 8, true>);
-    else launch_tile(&k_tile<TIn, 16, true>);
-  } else {
-    if (tw == 4) launch_tile(&k_tile<TIn, 4, false>);
-    else if (tw == 8) launch_tile(&k_tile<TIn, 8, false>);
-    else launch_tile(&k_tile<TIn, 16, false>);
-  }
+  if (tw == 4) launch_tile(&k_tile<TIn, 4>);
+  else if (tw == 8) launch_tile(&k_tile<TIn, 8>);
+  else launch_tile(&k_tile<TIn, 16>);
   EmitArgs a;
   a.g = g;
   a.np = np;
   a.P = P;
   a.N = N;
   a.ncap = l.ncap;
+  a.tile_meta = tile_meta;
+  a.tile_agg = tile_agg;
   a.pillar_meta = meta;
   a.totals = totals;
   a.sorted_pts = sorted_pts;
-  a.status = status;
-  a.ticket = ticket;
-  a.nwg_tile = l.nwg_tile;
   a.out = out;
   a.idx_out = idx_out;
   a.feat_out = feat_out;
@@ -1650,28 +1606,13 @@ extern "C" int pp_voxelize_check(pp_ctx_t *ctx, void *stream_) {
     return PP_ERR_VALUE;
   }
   DeviceGuard guard(ctx->device);
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  PP_HIP_TRY(hipStreamSynchronize(stream));
-  if (!ctx->vox_ws.ptr || !ctx->ws_errflag_off) return PP_OK;  // nothing launched yet
-  int flag = 0;
-  char *fp = static_cast<char *>(ctx->vox_ws.ptr) + ctx->ws_errflag_off;
-  PP_HIP_TRY(hipMemcpy(&flag, fp, 4, hipMemcpyDeviceToHost));
-  if (!flag) return PP_OK;
-  PP_HIP_TRY(hipMemset(fp, 0, 4));
-  set_error(flag == 2 ? "voxelizer: a tile ticket was out of range (workspace not armed); the call's outputs are invalid"
-                      : "voxelizer: a tile timed out waiting for an earlier tile's totals; the call's outputs are invalid");
-  return PP_ERR_INTERNAL;
-}
-
-extern "C" int pp_debug_poison_ticket(pp_ctx_t *ctx, void *stream_, int sweep, unsigned value) {
-  if (!ctx || !ctx->vox_ws.ptr || !ctx->ws_ticket_off || sweep < 0 || sweep >= PP_MAX_BATCH) {
-    set_error("pp_debug_poison_ticket: no voxelizer workspace yet (or bad sweep)");
-    return PP_ERR_VALUE;
+  hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream_));
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    std::memset(ctx->vox_layout_key, 0, sizeof ctx->vox_layout_key);
+    set_error("voxelizer: the stream reports %s", hipGetErrorString(e));
+    return PP_ERR_HIP;
   }
-  DeviceGuard guard(ctx->device);
-  PP_HIP_TRY(hipMemcpyAsync(static_cast<char *>(ctx->vox_ws.ptr) + ctx->ws_ticket_off + 4 * (size_t)sweep,
-                            &value, 4, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream_)));
-  PP_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
   return PP_OK;
 }
 
@@ -1921,25 +1862,16 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
                                l.ncap, 4, 1, 1, np, 1, n, g, P, N, l, kModeCompact, nullptr,
                                nullptr, static_cast<double *>(ctx->stage_out.ptr), false);
   if (rc) return rc;
-  // descriptors back: totals, errflag, pillar_meta[P]
+  // descriptors back: totals, pillar_meta[P] (pillar order, written by k_emit in compact mode)
   rc = ctx->pin_meta.ensure(256 + (size_t)P * 16);
   if (rc) return rc;
   char *ws = static_cast<char *>(ctx->vox_ws.ptr);
   char *pm = static_cast<char *>(ctx->pin_meta.ptr);
   PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.totals, 8, hipMemcpyDeviceToHost, stream));
-  PP_HIP_TRY(hipMemcpyAsync(pm + 16, ws + l.errflag, 4, hipMemcpyDeviceToHost, stream));
   PP_HIP_TRY(hipMemcpyAsync(pm + 256, ws + l.meta, (size_t)P * 16, hipMemcpyDeviceToHost, stream));
   PP_HIP_TRY(hipStreamSynchronize(stream));
-  int tot[2], err;
+  int tot[2];
   std::memcpy(tot, pm, 8);
-  std::memcpy(&err, pm + 16, 4);
-  if (err) {
-    // leave a clean workspace behind
-    (void)hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream);
-    (void)hipStreamSynchronize(stream);
-    set_error("cell scan timed out waiting for a predecessor tile");
-    return PP_ERR_INTERNAL;
-  }
   if (num_cells) *num_cells = tot[0];
   const int npil = std::min(tot[0], std::min(P, max_pillars));
   if (npil == 0) return PP_OK;

@@ -114,8 +114,8 @@ class PillarVoxelizer:
         return self.read_kernel_ms(_lib.KERNEL_EMIT, cap)
 
     def check(self):
-        """Synchronises the current stream and raises if a voxelizer launch on this context
-        failed since the last check (a tile's bounded wait ran out): pp_voxelize_check."""
+        """Synchronises the current stream and raises if a launch on it failed (the device entry
+        points never synchronise by themselves): pp_voxelize_check."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().pp_voxelize_check(self._ctx.handle, ctypes.c_void_p(stream)), "pp_voxelize_check")
 

@@ -369,14 +369,12 @@ int pp_relu_bn_train_bwd_dev(pp_ctx_t *ctx, void *stream, const float *z_dev,
                              float *dbeta_dev, float *dbias_dev);
 
 /*
- * Failure flag of the voxelizer launches on this context since the last check.  k_tile
- * workgroups exchange their tiles' totals through status words; every wait is bounded, and a
- * wait that ran out (or a ticket word that was not armed) sets a sticky flag instead of
- * producing a wrong prefix silently.  pp_voxelize_check synchronises `stream`, returns
- * PP_ERR_INTERNAL (and clears the flag) if any launch since the last check failed, else
- * PP_OK.  The workspace re-arms itself on every call (k_emit zeroes the status words), so the
- * call after a failed one is valid again.  pp_create_pillars_f64 checks by itself.
- * (The reference's only analogue is to fail loudly: pillars.cpp:166-169.)
+ * The device entry points never synchronise.  pp_voxelize_check synchronises `stream` and
+ * returns PP_ERR_HIP (with the runtime's message) if a launch on it failed, else PP_OK.  The
+ * voxelizer kernels themselves have no failure mode of their own any more: no workgroup waits
+ * for another one (round 1's look-back scan and its time-out flag are gone), every array is
+ * written before it is read within one call.  (The reference's only analogue is to fail
+ * loudly: pillars.cpp:166-169.)
  */
 int pp_voxelize_check(pp_ctx_t *ctx, void *stream);
 
@@ -385,7 +383,8 @@ int pp_voxelize_check(pp_ctx_t *ctx, void *stream);
  *   batch                  <= PP_MAX_BATCH (32) sweeps per call
  *   points per sweep       <  2^30
  *   cell grid              <= 32768 cells per axis and <= 16 777 216 cells in all (a tile of
- *                             up to 4096 cells lives in LDS, at most 4096 tiles)
+ *                             up to 4096 cells lives in LDS, at most 4096 tiles); the workspace
+ *                             holds 16 bytes per cell and sweep for the tiles' descriptor lists
  *   max_points_per_pillar  <= 65536; dense output: max_pillars * max_points_per_pillar <= 1e8
  *   fused feature net      exactly 64 output channels (model/model.py:28)
  * One context per HIP stream: calls on one context must be stream-ordered.
@@ -403,12 +402,6 @@ int pp_voxelize_check(pp_ctx_t *ctx, void *stream);
 int pp_ctx_set_timing(pp_ctx_t *ctx, int slots);
 int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int cap, int *count);
 int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count);
-
-/* Test hooks (tests/test_gpu_voxelize.py): bound of a status-word wait in polls (0 = default),
- * force the ticketed k_tile, and disarm sweep `sweep`'s ticket word so that the next call's
- * k_tile must report through pp_voxelize_check instead of hanging or corrupting. */
-int pp_debug_set_scan_limit(pp_ctx_t *ctx, unsigned polls, int force_ticket);
-int pp_debug_poison_ticket(pp_ctx_t *ctx, void *stream, int sweep, unsigned value);
 
 #ifdef __cplusplus
 }

@@ -314,36 +314,25 @@ def test_data_mean_subtraction(gpu, oracle):
         PillarVoxelizer(cfg, device=gpu, data_mean=np.zeros(5, np.float32))
 
 
-def test_failed_tile_wait_is_reported_and_the_next_call_is_clean(gpu, oracle):
-    """k_tile's waits are bounded: a tile that never publishes (here: the ticket word of sweep 0
-    is disarmed, so tile 0 is never claimed and one workgroup draws a ticket out of range) must
-    surface through pp_voxelize_check instead of hanging or yielding a wrong prefix silently,
-    and the workspace must be armed again for the call after (VERDICT r1 #6)."""
-    import ctypes
+def test_check_reports_a_clean_stream(gpu, oracle):
+    """pp_voxelize_check: synchronise + report.  The kernels have no failure mode of their own
+    (no workgroup waits for another one), so after valid calls it reports nothing, however the
+    calls were interleaved with other contexts' work."""
     import torch
-    from pp_amd import _lib, synth
+    from pp_amd import synth
     pts = synth.lidar_like(20000, 20.0, 4)
-    P, N = 6000, 32
-    vox = _vox(gpu, 20.0, 0.2, P, N, order=1)
-    good = _run(gpu, vox, pts)
-    vox.check()                                            # nothing failed so far
-    L = _lib.lib()
-    stream = ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
-    _lib.check(L.pp_debug_set_scan_limit(vox._ctx.handle, 4000, 1))     # ticketed kernel, short waits
-    try:
-        _lib.check(L.pp_debug_poison_ticket(vox._ctx.handle, stream, 0, 1))
-        _run(gpu, vox, pts)                                # outputs of this call are invalid
-        with pytest.raises(_lib.PPError):
-            vox.check()
-        vox.check()                                        # the flag was cleared by the report
-        again = _run(gpu, vox, pts)                        # k_emit re-armed the status words
-        vox.check()
-        for a, b in zip(good, again):
-            assert np.array_equal(a, b)
-    finally:
-        _lib.check(L.pp_debug_set_scan_limit(vox._ctx.handle, 0, 0))
-    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 20.0, 0.2, order=1)
-    assert _check_exact(again[0][0], again[1][0], ref_p, ref_i)
+    a = _vox(gpu, 20.0, 0.2, 6000, 32, order=1)
+    b = _vox(gpu, 20.0, 0.2, 500, 8, order=0)
+    ta = torch.from_numpy(pts).to(gpu)
+    for _ in range(3):
+        ra = a(ta, return_counts=True)
+        rb = b(ta, return_counts=True)
+    a.check()
+    b.check()
+    ref_p, ref_i, m = oracle_stage(oracle, pts, 6000, 32, 20.0, 0.2, order=1)
+    assert int(ra[2][0, 0]) == m and _check_exact(ra[0][0].cpu().numpy(), ra[1][0].cpu().numpy(), ref_p, ref_i)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, 500, 8, 20.0, 0.2, order=0)
+    assert int(rb[2][0, 0]) == m and _check_exact(rb[0][0].cpu().numpy(), rb[1][0].cpu().numpy(), ref_p, ref_i)
 
 
 @pytest.mark.parametrize("order", [0, 1])
