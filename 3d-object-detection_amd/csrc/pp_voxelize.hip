@@ -1353,10 +1353,13 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
     return v >= 16 && v <= kMaxTiles ? v : 0;
   }();
   // row-major tiles are strips of the plane and lidar clouds are centre-heavy: finer tiles
-  // bound the crowded ones; scrambled tiles are uniform and fewer, larger ones cost less
+  // (at most 2048 slots) bound the crowded ones; scrambled tiles are uniform and fewer, larger
+  // ones cost less.  Beyond kMaxTiles of them the tiles grow to their LDS limit either way.
   const int target_tiles = forced_tiles ? forced_tiles
                          : prm->order == PP_ORDER_ROW_MAJOR ? kTargetTiles : kTargetTiles / 2;
-  while ((nc + ts - 1) / ts > target_tiles && ts < kMaxTileSlots) ts *= 2;
+  const int soft_cap = prm->order == PP_ORDER_ROW_MAJOR && !forced_tiles ? 2048 : kMaxTileSlots;
+  while ((nc + ts - 1) / ts > target_tiles && ts < soft_cap) ts *= 2;
+  while ((nc + ts - 1) / ts > kMaxTiles && ts < kMaxTileSlots) ts *= 2;
   const long long nt = (nc + ts - 1) / ts;
   if (nt > kMaxTiles) {
     set_error("cell grid too large (%lld cells; limit %d)", nc, kMaxTiles * kMaxTileSlots);
@@ -1481,7 +1484,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   // k_tile geometry: waves per tile from the mean population of a tile
   const long long per_tile = ((long long)maxn + g.ntiles - 1) / g.ntiles;
   const int tw = ctx->force_tile_waves ? ctx->force_tile_waves
-               : per_tile <= 320 ? 4
+               : per_tile <= 96 ? 4
                : (per_tile <= 640 || g.order != PP_ORDER_ROW_MAJOR) ? 8 : 16;
   const int wi = tw == 4 ? 0 : tw == 8 ? 1 : 2;
   const size_t lds_split = split_lds_bytes(g.ntiles);
