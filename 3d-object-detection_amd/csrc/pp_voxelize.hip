@@ -4,24 +4,28 @@
 // device-resident path, the caller glue around it (data/dataset.py:88-106):
 // np.zeros + create_pillars + transpose to [9,P,N] + f64->f32 + indices->int64.
 //
-// Pipeline (three launches, grid.y = sweep of the batch; no global atomics on
-// the data path -- the cell grid only ever exists in LDS):
+// Pipeline (three launches, grid.y = sweep of the batch; no global atomics, no
+// workgroup that waits for another one -- the cell grid only ever exists in LDS):
 //   k_split  1024 points per workgroup: point -> cell slot (f64 true division +
 //            floor, half-open range test: pillars.cpp:271-280), then a STABLE
-//            workgroup-local multisplit by tile (a tile = 64..1024 consecutive
-//            slots): wave ballots find each point's peers, per-wave byte
-//            histograms in LDS give its position.  Writes the chunk's points
-//            grouped by tile plus one {offset,count} entry per (tile, chunk).
-//   k_tile   one wave per tile: walks the tile's runs chunk by chunk (= input
-//            order), LDS histogram over the tile's cells, wave prefix sums,
-//            one decoupled look-back per 16 tiles for the pillar index
-//            (P-index compaction) and the CSR offset; second walk places every
-//            point at bucket start + rank, rank from ballots -> buckets hold
+//            workgroup-local multisplit by tile (a tile = 256..4096 consecutive
+//            slots of the pillar order): wave ballots find each point's peers,
+//            per-wave byte histograms in LDS give its position.  Writes the
+//            chunk's points grouped by tile plus one {offset,count} entry per
+//            (tile, chunk).
+//   k_tile   one workgroup per tile: walks the tile's runs chunk by chunk (=
+//            input order), LDS histogram over the tile's cells, prefix sums ->
+//            bucket starts; second walk places every point at bucket start +
+//            rank, rank from ballots and per-wave byte counts -> buckets hold
 //            their points in INPUT order (pillars.cpp:98 push_back order).
-//   k_emit   one wave per 4 consecutive pillars: coalesced bucket read,
-//            LDS-staged, sequential running mean (pillars.cpp:311-328), N-cap,
-//            9 features (pillars.cpp:30-31,48-56,381-383), dense [9,P,N] f32
-//            store incl. the zero padding, [P,3] int64 indices
+//            The tile's CSR offset is the sum of its runs' offsets in their
+//            chunks; its occupied cells' descriptors go to a tile-local list.
+//   k_emit   one wave per 4 consecutive pillars: prefix sum over the tiles'
+//            occupied-cell counts (-> which tile's list holds pillar p),
+//            coalesced bucket read, LDS-staged, sequential running mean
+//            (pillars.cpp:311-328), N-cap, 9 features (pillars.cpp:30-31,48-56,
+//            381-383), dense [9,P,N] f32 store incl. the zero padding, [P,3]
+//            int64 indices
 //
 // The path is HBM-bound: 97% of the bytes are the dense store of
 // k_emit.  Every 128-byte line of the output is written once, whole.
