@@ -372,3 +372,24 @@ def test_maximum_batch(gpu, oracle):
     with pytest.raises(ValueError):
         import torch
         vox(torch.zeros((33, 8, 4), device=gpu))
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_largest_grids(gpu, oracle, order):
+    """4001 x 4001 cells = 3909 tiles of 4096 slots: the split's four bins per thread, tiles
+    with 64 cells per k_tile thread, 62 tiles per lane in k_emit's prefix.  One more doubling of
+    the grid is beyond the documented limit and must be refused."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    pts = synth.lidar_like(30000, 400.0, 9)
+    pts[:2000] = synth.lidar_like(2000, 3.0, 10)          # and a crowded spot
+    P, N = 20000, 8
+    vox = _vox(gpu, 400.0, 0.2, P, N, order=order)
+    pil, idx, cnt = _run(gpu, vox, pts)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, 400.0, 0.2, order=order)
+    assert cnt[0, 0] == m
+    assert _check_exact(pil[0], idx[0], ref_p, ref_i)
+    too_big = PillarVoxelizer(VoxelConfig.square(450.0, 0.2, 100, 4, order=order), device=gpu)   # 4501^2 > 2^24
+    with pytest.raises(ValueError, match="too large"):
+        too_big(torch.from_numpy(pts[:100]).to(gpu))
