@@ -159,13 +159,14 @@ struct TargetArgs {
   double pos_thresh, canvas_height;
   int num_classes;
   // scratch
-  u64 *col_max;  // [G] bit pattern of the column maximum IoU (0 = all zero)
-  int *col_arg;  // [G] first anchor reaching the column maximum
+  u64 *col_max;  // [G] bit pattern of the column maximum IoU (0 = all zero): the tail's scratch when
+  int *col_arg;  // [G] first anchor reaching it                 G is beyond its LDS
   int *errflag;
-  // (anchor, gt, IoU bits) of every pair with IoU > 0, appended by k_targets_rows
-  int4 *cand;       // [cand_cap] {anchor, gt, iou lo, iou hi}
-  int cand_cap;
-  unsigned *cand_count;  // entries appended (may exceed cand_cap: then k_targets_cols re-scans)
+  // per workgroup and ground truth it reaches with IoU > 0: {gt, first anchor of the workgroup's
+  // column maximum, maximum lo, hi}; at most G entries per workgroup
+  int4 *cand;            // [workgroups * G]
+  unsigned *cand_count;  // entries appended
+  unsigned *ticket;      // workgroups finished
   // outputs
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
@@ -266,227 +267,221 @@ __device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j
   return iou_pair_dev(a, g, bad, pl);
 }
 
-// T1: one lane per anchor.  Row maximum / first argmax over the ground truths
-// (box_utils.py:193-196), positive rows of both targets (:211, :219-221),
-// zero rows otherwise, the column maxima via 64-bit atomicMax on the f64 bit
-// pattern (IoU >= 0, so the patterns order like the values), and the list of
-// pairs with IoU > 0 for the column-argmax pass.
-//
-// Only ~0.16 % of the (anchor, gt) pairs pass the centre gate, but an anchor near
-// two or three boxes would clip them one after the other while the rest of its
-// wave idles.  The workgroup therefore queues its gated pairs in LDS (gate pass:
-// count, prefix sum, fill -- pairs of one anchor stay in ascending gt order) and
-// clips them one pair per lane, all lanes busy; each anchor then reduces its own
-// slice of the results.  A workgroup with more gated pairs than the queue holds
-// falls back to the serial loop.
-constexpr int kPairCap = 512;
-constexpr int kGtChunk = 256;  // ground-truth centres staged in LDS per pass (uniform global loads in
-                               // the gate loop are a 500-cycle round trip each: the loop is load-latency-bound)
+// ------------------------------------------------------------------------- //
+// k_targets: create_target (utils/box_utils.py:162-232) in ONE launch         //
+// ------------------------------------------------------------------------- //
+// One workgroup per 256 consecutive anchors:
+//   gate     every anchor tests the +-10 centre gate against a chunk of 64 ground truths (centres in
+//            LDS) and keeps the survivors as a 64-bit mask; only ~0.16 % of the pairs pass;
+//   queue    a workgroup prefix sum lines the surviving (anchor, gt) pairs up in LDS, pairs of one
+//            anchor in ascending gt order, and they are clipped a window of 512 at a time;
+//   clip     EIGHT lanes per pair, one polygon vertex each (clip_group): a Sutherland-Hodgman pass
+//            is one step for the whole ring instead of a loop over it -- the serial clip was a
+//            10 us dependent chain, half of the old kernel;
+//   reduce   row maximum / first argmax per anchor (box_utils.py:193-196); per ground truth the
+//            workgroup's column maximum and the first anchor reaching it, reduced in LDS and
+//            appended to a list (at most one entry per workgroup and ground truth: the list can
+//            never overflow its [workgroups x G] slots, no global atomic on the data path except
+//            one counter bump per workgroup and chunk);
+//   store    class and regression rows (:211, :219-221; zero rows otherwise) staged in LDS and
+//            written as whole 16-byte groups;
+//   tail     the LAST workgroup to finish (ticket) reduces the list to the column argmax
+//            (np.argmax over the transposed matrix, :199-200) and writes the forced rows
+//            (:204-205, :212-213, :223-228).  Two more launches cost more than this tail.
+constexpr int kTgtThreads = 256;
+constexpr int kTgtWaves = kTgtThreads / 64;
+constexpr int kGtChunk = 64;    // ground truths per gate pass: one mask bit each
+constexpr int kPairCap = 512;   // pairs per window
+constexpr int kGroup = 8;       // lanes per pair: a quad clipped by a quad has at most 8 vertices
+constexpr int kPairsPerRound = kTgtThreads / kGroup;
+constexpr int kStageCols = 16;  // widest target row staged in LDS
+constexpr int kForcedLds = 2048;  // ground truths whose column results the tail keeps in LDS
 
-__global__ __launch_bounds__(kIouThreads) void k_targets_rows(TargetArgs t) {
-  // LDS budget decides how many workgroups are resident (the grid should fit in one
-  // round): vertex lists for ONE clipping wave (16 KB), centres, queue, results = 26 KB
-  __shared__ double2 s_poly[16 * 64];
-  __shared__ double2 s_gc[kGtChunk];
-  __shared__ double s_iou[kPairCap];
-  __shared__ unsigned short s_pair_lane[kPairCap], s_pair_gt[kPairCap];
-  __shared__ int s_off[kIouThreads / 64];
-  __shared__ u64 s_cmax[kGtChunk];        // column maxima of this workgroup
-  __shared__ unsigned s_npos[2], s_base;  // positives of this workgroup / their first list slot
-  const PolyLds pl{s_poly + (threadIdx.x & 63), 64};
-  const int tid = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kIouThreads + tid;
-  const bool live = i < t.A;
-  double acx = 0, acy = 0;
-  if (live) {
-    const AnchorId id = anchor_id(t, i);
-    acx = id.cx;
-    acy = id.cy;
+struct TgtLds {
+  double2 gc[kGtChunk];                   // image-space centres of the chunk's ground truths
+  double2 gk[kGtChunk][4];                // their corners
+  double2 poly[kPairsPerRound][kGroup];   // hand-over of a clip pass's output ring
+  double iou[kPairCap];
+  u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
+  int carg[kGtChunk];                     // first anchor reaching it
+  unsigned short pair_lane[kPairCap], pair_gt[kPairCap];
+  int woff[kTgtWaves];
+  int is_last;
+  float stage[kTgtThreads * kStageCols];
+};
+struct TailLds {
+  u64 colmax[kForcedLds];
+  int colarg[kForcedLds];
+  unsigned char cls[kForcedLds];
+};
+constexpr size_t kTgtLdsBytes = sizeof(TgtLds) > sizeof(TailLds) ? sizeof(TgtLds) : sizeof(TailLds);
+
+__device__ __forceinline__ void iou_wave_sync() {
+  // LDS operations of one wave execute in program order; this only stops the compiler from
+  // moving them across a cross-lane hand-off
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// shoelace_dev over a ring held one vertex per lane (lanes gbase .. gbase+n-1): the terms are
+// formed in parallel, the sum runs in the serial order
+__device__ __forceinline__ double group_shoelace(double x, double y, int n, int v, int gbase) {
+  const int succ = gbase + ((v + 1 >= n) ? 0 : v + 1);
+  const double jx = __shfl(x, succ, 64), jy = __shfl(y, succ, 64);
+  const double term = x * jy - jx * y;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < kGroup; ++k) {
+    const double tk = __shfl(term, gbase + k, 64);
+    if (k < n) s = s + tk;
   }
-  double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
-  int best_j = 0;
-  bool bad = false;
-  auto row_max = [&](int j, double v) {
-    if (v > best) {  // strict: first maximum wins, like np.argmax
-      best = v;
-      best_j = j;
-    }
-  };
-  auto consume = [&](int j, double v) {  // overflow path only: one global atomic per pair
-    row_max(j, v);
-    if (v > 0.0) {
-      const u64 bits = (u64)__double_as_longlong(v);
-      atomicMax(&t.col_max[j], bits);
-      const unsigned pos = atomicAdd(t.cand_count, 1u);
-      if (pos < (unsigned)t.cand_cap)
-        t.cand[pos] = make_int4((int)i, j, (int)(bits & 0xFFFFFFFFull), (int)(bits >> 32));
-    }
-  };
-  for (int j0 = 0; j0 < t.G; j0 += kGtChunk) {
-    const int gn = min(kGtChunk, t.G - j0);
-    __syncthreads();
-    for (int j = tid; j < gn; j += kIouThreads) {
-      s_gc[j] = make_double2(t.g_centers_img[(int64_t)(j0 + j) * 3], t.g_centers_img[(int64_t)(j0 + j) * 3 + 1]);
-      s_cmax[j] = 0;
-    }
-    if (tid < 2) s_npos[tid] = 0;
-    __syncthreads();
-    // gate pass 1: count
-    int cnt = 0;
-    if (live)
-      for (int j = 0; j < gn; ++j) cnt += gate_far(acx, acy, s_gc[j].x, s_gc[j].y) ? 0 : 1;
-    // exclusive prefix sum of the counts over the workgroup (wave scans + wave totals)
-    int inc = cnt;
+  return 0.5 * s;
+}
+
+// iou_pair_dev with the ring spread over the 8 lanes of a group: lane v holds vertex v.  Every
+// vertex goes through the same operations in the same order as in the serial loop (dp of vertex
+// i is dc of vertex i-1, the same function of the same operands), and the output ring is laid
+// out in the serial order (crossing point before the kept vertex, vertices ascending): same
+// bits.  (cx, cy): this lane's anchor corner (v < 4); gk: the ground truth's corners in LDS.
+// All 64 lanes must call it together; lanes of idle groups pass zeros.
+__device__ __forceinline__ double clip_group(double cx, double cy, const double2 *gk, double2 *poly,
+                                             int v, int gbase, bool *wrong) {
+  const double area_a = group_shoelace(cx, cy, 4, v, gbase);
+  const double2 gv = gk[v & 3];
+  const double area_g = -group_shoelace(gv.x, gv.y, 4, v, gbase);
+  *wrong = (area_a < 0.0 || area_g < 0.0);
+  int n = 4;
+  const unsigned below = (1u << v) - 1u;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d, 64);
-      if ((tid & 63) >= d) inc += o;
+  for (int e = 0; e < 4; ++e) {
+    const int ia = (4 - e) & 3, ib = (3 - e) & 3;
+    const double2 a = gk[ia], b = gk[ib];
+    const double ex = b.x - a.x, ey = b.y - a.y;
+    const bool act = v < n;
+    const double dc = ex * (cy - a.y) - ey * (cx - a.x);
+    const int pred = gbase + ((v == 0) ? max(n - 1, 0) : v - 1);
+    const double dp = __shfl(dc, pred, 64), px = __shfl(cx, pred, 64), py = __shfl(cy, pred, 64);
+    const bool in_c = dc >= 0.0, in_p = dp >= 0.0;
+    const bool cross = act && (in_c != in_p), keep = act && in_c;
+    const unsigned cb = (unsigned)(__ballot(cross) >> gbase) & 0xFFu;
+    const unsigned kb = (unsigned)(__ballot(keep) >> gbase) & 0xFFu;
+    int pos = __popc(cb & below) + __popc(kb & below);
+    if (cross) {
+      const double tt = dp / (dp - dc);
+      // (a ninth vertex cannot come from two convex quads; never write past the ring)
+      if (pos < kGroup) poly[pos] = make_double2(px + tt * (cx - px), py + tt * (cy - py));
+      ++pos;
     }
-    if ((tid & 63) == 63) s_off[tid >> 6] = inc;
+    if (keep && pos < kGroup) poly[pos] = make_double2(cx, cy);
+    n = min(__popc(cb) + __popc(kb), kGroup);
+    iou_wave_sync();
+    if (v < n) {
+      const double2 c = poly[v];
+      cx = c.x;
+      cy = c.y;
+    }
+    iou_wave_sync();
+  }
+  const double inter = group_shoelace(cx, cy, n, v, gbase);
+  if (*wrong) return -1.0;
+  if (n < 3) return 0.0;
+  if (!(inter > 0.0)) return 0.0;
+  return inter / (area_a + area_g - inter);
+}
+
+__device__ __forceinline__ u64 ld_agent(const u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Stores another XCD must be able to order against (the tail overwrites forced rows, and reads
+// the workgroups' list entries): write-through (sc1), drained with s_waitcnt vmcnt(0) before the
+// workgroup's ticket.  An agent-scope release fence instead writes the XCD's whole L2 back, once
+// per wave: measured 39 us of a 55 us kernel.
+typedef unsigned v4u __attribute__((__vector_size__(4 * sizeof(unsigned))));
+constexpr int kAuxSc1 = 16;
+
+// `total` floats from the LDS stage to dst (16-byte aligned), 16 bytes per store
+__device__ __forceinline__ void store_rows(float *dst, const float *stage, int total, int tid) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, total * 4, 0x00020000);
+  const int n4 = total >> 2;
+  for (int k = tid; k < n4; k += kTgtThreads)
+    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const v4u *>(stage)[k], rs, k * 16, 0, kAuxSc1);
+  for (int k = (n4 << 2) + tid; k < total; k += kTgtThreads)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stage[k]), rs, k * 4, 0, kAuxSc1);
+}
+__device__ __forceinline__ void store_f32_sc1(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The last workgroup: column argmax from the workgroups' entries, then the forced rows.  A
+// column whose argmax is anchor 0 -- all-zero columns included -- is dropped, exactly like the
+// reference's np.nonzero filter (box_utils.py:204-205).  IN_LDS: the column words live in LDS
+// (G <= kForcedLds), else in the armed global scratch (0 / INT_MAX), which only this workgroup
+// touches: atomics and sc1 loads meet in its XCD's L2.
+template <bool IN_LDS>
+__device__ void targets_tail(const TargetArgs &t, TailLds &T) {
+  const int G = t.G, tid = threadIdx.x;
+  const unsigned n = __hip_atomic_load(t.cand_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto cmax_at = [&](int j) -> u64 * { return IN_LDS ? &T.colmax[j] : &t.col_max[j]; };
+  auto carg_at = [&](int j) -> int * { return IN_LDS ? &T.colarg[j] : &t.col_arg[j]; };
+  auto cmax_ld = [&](int j) -> u64 { return IN_LDS ? T.colmax[j] : ld_agent(&t.col_max[j]); };
+  auto carg_ld = [&](int j) -> int { return IN_LDS ? T.colarg[j] : ld_agent(&t.col_arg[j]); };
+  auto sync = [&]() {
+    if (!IN_LDS) __threadfence();
     __syncthreads();
-    int wave_base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kIouThreads / 64; ++w) {
-      if (w < (tid >> 6)) wave_base += s_off[w];
-      total += s_off[w];
+  };
+  if (IN_LDS)
+    for (int j = tid; j < G; j += kTgtThreads) {
+      T.colmax[j] = 0ull;
+      T.colarg[j] = INT_MAX;
     }
-    const int my_off = wave_base + inc - cnt;
-    if (total == 0) continue;
-    if (total <= kPairCap) {
-      // gate pass 2: fill the queue (ascending gt inside each anchor's slice)
-      if (live) {
-        int q = my_off;
-        for (int j = 0; j < gn; ++j)
-          if (!gate_far(acx, acy, s_gc[j].x, s_gc[j].y)) {
-            s_pair_lane[q] = (unsigned short)tid;
-            s_pair_gt[q] = (unsigned short)j;
-            ++q;
-          }
-      }
-      __syncthreads();
-      const int64_t i0 = (int64_t)blockIdx.x * kIouThreads;
-      if (tid < 64)  // wave 0 clips, one pair per lane
-        for (int q = tid; q < total; q += 64)
-          s_iou[q] = pair_iou(t, i0 + s_pair_lane[q], j0 + s_pair_gt[q], &bad, pl);
-      __syncthreads();
-      if (live)
-        for (int q = my_off; q < my_off + cnt; ++q) row_max(j0 + s_pair_gt[q], s_iou[q]);
-      // Column maxima and the list of positive pairs: every pair with IoU > 0 needs an
-      // atomicMax on its column and a list slot.  Done per pair on global memory that is
-      // tens of thousands of atomics on G + 1 addresses, which the L2 serialises (it was
-      // 3/4 of this kernel); reduce in LDS and issue one global atomic per (workgroup,
-      // column) and one per workgroup for the list.
-      for (int q = tid; q < total; q += kIouThreads) {
-        const double v = s_iou[q];
-        if (v > 0.0) {
-          atomicMax(&s_cmax[s_pair_gt[q]], (u64)__double_as_longlong(v));
-          atomicAdd(&s_npos[0], 1u);
-        }
-      }
-      __syncthreads();
-      if (tid == 0 && s_npos[0]) s_base = atomicAdd(t.cand_count, s_npos[0]);
-      for (int j = tid; j < gn; j += kIouThreads)
-        if (s_cmax[j]) atomicMax(&t.col_max[j0 + j], s_cmax[j]);
-      __syncthreads();
-      if (s_npos[0]) {
-        const unsigned base = s_base;
-        for (int q = tid; q < total; q += kIouThreads) {
-          const double v = s_iou[q];
-          if (v > 0.0) {
-            const unsigned pos = base + atomicAdd(&s_npos[1], 1u);
-            const u64 bits = (u64)__double_as_longlong(v);
-            if (pos < (unsigned)t.cand_cap)
-              t.cand[pos] = make_int4((int)(i0 + s_pair_lane[q]), j0 + s_pair_gt[q],
-                                      (int)(bits & 0xFFFFFFFFull), (int)(bits >> 32));
-          }
-        }
-      }
+  __syncthreads();
+  auto entry = [&](unsigned e, int &j, int &anchor, u64 &bits) {
+    const u64 *q = reinterpret_cast<const u64 *>(t.cand + e);
+    const u64 lo = ld_agent(q), hi = ld_agent(q + 1);
+    j = (int)(lo & 0xFFFFFFFFull);
+    anchor = (int)(lo >> 32);
+    bits = hi;
+  };
+  for (unsigned e = tid; e < n; e += kTgtThreads) {
+    int j, anchor;
+    u64 bits;
+    entry(e, j, anchor, bits);
+    atomicMax(cmax_at(j), bits);
+  }
+  sync();
+  for (unsigned e = tid; e < n; e += kTgtThreads) {
+    int j, anchor;
+    u64 bits;
+    entry(e, j, anchor, bits);
+    if (bits == cmax_ld(j)) atomicMin(carg_at(j), anchor);
+  }
+  sync();
+  // carg[j] <- the anchor ground truth j forces, 0 for none
+  for (int j = tid; j < G; j += kTgtThreads) {
+    const int i = (cmax_ld(j) != 0ull) ? carg_ld(j) : 0;
+    if (IN_LDS) {
+      T.colarg[j] = i;
+      T.cls[j] = (unsigned char)t.g_class[j];
     } else {
-      // queue overflow (never on real scenes): the two waves take turns on the vertex lists
-      for (int turn = 0; turn < kIouThreads / 64; ++turn) {
-        if (live && (tid >> 6) == turn)
-          for (int j = 0; j < gn; ++j) {
-            if (gate_far(acx, acy, s_gc[j].x, s_gc[j].y)) continue;
-            consume(j0 + j, pair_iou(t, i, j0 + j, &bad, pl));
-          }
-        __syncthreads();
-      }
+      __hip_atomic_store(&t.col_arg[j], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (bad) atomicExch(t.errflag, 1);
-  if (!live) return;
-  float *cls = t.cls_targets + i * t.num_classes;
-  float *reg = t.reg_targets + i * 9;
-  const bool pos = best > t.pos_thresh;  // box_utils.py:195 (strict >)
-  const int cj = pos ? t.g_class[best_j] : -1;
-  for (int c = 0; c < t.num_classes; ++c) cls[c] = (c == cj) ? 1.0f : 0.0f;
-  float r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (pos) make_target_dev(t, i, best_j, r);
-#pragma unroll
-  for (int d = 0; d < 9; ++d) reg[d] = r[d];
-}
-
-// T2: first anchor index that reaches each column maximum (np.argmax over the
-// transposed matrix, box_utils.py:199-200): one lane per listed pair.  If the
-// list overflowed (more pairs with IoU > 0 than anchors: never on real scenes),
-// every lane re-scans its anchor instead -- the IoU is deterministic, so the
-// recomputed bits are identical.
-__global__ __launch_bounds__(kIouThreads) void k_targets_cols(TargetArgs t) {
-  __shared__ double2 s_poly[16 * kIouThreads];
-  const int64_t i = (int64_t)blockIdx.x * kIouThreads + threadIdx.x;
-  const unsigned count = *t.cand_count;
-  if (count <= (unsigned)t.cand_cap) {
-    if (i < count) {
-      const int4 c = t.cand[i];
-      const u64 bits = ((u64)(unsigned)c.w << 32) | (unsigned)c.z;
-      if (bits == t.col_max[c.y]) atomicMin(&t.col_arg[c.y], c.x);
-    }
-    return;
-  }
-  if (i >= t.A) return;
-  const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
-  const AnchorId aid = anchor_id(t, i);
-  const double acx = aid.cx, acy = aid.cy;
-  bool bad = false;
-  for (int j = 0; j < t.G; ++j) {
-    const double gcx = t.g_centers_img[(int64_t)j * 3], gcy = t.g_centers_img[(int64_t)j * 3 + 1];
-    if (gate_far(acx, acy, gcx, gcy)) continue;
-    const double v = pair_iou(t, i, j, &bad, pl);
-    if (v > 0.0 && (u64)__double_as_longlong(v) == t.col_max[j]) atomicMin(&t.col_arg[j], (int)i);
-  }
-}
-
-// T3 (one workgroup): the highest-IoU anchor of every ground truth overrides
-// the row written by T1 (box_utils.py:204-205, 212-213, 223-228).  A column
-// whose argmax is anchor 0 -- all-zero columns included -- is dropped, exactly
-// like the reference's np.nonzero filter.
-constexpr int kForcedLds = 2048;  // ground truths whose forced anchor / class are staged in LDS
-
-__global__ __launch_bounds__(kIouThreads) void k_targets_forced(TargetArgs t) {
-  const int G = t.G;
-  if (G <= kForcedLds && t.num_classes <= 64) {
-    // One round trip to global memory for the column results, everything else in LDS.
-    // (The general path below is a chain of dependent global round trips, ~1.5 us each.)
-    __shared__ int s_i[kForcedLds];
-    __shared__ unsigned char s_c[kForcedLds];
-    for (int j = threadIdx.x; j < G; j += kIouThreads) {
-      s_i[j] = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
-      s_c[j] = (unsigned char)t.g_class[j];
-      t.col_max[j] = 0ull;  // re-arm the scratch words for the next call on this context
-      t.col_arg[j] = INT_MAX;
-    }
-    if (threadIdx.x == 0) *t.cand_count = 0u;
-    __syncthreads();
-    for (int j = threadIdx.x; j < G; j += kIouThreads) {
-      const int i = s_i[j];
+  sync();
+  if (IN_LDS && t.num_classes <= 64) {
+    for (int j = tid; j < G; j += kTgtThreads) {
+      const int i = T.colarg[j];
       if (i == 0) continue;
       // class row of anchor i: ones at the classes of ALL ground truths forcing it (every
       // duplicate writes the same full row); regression row: the last ground truth wins
       u64 mask = 0;
       bool later = false;
       for (int j2 = 0; j2 < G; ++j2)
-        if (s_i[j2] == i) {
-          mask |= 1ull << (s_c[j2] & 63);
+        if (T.colarg[j2] == i) {
+          mask |= 1ull << (T.cls[j2] & 63);
           later = later || (j2 > j);
         }
       float *cls = t.cls_targets + (int64_t)i * t.num_classes;
@@ -498,48 +493,239 @@ __global__ __launch_bounds__(kIouThreads) void k_targets_forced(TargetArgs t) {
         for (int d = 0; d < 9; ++d) reg[d] = r[d];
       }
     }
-    return;
-  }
-  // phase A: clear the class rows of all forced anchors
-  for (int j = threadIdx.x; j < G; j += kIouThreads) {
-    const int i = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
-    if (i != 0) {
-      float *cls = t.cls_targets + (int64_t)i * t.num_classes;
-      for (int c = 0; c < t.num_classes; ++c) cls[c] = 0.0f;
+  } else {
+    // phase A: clear the class rows of all forced anchors
+    for (int j = tid; j < G; j += kTgtThreads) {
+      const int i = carg_ld(j);
+      if (i != 0) {
+        float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+        for (int c = 0; c < t.num_classes; ++c) cls[c] = 0.0f;
+      }
     }
-  }
-  __threadfence_block();
-  __syncthreads();
-  // phase B: set the classes (duplicates of one anchor set several ones, as
-  // numpy's fancy assignment does); regression row: the last ground truth wins
-  for (int j = threadIdx.x; j < G; j += kIouThreads) {
-    const int i = (t.col_max[j] != 0ull) ? t.col_arg[j] : 0;
-    if (i == 0) continue;
-    if ((unsigned)t.g_class[j] < (unsigned)t.num_classes)  // a class outside the row is ignored, never written
-      t.cls_targets[(int64_t)i * t.num_classes + t.g_class[j]] = 1.0f;
-    bool later = false;
-    for (int j2 = j + 1; j2 < G; ++j2) {
-      const int i2 = (t.col_max[j2] != 0ull) ? t.col_arg[j2] : 0;
-      later = later || (i2 == i);
-    }
-    if (!later) {
-      float r[9];
-      make_target_dev(t, i, j, r);
-      float *reg = t.reg_targets + (int64_t)i * 9;
-      for (int d = 0; d < 9; ++d) reg[d] = r[d];
+    __threadfence_block();
+    __syncthreads();
+    // phase B: set the classes (duplicates of one anchor set several ones, as numpy's fancy
+    // assignment does); regression row: the last ground truth wins
+    for (int j = tid; j < G; j += kTgtThreads) {
+      const int i = carg_ld(j);
+      if (i == 0) continue;
+      if ((unsigned)t.g_class[j] < (unsigned)t.num_classes)  // a class outside the row is ignored, never written
+        t.cls_targets[(int64_t)i * t.num_classes + t.g_class[j]] = 1.0f;
+      bool later = false;
+      for (int j2 = j + 1; j2 < G; ++j2) later = later || (carg_ld(j2) == i);
+      if (!later) {
+        float r[9];
+        make_target_dev(t, i, j, r);
+        float *reg = t.reg_targets + (int64_t)i * 9;
+        for (int d = 0; d < 9; ++d) reg[d] = r[d];
+      }
     }
   }
   // re-arm the scratch words for the next call on this context
   __syncthreads();
-  for (int j = threadIdx.x; j < G; j += kIouThreads) {
-    t.col_max[j] = 0ull;
-    t.col_arg[j] = INT_MAX;
+  if (!IN_LDS)
+    for (int j = tid; j < G; j += kTgtThreads) {
+      t.col_max[j] = 0ull;
+      t.col_arg[j] = INT_MAX;
+    }
+  if (tid == 0) {
+    *t.cand_count = 0u;
+    *t.ticket = 0u;
   }
-  if (threadIdx.x == 0) *t.cand_count = 0u;
+}
+
+__global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
+  __shared__ __align__(16) unsigned char smem[kTgtLdsBytes];
+  TgtLds &S = *reinterpret_cast<TgtLds *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int v = lane & (kGroup - 1), gbase = lane & ~(kGroup - 1);
+  const int64_t i0 = (int64_t)blockIdx.x * kTgtThreads;
+  const int64_t i = i0 + tid;
+  const bool live = i < t.A;
+  double acx = 0, acy = 0;
+  if (live) {
+    const AnchorId id = anchor_id(t, i);
+    acx = id.cx;
+    acy = id.cy;
+  }
+  double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
+  int best_j = 0;
+  bool bad = false;
+  for (int j0 = 0; j0 < t.G; j0 += kGtChunk) {
+    const int gn = min(kGtChunk, t.G - j0);
+    __syncthreads();
+    if (tid < gn) {
+      S.gc[tid] = make_double2(t.g_centers_img[(int64_t)(j0 + tid) * 3], t.g_centers_img[(int64_t)(j0 + tid) * 3 + 1]);
+      S.cmax[tid] = 0ull;
+      S.cseen[tid] = 0ull;
+      S.carg[tid] = INT_MAX;
+    }
+    for (int k = tid; k < gn * 4; k += kTgtThreads) {
+      const double *gp = t.g_corners + ((int64_t)j0 * 4 + k) * 2;
+      S.gk[k >> 2][k & 3] = make_double2(gp[0], gp[1]);
+    }
+    __syncthreads();
+    // gate: the survivors of this chunk as a mask
+    u64 mask = 0;
+    if (live)
+      for (int j = 0; j < gn; ++j)
+        mask |= (u64)(gate_far(acx, acy, S.gc[j].x, S.gc[j].y) ? 0 : 1) << j;
+    const int cnt = __popcll(mask);
+    // exclusive prefix sum of the counts over the workgroup (wave scans + wave totals)
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) S.woff[wv] = inc;
+    __syncthreads();
+    int wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kTgtWaves; ++w) {
+      if (w < wv) wave_base += S.woff[w];
+      total += S.woff[w];
+    }
+    const int my_off = wave_base + inc - cnt;
+    if (total == 0) continue;
+    for (int wb = 0; wb < total; wb += kPairCap) {
+      const int wn = min(kPairCap, total - wb);
+      // queue: this window's pairs (ascending gt inside each anchor's slice)
+      if (cnt > 0 && my_off < wb + wn && my_off + cnt > wb) {
+        u64 m = mask;
+        int q = my_off - wb;
+        while (m) {
+          const int j = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          if (q >= 0 && q < wn) {
+            S.pair_lane[q] = (unsigned short)tid;
+            S.pair_gt[q] = (unsigned short)j;
+          }
+          ++q;
+        }
+      }
+      __syncthreads();
+      // clip: 32 pairs per round
+      for (int r0 = 0; r0 < wn; r0 += kPairsPerRound) {
+        const int q = r0 + (tid >> 3);
+        const bool on = q < wn;
+        const int pl = on ? S.pair_lane[q] : 0, pg = on ? S.pair_gt[q] : 0;
+        double cx = 0, cy = 0;
+        if (on && v < 4) {
+          if (t.grid) {
+            const AnchorId id = anchor_id(t, i0 + pl);
+            const double *ty = t.types + id.d * kTypeCols;
+            cx = ty[2 * v] + id.cx;
+            cy = ty[2 * v + 1] + id.cy;
+          } else {
+            cx = t.a_corners[(i0 + pl) * 8 + 2 * v];
+            cy = t.a_corners[(i0 + pl) * 8 + 2 * v + 1];
+          }
+        }
+        bool wrong;
+        const double iou = clip_group(cx, cy, S.gk[pg], S.poly[tid >> 3], v, gbase, &wrong);
+        if (on && v == 0) {
+          S.iou[q] = iou;
+          bad = bad || wrong;
+        }
+      }
+      __syncthreads();
+      // rows: this anchor's slice of the window, ascending gt; strict >: first maximum wins
+      if (cnt > 0) {
+        const int qa = max(my_off, wb), qb = min(my_off + cnt, wb + wn);
+        for (int q = qa; q < qb; ++q) {
+          const double val = S.iou[q - wb];
+          if (val > best) {
+            best = val;
+            best_j = j0 + S.pair_gt[q - wb];
+          }
+        }
+      }
+      // columns: maximum, then the first anchor that reaches it (anchors ascend with the windows:
+      // a column whose maximum grew in this window forgets the earlier windows' anchor)
+      for (int q = tid; q < wn; q += kTgtThreads) {
+        const double val = S.iou[q];
+        if (val > 0.0) atomicMax(&S.cmax[S.pair_gt[q]], (u64)__double_as_longlong(val));
+      }
+      __syncthreads();
+      if (tid < gn && S.cmax[tid] != S.cseen[tid]) {
+        S.cseen[tid] = S.cmax[tid];
+        S.carg[tid] = INT_MAX;
+      }
+      __syncthreads();
+      for (int q = tid; q < wn; q += kTgtThreads) {
+        const double val = S.iou[q];
+        if (val > 0.0 && (u64)__double_as_longlong(val) == S.cmax[S.pair_gt[q]])
+          atomicMin(&S.carg[S.pair_gt[q]], (int)(i0 + S.pair_lane[q]));
+      }
+      __syncthreads();
+    }
+    // this workgroup's columns of the chunk -> the list
+    if (wv == 0) {
+      const bool touched = lane < gn && S.cmax[lane] != 0ull;
+      const u64 tb = __ballot(touched);
+      if (tb) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(t.cand_count, (unsigned)__popcll(tb));
+        base = (unsigned)__shfl((int)base, 0, 64);
+        if (touched) {
+          const unsigned pos = base + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
+          const u64 bits = S.cmax[lane];
+          u64 *q = reinterpret_cast<u64 *>(t.cand + pos);  // {gt, anchor}, bits
+          __hip_atomic_store(q, (u64)(unsigned)(j0 + lane) | ((u64)(unsigned)S.carg[lane] << 32), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(q + 1, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  if (bad) atomicExch(t.errflag, 1);
+  // rows: positives of both targets, zero rows otherwise
+  const int nc = t.num_classes;
+  const int nrows = (int)min((int64_t)kTgtThreads, t.A - i0);
+  const bool pos = live && best > t.pos_thresh;  // box_utils.py:195 (strict >)
+  const int cj = pos ? t.g_class[best_j] : -1;
+  float r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (pos) make_target_dev(t, i, best_j, r);
+  float *cls_dst = t.cls_targets + i0 * nc, *reg_dst = t.reg_targets + i0 * 9;
+  __syncthreads();
+  if (nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0) {
+    if (live)
+      for (int c = 0; c < nc; ++c) S.stage[tid * nc + c] = (c == cj) ? 1.0f : 0.0f;
+    __syncthreads();
+    store_rows(cls_dst, S.stage, nrows * nc, tid);
+    __syncthreads();
+  } else if (live) {
+    for (int c = 0; c < nc; ++c) store_f32_sc1(&cls_dst[(int64_t)tid * nc + c], (c == cj) ? 1.0f : 0.0f);
+  }
+  if (((uintptr_t)t.reg_targets & 15) == 0) {
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) S.stage[tid * 9 + d] = r[d];
+    }
+    __syncthreads();
+    store_rows(reg_dst, S.stage, nrows * 9, tid);
+  } else if (live) {
+#pragma unroll
+    for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], r[d]);
+  }
+  if (t.G == 0) return;
+  // The last workgroup to get here finishes the job.  Every store above that the tail depends on
+  // is write-through; drained per wave, then one agent-scope add per workgroup: the workgroup
+  // whose add comes last reads the others' entries with sc1 loads and may overwrite their rows.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) S.is_last = (atomicAdd(t.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!S.is_last) return;
+  if (t.G <= kForcedLds)
+    targets_tail<true>(t, *reinterpret_cast<TailLds *>(smem));
+  else
+    targets_tail<false>(t, *reinterpret_cast<TailLds *>(smem));
 }
 
 __global__ void k_targets_init(u64 *col_max, int *col_arg, int G, int *errflag,
-                               unsigned *cand_count) {
+                               unsigned *cand_count, unsigned *ticket) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < G) {
     col_max[j] = 0ull;
@@ -548,6 +734,7 @@ __global__ void k_targets_init(u64 *col_max, int *col_arg, int G, int *errflag,
   if (j == 0) {
     *errflag = 0;
     *cand_count = 0u;
+    *ticket = 0u;
   }
 }
 
@@ -721,11 +908,12 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard2 guard(ctx->device);
-  // scratch: [0,4096) flags/counters | col_max[Gcap] | col_arg[Gcap] | cand[A]
+  // scratch: [0,4096) flags/counters | col_max[Gcap] | col_arg[Gcap] | cand[workgroups * Gcap]
   const size_t gcap = (size_t)std::max<int64_t>(G, 1);
+  const size_t nwg = (size_t)((A + kTgtThreads - 1) / kTgtThreads);
   const size_t off_cmax = 4096, off_carg = off_cmax + gcap * 8;
   const size_t off_cand = (off_carg + gcap * 4 + 255) / 256 * 256;
-  const size_t need = off_cand + (size_t)A * 16;
+  const size_t need = off_cand + nwg * gcap * 16;
   bool grew = false;
   int rc = ctx->iou_ws.ensure(need, &grew);
   if (rc) return rc;
@@ -753,27 +941,22 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   t.num_classes = prm->num_classes;
   t.errflag = reinterpret_cast<int *>(ws);
   t.cand_count = reinterpret_cast<unsigned *>(ws + 64);
+  t.ticket = reinterpret_cast<unsigned *>(ws + 128);
   t.col_max = reinterpret_cast<u64 *>(ws + off_cmax);
   t.col_arg = reinterpret_cast<int *>(ws + off_carg);
   t.cand = reinterpret_cast<int4 *>(ws + off_cand);
-  t.cand_cap = (int)A;
   t.cls_targets = cls_targets;
   t.reg_targets = reg_targets;
-  // The scratch words are re-armed by k_targets_forced at the end of every call; only a
-  // fresh / regrown / re-shaped workspace (or a call without ground truths) needs the init.
+  // The scratch words are re-armed by the kernel's tail at the end of every call; only a
+  // fresh / regrown / re-shaped workspace needs the init.
   const unsigned long long key = ((unsigned long long)A << 20) ^ (unsigned long long)gcap;
-  if (grew || ctx->tgt_key != key || G == 0) {
+  if (grew || ctx->tgt_key != key) {
     const unsigned gb = (unsigned)((gcap + 255) / 256);
     hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_arg,
-                       (int)G, t.errflag, t.cand_count);
+                       (int)G, t.errflag, t.cand_count, t.ticket);
     ctx->tgt_key = key;
   }
-  const unsigned ab = (unsigned)((A + kIouThreads - 1) / kIouThreads);
-  hipLaunchKernelGGL(k_targets_rows, dim3(ab), dim3(kIouThreads), 0, stream, t);
-  if (G > 0) {
-    hipLaunchKernelGGL(k_targets_cols, dim3(ab), dim3(kIouThreads), 0, stream, t);
-    hipLaunchKernelGGL(k_targets_forced, dim3(1), dim3(kIouThreads), 0, stream, t);
-  }
+  hipLaunchKernelGGL(k_targets, dim3((unsigned)nwg), dim3(kTgtThreads), 0, stream, t);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
