@@ -145,6 +145,12 @@ __global__ __launch_bounds__(kIouThreads) void k_make_ious(
 // ------------------------------------------------------------------------- //
 // fused target assignment                                                    //
 // ------------------------------------------------------------------------- //
+struct ColEntry {
+  u64 key;   // gt | anchor << 32
+  u64 bits;  // IoU
+};
+static_assert(sizeof(ColEntry) == 16, "list entry layout");
+
 struct TargetArgs {
   int64_t A;
   int G;
@@ -160,11 +166,11 @@ struct TargetArgs {
   int num_classes;
   // scratch
   u64 *col_max;  // [G] bit pattern of the column maximum IoU (0 = all zero): the tail's scratch when
-  int *col_arg;  // [G] first anchor reaching it                 G is beyond its LDS
+  u64 *col_win;  // [G] {first anchor reaching it, its list entry}             G is beyond its LDS
   int *errflag;
   // per workgroup and ground truth it reaches with IoU > 0: {gt, first anchor of the workgroup's
-  // column maximum, maximum lo, hi}; at most G entries per workgroup
-  int4 *cand;            // [workgroups * G]
+  // column maximum}, the maximum's bits; at most G entries per workgroup
+  ColEntry *cand;        // [workgroups * G]
   unsigned *cand_count;  // entries appended
   unsigned *ticket;      // workgroups finished
   // outputs
@@ -181,10 +187,10 @@ struct AnchorId {
 
 __device__ __forceinline__ AnchorId anchor_id(const TargetArgs &t, int64_t i) {
   AnchorId a;
-  if (t.grid) {
-    const int64_t cell = i / t.per_cell;
-    a.d = (int)(i - cell * t.per_cell);
-    const int64_t y = cell / t.fm_w, x = cell - y * t.fm_w;
+  if (t.grid) {  // A <= INT_MAX / 2 (host check): 32-bit divisions
+    const unsigned iu = (unsigned)i, cell = iu / (unsigned)t.per_cell;
+    a.d = (int)(iu - cell * (unsigned)t.per_cell);
+    const unsigned y = cell / (unsigned)t.fm_w, x = cell - y * (unsigned)t.fm_w;
     a.cx = ((double)x + 0.5) / t.fm_scale;  // box_utils.py:137-138, same f64 operations
     a.cy = ((double)y + 0.5) / t.fm_scale;
   } else {
@@ -212,27 +218,24 @@ __device__ __forceinline__ void anchor_corners(const TargetArgs &t, int64_t i, d
   }
 }
 
-// utils/box_utils.py:70-109
-__device__ void make_target_dev(const TargetArgs &t, int64_t i, int j, float out[9]) {
-  double ax, ay, az, aw, al, ah, at;
-  if (t.grid) {
-    const AnchorId id = anchor_id(t, i);
-    const double *ty = t.types + id.d * kTypeCols;
-    ax = id.cx, ay = id.cy, az = ty[12];
-    aw = ty[8], al = ty[9], ah = ty[10], at = ty[11];
-  } else {
-    ax = t.a_centers[i * 3], ay = t.a_centers[i * 3 + 1], az = t.a_centers[i * 3 + 2];
-    aw = t.a_wlh[i * 3], al = t.a_wlh[i * 3 + 1], ah = t.a_wlh[i * 3 + 2];
-    at = t.a_yaw[i];
-  }
-  const double gx = t.g_centers[j * 3];
-  double gy = t.g_centers[j * 3 + 1];
-  const double gz = t.g_centers[j * 3 + 2];
-  const double gw = t.g_wlh[j * 3], gl = t.g_wlh[j * 3 + 1], gh = t.g_wlh[j * 3 + 2];
+// utils/box_utils.py:70-109.  The arithmetic is ONE out-of-line function on plain values (three
+// logs, a sine and a square root in f64 inlined at every use were most of the kernel's code, and a
+// by-reference argument would put the whole TargetArgs on the stack).
+struct Row9 {
+  float v[9];
+};
+struct BoxVals {
+  double x, y, z, w, l, h, yaw;
+};
+__device__ __noinline__ Row9 target_row(BoxVals a, BoxVals g, double canvas_height) {
+  Row9 res;
+  float *out = res.v;
+  const double ax = a.x, ay = a.y, az = a.z, aw = a.w, al = a.l, ah = a.h, at = a.yaw;
+  const double gx = g.x, gz = g.z, gw = g.w, gl = g.l, gh = g.h;
+  double gy = g.y, gt = g.yaw;
   const double ad = sqrt(aw * aw + al * al);
-  double gt = t.g_yaw[j];
   const double pi = 3.141592653589793;  // np.pi
-  gy = (t.canvas_height - 1) - gy;       // box_utils.py:83
+  gy = (canvas_height - 1) - gy;         // box_utils.py:83
   const double dx = (gx - ax) / ad;
   const double dy = (gy - ay) / ad;
   const double dz = (gz - az) / ah;
@@ -256,6 +259,24 @@ __device__ void make_target_dev(const TargetArgs &t, int64_t i, int j, float out
   out[6] = (float)dh;
   out[7] = (float)dt;
   out[8] = (float)ort;
+  return res;
+}
+__device__ __forceinline__ Row9 make_target_dev(const TargetArgs &t, int64_t i, int j) {
+  BoxVals a, g;
+  if (t.grid) {
+    const AnchorId id = anchor_id(t, i);
+    const double *ty = t.types + id.d * kTypeCols;
+    a.x = id.cx, a.y = id.cy, a.z = ty[12];
+    a.w = ty[8], a.l = ty[9], a.h = ty[10], a.yaw = ty[11];
+  } else {
+    a.x = t.a_centers[i * 3], a.y = t.a_centers[i * 3 + 1], a.z = t.a_centers[i * 3 + 2];
+    a.w = t.a_wlh[i * 3], a.l = t.a_wlh[i * 3 + 1], a.h = t.a_wlh[i * 3 + 2];
+    a.yaw = t.a_yaw[i];
+  }
+  g.x = t.g_centers[j * 3], g.y = t.g_centers[j * 3 + 1], g.z = t.g_centers[j * 3 + 2];
+  g.w = t.g_wlh[j * 3], g.l = t.g_wlh[j * 3 + 1], g.h = t.g_wlh[j * 3 + 2];
+  g.yaw = t.g_yaw[j];
+  return target_row(a, g, t.canvas_height);
 }
 
 __device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad,
@@ -297,23 +318,34 @@ constexpr int kPairsPerRound = kTgtThreads / kGroup;
 constexpr int kStageCols = 16;  // widest target row staged in LDS
 constexpr int kForcedLds = 2048;  // ground truths whose column results the tail keeps in LDS
 
+constexpr int kMaxNP = 2;        // pairs a group of 8 lanes clips side by side (independent chains interleave)
+constexpr int kLdsTypes = 8;     // anchor types per cell whose table is kept in LDS
+constexpr int kTailBatch = 8;    // list entries per thread the tail keeps in registers
+
 struct TgtLds {
   double2 gc[kGtChunk];                   // image-space centres of the chunk's ground truths
   double2 gk[kGtChunk][4];                // their corners
-  double2 poly[kPairsPerRound][kGroup];   // hand-over of a clip pass's output ring
+  double garea[kGtChunk];                 // their declared-orientation areas
+  union {
+    double2 poly[kMaxNP][kPairsPerRound][kGroup + 1];  // hand-over of a clip pass's output rings (+ a spare slot)
+    float stage[kTgtThreads * kStageCols];         // target rows on their way out
+  };
   double iou[kPairCap];
   u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
   int carg[kGtChunk];                     // first anchor reaching it
   unsigned short pair_lane[kPairCap], pair_gt[kPairCap];
+  double2 acen[kTgtThreads];              // the workgroup's anchor centres ...
+  unsigned short atype[kTgtThreads];      // ... and types (grid anchors)
+  double types[kLdsTypes][kTypeCols];
+  double bbox[kTgtWaves][4];
   int woff[kTgtWaves];
   int is_last;
-  float stage[kTgtThreads * kStageCols];
 };
 struct TailLds {
   u64 colmax[kForcedLds];
-  int colarg[kForcedLds];
-  unsigned char cls[kForcedLds];
+  u64 colwin[kForcedLds];
 };
+static_assert(sizeof(TailLds) <= sizeof(TgtLds), "the tail reuses the workgroup's LDS");
 constexpr size_t kTgtLdsBytes = sizeof(TgtLds) > sizeof(TailLds) ? sizeof(TgtLds) : sizeof(TailLds);
 
 __device__ __forceinline__ void iou_wave_sync() {
@@ -325,13 +357,14 @@ __device__ __forceinline__ void iou_wave_sync() {
 
 // shoelace_dev over a ring held one vertex per lane (lanes gbase .. gbase+n-1): the terms are
 // formed in parallel, the sum runs in the serial order
+template <int KMAX = kGroup>
 __device__ __forceinline__ double group_shoelace(double x, double y, int n, int v, int gbase) {
   const int succ = gbase + ((v + 1 >= n) ? 0 : v + 1);
   const double jx = __shfl(x, succ, 64), jy = __shfl(y, succ, 64);
   const double term = x * jy - jx * y;
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < kGroup; ++k) {
+  for (int k = 0; k < KMAX; ++k) {
     const double tk = __shfl(term, gbase + k, 64);
     if (k < n) s = s + tk;
   }
@@ -342,51 +375,125 @@ __device__ __forceinline__ double group_shoelace(double x, double y, int n, int 
 // vertex goes through the same operations in the same order as in the serial loop (dp of vertex
 // i is dc of vertex i-1, the same function of the same operands), and the output ring is laid
 // out in the serial order (crossing point before the kept vertex, vertices ascending): same
-// bits.  (cx, cy): this lane's anchor corner (v < 4); gk: the ground truth's corners in LDS.
-// All 64 lanes must call it together; lanes of idle groups pass zeros.
-__device__ __forceinline__ double clip_group(double cx, double cy, const double2 *gk, double2 *poly,
-                                             int v, int gbase, bool *wrong) {
-  const double area_a = group_shoelace(cx, cy, 4, v, gbase);
-  const double2 gv = gk[v & 3];
-  const double area_g = -group_shoelace(gv.x, gv.y, 4, v, gbase);
-  *wrong = (area_a < 0.0 || area_g < 0.0);
-  int n = 4;
+// bits.  A group clips NP pairs side by side: the chain of one pair is latency, not issue
+// slots alone, so two cost less than twice one.  (cx, cy): this lane's anchor corner of
+// pair u (v < 4); gk: that pair's ground-truth corners in LDS; area_g: its area.  All 64 lanes
+// call it together; lanes of idle groups / idle pairs pass zeros.
+template <int NP>
+__device__ __forceinline__ void clip_groups(double (&cx)[NP], double (&cy)[NP], const double2 *(&gk)[NP],
+                                            const double (&area_g)[NP], double2 *(&poly)[NP], int v, int gbase,
+                                            double (&iou)[NP], bool (&wrong)[NP]) {
+  double area_a[NP];
+  int n[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    area_a[u] = group_shoelace<4>(cx[u], cy[u], 4, v, gbase);
+    wrong[u] = (area_a[u] < 0.0 || area_g[u] < 0.0);
+    n[u] = 4;
+  }
   const unsigned below = (1u << v) - 1u;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int ia = (4 - e) & 3, ib = (3 - e) & 3;
-    const double2 a = gk[ia], b = gk[ib];
-    const double ex = b.x - a.x, ey = b.y - a.y;
-    const bool act = v < n;
-    const double dc = ex * (cy - a.y) - ey * (cx - a.x);
-    const int pred = gbase + ((v == 0) ? max(n - 1, 0) : v - 1);
-    const double dp = __shfl(dc, pred, 64), px = __shfl(cx, pred, 64), py = __shfl(cy, pred, 64);
-    const bool in_c = dc >= 0.0, in_p = dp >= 0.0;
-    const bool cross = act && (in_c != in_p), keep = act && in_c;
-    const unsigned cb = (unsigned)(__ballot(cross) >> gbase) & 0xFFu;
-    const unsigned kb = (unsigned)(__ballot(keep) >> gbase) & 0xFFu;
-    int pos = __popc(cb & below) + __popc(kb & below);
-    if (cross) {
-      const double tt = dp / (dp - dc);
-      // (a ninth vertex cannot come from two convex quads; never write past the ring)
-      if (pos < kGroup) poly[pos] = make_double2(px + tt * (cx - px), py + tt * (cy - py));
-      ++pos;
+    // stage by stage over the pairs, so that the source order already interleaves their chains
+    double ex[NP], ey[NP], ax[NP], ay[NP], dc[NP], dp[NP], px[NP], py[NP], tt[NP];
+    unsigned cb[NP], kb[NP];
+    bool cross[NP], keep[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const double2 a = gk[u][ia], b = gk[u][ib];
+      ax[u] = a.x;
+      ay[u] = a.y;
+      ex[u] = b.x - a.x;
+      ey[u] = b.y - a.y;
     }
-    if (keep && pos < kGroup) poly[pos] = make_double2(cx, cy);
-    n = min(__popc(cb) + __popc(kb), kGroup);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) dc[u] = ex[u] * (cy[u] - ay[u]) - ey[u] * (cx[u] - ax[u]);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int pred = gbase + ((v == 0) ? max(n[u] - 1, 0) : v - 1);
+      dp[u] = __shfl(dc[u], pred, 64);
+      px[u] = __shfl(cx[u], pred, 64);
+      py[u] = __shfl(cy[u], pred, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const bool act = v < n[u];
+      const bool in_c = dc[u] >= 0.0, in_p = dp[u] >= 0.0;
+      cross[u] = act && (in_c != in_p);
+      keep[u] = act && in_c;
+      cb[u] = (unsigned)(__ballot(cross[u]) >> gbase) & 0xFFu;
+      kb[u] = (unsigned)(__ballot(keep[u]) >> gbase) & 0xFFu;
+    }
+    // straight-line code: every lane divides and stores, lanes with nothing to emit into the
+    // spare slot.  (A ninth vertex cannot come from two convex quads; it would land there too.)
+#pragma unroll
+    for (int u = 0; u < NP; ++u) tt[u] = dp[u] / (dp[u] - dc[u]);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int pos = __popc(cb[u] & below) + __popc(kb[u] & below);
+      const int pc = cross[u] ? min(pos, kGroup) : kGroup;
+      const int pk = keep[u] ? min(pos + (cross[u] ? 1 : 0), kGroup) : kGroup;
+      poly[u][pc] = make_double2(px[u] + tt[u] * (cx[u] - px[u]), py[u] + tt[u] * (cy[u] - py[u]));
+      poly[u][pk] = make_double2(cx[u], cy[u]);
+      n[u] = min(__popc(cb[u]) + __popc(kb[u]), kGroup);
+    }
     iou_wave_sync();
-    if (v < n) {
-      const double2 c = poly[v];
-      cx = c.x;
-      cy = c.y;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const double2 c = poly[u][v];
+      cx[u] = (v < n[u]) ? c.x : cx[u];
+      cy[u] = (v < n[u]) ? c.y : cy[u];
     }
     iou_wave_sync();
   }
-  const double inter = group_shoelace(cx, cy, n, v, gbase);
-  if (*wrong) return -1.0;
-  if (n < 3) return 0.0;
-  if (!(inter > 0.0)) return 0.0;
-  return inter / (area_a + area_g - inter);
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const double inter = group_shoelace(cx[u], cy[u], n[u], v, gbase);
+    double r = inter / (area_a[u] + area_g[u] - inter);
+    if (!(inter > 0.0)) r = 0.0;
+    if (n[u] < 3) r = 0.0;
+    if (wrong[u]) r = -1.0;
+    iou[u] = r;
+  }
+}
+
+// one round of a window: pairs r0 + u*32 + group, u < NP
+template <int NP>
+__device__ __forceinline__ void clip_round(const TargetArgs &t, TgtLds &S, int r0, int wn, int64_t i0, int tid,
+                                           int v, int gbase, bool lds_types, bool &bad) {
+  double cx[NP], cy[NP], area_g[NP], iou[NP];
+  const double2 *gk[NP];
+  double2 *poly[NP];
+  bool wrong[NP];
+  int q[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    q[u] = r0 + u * kPairsPerRound + (tid >> 3);
+    const bool on = q[u] < wn;
+    const int pl = on ? S.pair_lane[q[u]] : 0, pg = on ? S.pair_gt[q[u]] : 0;
+    cx[u] = cy[u] = 0.0;
+    if (on && v < 4) {
+      if (t.grid) {
+        const double *ty = lds_types ? S.types[S.atype[pl]] : t.types + (int)S.atype[pl] * kTypeCols;
+        cx[u] = ty[2 * v] + S.acen[pl].x;
+        cy[u] = ty[2 * v + 1] + S.acen[pl].y;
+      } else {
+        cx[u] = t.a_corners[(i0 + pl) * 8 + 2 * v];
+        cy[u] = t.a_corners[(i0 + pl) * 8 + 2 * v + 1];
+      }
+    }
+    gk[u] = S.gk[pg];
+    area_g[u] = on ? S.garea[pg] : 0.0;
+    poly[u] = S.poly[u][tid >> 3];
+  }
+  clip_groups<NP>(cx, cy, gk, area_g, poly, v, gbase, iou, wrong);
+#pragma unroll
+  for (int u = 0; u < NP; ++u)
+    if (q[u] < wn && v == 0) {
+      S.iou[q[u]] = iou[u];
+      bad = bad || wrong[u];
+    }
 }
 
 __device__ __forceinline__ u64 ld_agent(const u64 *p) {
@@ -418,17 +525,24 @@ __device__ __forceinline__ void store_f32_sc1(float *p, float v) {
 
 // The last workgroup: column argmax from the workgroups' entries, then the forced rows.  A
 // column whose argmax is anchor 0 -- all-zero columns included -- is dropped, exactly like the
-// reference's np.nonzero filter (box_utils.py:204-205).  IN_LDS: the column words live in LDS
-// (G <= kForcedLds), else in the armed global scratch (0 / INT_MAX), which only this workgroup
-// touches: atomics and sc1 loads meet in its XCD's L2.
+// reference's np.nonzero filter (box_utils.py:204-205).
+// IN_LDS: the column words live in LDS (G <= kForcedLds), else in the armed global scratch
+// (0 / all ones), which only this workgroup touches: atomics and sc1 loads meet in its XCD's L2.
+#ifdef PP_IOU_STAMPS
+__device__ unsigned long long g_iou_stamps[16 * 4096];
+#define IOU_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_iou_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define IOU_STAMP(k) do {} while (0)
+#endif
+
 template <bool IN_LDS>
 __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
   const int G = t.G, tid = threadIdx.x;
   const unsigned n = __hip_atomic_load(t.cand_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   auto cmax_at = [&](int j) -> u64 * { return IN_LDS ? &T.colmax[j] : &t.col_max[j]; };
-  auto carg_at = [&](int j) -> int * { return IN_LDS ? &T.colarg[j] : &t.col_arg[j]; };
+  auto cwin_at = [&](int j) -> u64 * { return IN_LDS ? &T.colwin[j] : &t.col_win[j]; };
   auto cmax_ld = [&](int j) -> u64 { return IN_LDS ? T.colmax[j] : ld_agent(&t.col_max[j]); };
-  auto carg_ld = [&](int j) -> int { return IN_LDS ? T.colarg[j] : ld_agent(&t.col_arg[j]); };
+  auto cwin_ld = [&](int j) -> u64 { return IN_LDS ? T.colwin[j] : ld_agent(&t.col_win[j]); };
   auto sync = [&]() {
     if (!IN_LDS) __threadfence();
     __syncthreads();
@@ -436,67 +550,101 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
   if (IN_LDS)
     for (int j = tid; j < G; j += kTgtThreads) {
       T.colmax[j] = 0ull;
-      T.colarg[j] = INT_MAX;
+      T.colwin[j] = ~0ull;
     }
   __syncthreads();
-  auto entry = [&](unsigned e, int &j, int &anchor, u64 &bits) {
-    const u64 *q = reinterpret_cast<const u64 *>(t.cand + e);
-    const u64 lo = ld_agent(q), hi = ld_agent(q + 1);
-    j = (int)(lo & 0xFFFFFFFFull);
-    anchor = (int)(lo >> 32);
-    bits = hi;
-  };
-  for (unsigned e = tid; e < n; e += kTgtThreads) {
-    int j, anchor;
-    u64 bits;
-    entry(e, j, anchor, bits);
-    atomicMax(cmax_at(j), bits);
+  // The first 2048 entries (all of them on real scenes) are fetched once, every load in flight
+  // together.
+  u64 e_key[kTailBatch], e_bits[kTailBatch];
+#pragma unroll
+  for (int k = 0; k < kTailBatch; ++k) {
+    const unsigned e = (unsigned)(k * kTgtThreads + tid);
+    e_key[k] = e_bits[k] = 0ull;  // an entry's maximum is never 0
+    if (e < n) {
+      e_key[k] = ld_agent(&t.cand[e].key);
+      e_bits[k] = ld_agent(&t.cand[e].bits);
+    }
+  }
+  IOU_STAMP(11);
+#pragma unroll
+  for (int k = 0; k < kTailBatch; ++k)
+    if (e_bits[k]) atomicMax(cmax_at((int)(e_key[k] & 0xFFFFFFFFull)), e_bits[k]);
+  for (unsigned e = kTailBatch * kTgtThreads + tid; e < n; e += kTgtThreads)
+    atomicMax(cmax_at((int)(ld_agent(&t.cand[e].key) & 0xFFFFFFFFull)), ld_agent(&t.cand[e].bits));
+  sync();
+  // the first anchor that reaches the maximum, and the entry it came in
+#pragma unroll
+  for (int k = 0; k < kTailBatch; ++k) {
+    const int j = (int)(e_key[k] & 0xFFFFFFFFull);
+    if (e_bits[k] && e_bits[k] == cmax_ld(j))
+      atomicMin(cwin_at(j), (e_key[k] & 0xFFFFFFFF00000000ull) | (unsigned)(k * kTgtThreads + tid));
+  }
+  for (unsigned e = kTailBatch * kTgtThreads + tid; e < n; e += kTgtThreads) {
+    const u64 key = ld_agent(&t.cand[e].key);
+    const int j = (int)(key & 0xFFFFFFFFull);
+    if (ld_agent(&t.cand[e].bits) == cmax_ld(j)) atomicMin(cwin_at(j), (key & 0xFFFFFFFF00000000ull) | e);
   }
   sync();
-  for (unsigned e = tid; e < n; e += kTgtThreads) {
-    int j, anchor;
-    u64 bits;
-    entry(e, j, anchor, bits);
-    if (bits == cmax_ld(j)) atomicMin(carg_at(j), anchor);
-  }
-  sync();
-  // carg[j] <- the anchor ground truth j forces, 0 for none
+  IOU_STAMP(12);
+  // colwin[j] <- {anchor ground truth j forces, entry}; anchor 0: none
   for (int j = tid; j < G; j += kTgtThreads) {
-    const int i = (cmax_ld(j) != 0ull) ? carg_ld(j) : 0;
+    const u64 w = (cmax_ld(j) != 0ull) ? cwin_ld(j) : 0ull;
     if (IN_LDS) {
-      T.colarg[j] = i;
-      T.cls[j] = (unsigned char)t.g_class[j];
+      // anchor, class (63: a class outside the row, ignored like numpy would raise -- never written)
+      const unsigned gc = (unsigned)t.g_class[j];
+      T.colwin[j] = (w & 0xFFFFFFFF00000000ull) | (gc < 63u ? gc : 63u);
     } else {
-      __hip_atomic_store(&t.col_arg[j], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&t.col_win[j], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   sync();
-  if (IN_LDS && t.num_classes <= 64) {
-    for (int j = tid; j < G; j += kTgtThreads) {
-      const int i = T.colarg[j];
-      if (i == 0) continue;
-      // class row of anchor i: ones at the classes of ALL ground truths forcing it (every
-      // duplicate writes the same full row); regression row: the last ground truth wins
+  IOU_STAMP(13);
+  // the regression row of the last ground truth forcing an anchor
+  auto write_row = [&](int i, int j) {
+    const Row9 row = make_target_dev(t, i, j);
+    float *reg = t.reg_targets + (int64_t)i * 9;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) reg[d] = row.v[d];
+  };
+  if (IN_LDS && t.num_classes <= 63) {
+    // class row of a forced anchor i: ones at the classes of ALL ground truths forcing it (every
+    // duplicate writes the same full row); regression row: the last ground truth wins.  The scan
+    // over the ground truths for duplicates is split over the four waves (quarter q of the
+    // range each; a serial LDS scan was 90 ns per ground truth), merged in LDS.
+    const int q = tid >> 6, ql = tid & 63;
+    const int span = (G + kTgtWaves - 1) / kTgtWaves, qa = q * span, qb = min(G, qa + span);
+    for (int jb = 0; jb < G; jb += 64) {
+      const int j = jb + ql;
+      const u64 w = (j < G) ? T.colwin[j] : 0ull;
+      const int i = (int)(w >> 32);
       u64 mask = 0;
       bool later = false;
-      for (int j2 = 0; j2 < G; ++j2)
-        if (T.colarg[j2] == i) {
-          mask |= 1ull << (T.cls[j2] & 63);
-          later = later || (j2 > j);
+      if (i != 0) {
+#pragma unroll 8
+        for (int j2 = qa; j2 < qb; ++j2) {  // branch-free: the reads of one batch must not wait for each other
+          const u64 w2 = T.colwin[j2];
+          const bool hit = (int)(w2 >> 32) == i;
+          mask |= hit ? (1ull << (w2 & 63)) : 0ull;
+          later = later || (hit && j2 > j);
         }
-      float *cls = t.cls_targets + (int64_t)i * t.num_classes;
-      for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;
-      if (!later) {
-        float r[9];
-        make_target_dev(t, i, j, r);
-        float *reg = t.reg_targets + (int64_t)i * 9;
-        for (int d = 0; d < 9; ++d) reg[d] = r[d];
+      }
+      // merge: colmax is free by now
+      __syncthreads();
+      if (q == 0 && j < G) T.colmax[j] = 0ull;
+      __syncthreads();
+      if (i != 0) atomicOr(&T.colmax[j], (mask & 0x7FFFFFFFFFFFFFFFull) | (later ? 0x8000000000000000ull : 0ull));
+      __syncthreads();
+      if (q == 0 && i != 0) {
+        const u64 m = T.colmax[j];
+        float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+        for (int c = 0; c < t.num_classes; ++c) cls[c] = ((m >> c) & 1ull) ? 1.0f : 0.0f;
+        if (!(m >> 63)) write_row(i, j);
       }
     }
   } else {
     // phase A: clear the class rows of all forced anchors
     for (int j = tid; j < G; j += kTgtThreads) {
-      const int i = carg_ld(j);
+      const int i = (int)(cwin_ld(j) >> 32);
       if (i != 0) {
         float *cls = t.cls_targets + (int64_t)i * t.num_classes;
         for (int c = 0; c < t.num_classes; ++c) cls[c] = 0.0f;
@@ -507,26 +655,23 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
     // phase B: set the classes (duplicates of one anchor set several ones, as numpy's fancy
     // assignment does); regression row: the last ground truth wins
     for (int j = tid; j < G; j += kTgtThreads) {
-      const int i = carg_ld(j);
+      const u64 w = cwin_ld(j);
+      const int i = (int)(w >> 32);
       if (i == 0) continue;
       if ((unsigned)t.g_class[j] < (unsigned)t.num_classes)  // a class outside the row is ignored, never written
         t.cls_targets[(int64_t)i * t.num_classes + t.g_class[j]] = 1.0f;
       bool later = false;
-      for (int j2 = j + 1; j2 < G; ++j2) later = later || (carg_ld(j2) == i);
-      if (!later) {
-        float r[9];
-        make_target_dev(t, i, j, r);
-        float *reg = t.reg_targets + (int64_t)i * 9;
-        for (int d = 0; d < 9; ++d) reg[d] = r[d];
-      }
+      for (int j2 = j + 1; j2 < G; ++j2) later = later || ((int)(cwin_ld(j2) >> 32) == i);
+      if (!later) write_row(i, j);
     }
   }
+  IOU_STAMP(14);
   // re-arm the scratch words for the next call on this context
   __syncthreads();
   if (!IN_LDS)
     for (int j = tid; j < G; j += kTgtThreads) {
       t.col_max[j] = 0ull;
-      t.col_arg[j] = INT_MAX;
+      t.col_win[j] = ~0ull;
     }
   if (tid == 0) {
     *t.cand_count = 0u;
@@ -542,15 +687,81 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
   const int64_t i0 = (int64_t)blockIdx.x * kTgtThreads;
   const int64_t i = i0 + tid;
   const bool live = i < t.A;
+  IOU_STAMP(0);
   double acx = 0, acy = 0;
   if (live) {
     const AnchorId id = anchor_id(t, i);
     acx = id.cx;
     acy = id.cy;
+    S.acen[tid] = make_double2(acx, acy);
+    S.atype[tid] = (unsigned short)id.d;
   }
+  // Bounding box of the workgroup's anchor centres: a ground truth further than the gate's 10
+  // (+1: rounding of the gate's subtraction, whatever the magnitudes) from it is far from every
+  // anchor here, and most are -- the gate loop runs over the few that are left.
+  double bx0, bx1, by0, by1;
+  if (t.grid) {
+    const unsigned pc = (unsigned)t.per_cell, fw = (unsigned)t.fm_w;
+    const unsigned c0 = (unsigned)i0 / pc, c1 = (unsigned)(min(i0 + kTgtThreads, t.A) - 1) / pc;
+    const unsigned y0 = c0 / fw, y1 = c1 / fw;
+    const unsigned x0 = (y0 == y1) ? c0 - y0 * fw : 0u, x1 = (y0 == y1) ? c1 - y1 * fw : fw - 1u;
+    bx0 = ((double)x0 + 0.5) / t.fm_scale;
+    bx1 = ((double)x1 + 0.5) / t.fm_scale;
+    by0 = ((double)y0 + 0.5) / t.fm_scale;
+    by1 = ((double)y1 + 0.5) / t.fm_scale;
+  } else {
+    double mnx = live ? acx : INFINITY, mxx = live ? acx : -INFINITY;
+    double mny = live ? acy : INFINITY, mxy = live ? acy : -INFINITY;
+    const bool odd = live && !(acx == acx && acy == acy);  // a NaN centre passes every gate
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      mnx = fmin(mnx, __shfl_xor(mnx, d, 64));
+      mxx = fmax(mxx, __shfl_xor(mxx, d, 64));
+      mny = fmin(mny, __shfl_xor(mny, d, 64));
+      mxy = fmax(mxy, __shfl_xor(mxy, d, 64));
+    }
+    if (lane == 0) {
+      const bool any_odd = __ballot(odd) != 0ull;
+      S.bbox[wv][0] = any_odd ? -INFINITY : mnx;
+      S.bbox[wv][1] = any_odd ? INFINITY : mxx;
+      S.bbox[wv][2] = any_odd ? -INFINITY : mny;
+      S.bbox[wv][3] = any_odd ? INFINITY : mxy;
+    }
+    __syncthreads();
+    bx0 = S.bbox[0][0], bx1 = S.bbox[0][1], by0 = S.bbox[0][2], by1 = S.bbox[0][3];
+#pragma unroll
+    for (int w = 1; w < kTgtWaves; ++w) {
+      bx0 = fmin(bx0, S.bbox[w][0]);
+      bx1 = fmax(bx1, S.bbox[w][1]);
+      by0 = fmin(by0, S.bbox[w][2]);
+      by1 = fmax(by1, S.bbox[w][3]);
+    }
+  }
+  const double fx0 = bx0 - 11.0, fx1 = bx1 + 11.0, fy0 = by0 - 11.0, fy1 = by1 + 11.0;
+  const bool lds_types = t.grid && t.per_cell <= kLdsTypes;
+  if (lds_types)
+    for (int k = tid; k < t.per_cell * kTypeCols; k += kTgtThreads) S.types[0][k] = t.types[k];
   double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
   int best_j = 0;
   bool bad = false;
+  // this workgroup's columns of a chunk -> the list (at most one entry per ground truth)
+  auto append_columns = [&](int j0, int gn) {
+    if (wv != 0) return;
+    const bool touched = lane < gn && S.cmax[lane] != 0ull;
+    const u64 tb = __ballot(touched);
+    if (!tb) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(t.cand_count, (unsigned)__popcll(tb));
+    base = (unsigned)__shfl((int)base, 0, 64);
+    if (touched) {
+      const unsigned pos = base + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
+      ColEntry *ce = t.cand + pos;
+      __hip_atomic_store(&ce->key, (u64)(unsigned)(j0 + lane) | ((u64)(unsigned)S.carg[lane] << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ce->bits, S.cmax[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  int last_j0 = 0, last_gn = 0;  // the last chunk's columns are appended behind the row stores
   for (int j0 = 0; j0 < t.G; j0 += kGtChunk) {
     const int gn = min(kGtChunk, t.G - j0);
     __syncthreads();
@@ -565,11 +776,31 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       S.gk[k >> 2][k & 3] = make_double2(gp[0], gp[1]);
     }
     __syncthreads();
+    IOU_STAMP(1);
+    // the chunk's ground truths near this workgroup (every wave works out the same mask)
+    bool near = false;
+    if (lane < gn) {
+      const double2 gcn = S.gc[lane];
+      near = !(gcn.x < fx0 || gcn.x > fx1 || gcn.y < fy0 || gcn.y > fy1);
+    }
+    const u64 nb = __ballot(near);
+    if (nb == 0ull) continue;
+    if (near && wv == 0) {  // read after the next barrier
+      double g8[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g8[2 * k] = S.gk[lane][k].x;
+        g8[2 * k + 1] = S.gk[lane][k].y;
+      }
+      S.garea[lane] = -shoelace_dev(g8, 4);
+    }
     // gate: the survivors of this chunk as a mask
     u64 mask = 0;
     if (live)
-      for (int j = 0; j < gn; ++j)
+      for (u64 m = nb; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
         mask |= (u64)(gate_far(acx, acy, S.gc[j].x, S.gc[j].y) ? 0 : 1) << j;
+      }
     const int cnt = __popcll(mask);
     // exclusive prefix sum of the counts over the workgroup (wave scans + wave totals)
     int inc = cnt;
@@ -587,6 +818,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       total += S.woff[w];
     }
     const int my_off = wave_base + inc - cnt;
+    IOU_STAMP(2);
     if (total == 0) continue;
     for (int wb = 0; wb < total; wb += kPairCap) {
       const int wn = min(kPairCap, total - wb);
@@ -605,31 +837,16 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
         }
       }
       __syncthreads();
-      // clip: 32 pairs per round
-      for (int r0 = 0; r0 < wn; r0 += kPairsPerRound) {
-        const int q = r0 + (tid >> 3);
-        const bool on = q < wn;
-        const int pl = on ? S.pair_lane[q] : 0, pg = on ? S.pair_gt[q] : 0;
-        double cx = 0, cy = 0;
-        if (on && v < 4) {
-          if (t.grid) {
-            const AnchorId id = anchor_id(t, i0 + pl);
-            const double *ty = t.types + id.d * kTypeCols;
-            cx = ty[2 * v] + id.cx;
-            cy = ty[2 * v + 1] + id.cy;
-          } else {
-            cx = t.a_corners[(i0 + pl) * 8 + 2 * v];
-            cy = t.a_corners[(i0 + pl) * 8 + 2 * v + 1];
-          }
-        }
-        bool wrong;
-        const double iou = clip_group(cx, cy, S.gk[pg], S.poly[tid >> 3], v, gbase, &wrong);
-        if (on && v == 0) {
-          S.iou[q] = iou;
-          bad = bad || wrong;
-        }
+      IOU_STAMP(3);
+      // clip: 32 groups of 8 lanes, one or two pairs each per round
+      for (int r0 = 0; r0 < wn; r0 += kMaxNP * kPairsPerRound) {
+        if (wn - r0 <= kPairsPerRound)
+          clip_round<1>(t, S, r0, wn, i0, tid, v, gbase, lds_types, bad);
+        else
+          clip_round<kMaxNP>(t, S, r0, wn, i0, tid, v, gbase, lds_types, bad);
       }
       __syncthreads();
+      IOU_STAMP(4);
       // rows: this anchor's slice of the window, ascending gt; strict >: first maximum wins
       if (cnt > 0) {
         const int qa = max(my_off, wb), qb = min(my_off + cnt, wb + wn);
@@ -660,33 +877,23 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       }
       __syncthreads();
     }
-    // this workgroup's columns of the chunk -> the list
-    if (wv == 0) {
-      const bool touched = lane < gn && S.cmax[lane] != 0ull;
-      const u64 tb = __ballot(touched);
-      if (tb) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(t.cand_count, (unsigned)__popcll(tb));
-        base = (unsigned)__shfl((int)base, 0, 64);
-        if (touched) {
-          const unsigned pos = base + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
-          const u64 bits = S.cmax[lane];
-          u64 *q = reinterpret_cast<u64 *>(t.cand + pos);  // {gt, anchor}, bits
-          __hip_atomic_store(q, (u64)(unsigned)(j0 + lane) | ((u64)(unsigned)S.carg[lane] << 32), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(q + 1, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+    if (j0 + kGtChunk < t.G) {
+      append_columns(j0, gn);
+    } else {
+      last_j0 = j0;
+      last_gn = gn;
     }
   }
+  IOU_STAMP(5);
   if (bad) atomicExch(t.errflag, 1);
   // rows: positives of both targets, zero rows otherwise
   const int nc = t.num_classes;
   const int nrows = (int)min((int64_t)kTgtThreads, t.A - i0);
   const bool pos = live && best > t.pos_thresh;  // box_utils.py:195 (strict >)
   const int cj = pos ? t.g_class[best_j] : -1;
-  float r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (pos) make_target_dev(t, i, best_j, r);
+  Row9 row = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  if (pos) row = make_target_dev(t, i, best_j);
+  const float *r = row.v;
   float *cls_dst = t.cls_targets + i0 * nc, *reg_dst = t.reg_targets + i0 * 9;
   __syncthreads();
   if (nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0) {
@@ -709,27 +916,33 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
 #pragma unroll
     for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], r[d]);
   }
+  IOU_STAMP(6);
   if (t.G == 0) return;
+  append_columns(last_j0, last_gn);  // its counter round trip overlaps the drain of the row stores
   // The last workgroup to get here finishes the job.  Every store above that the tail depends on
   // is write-through; drained per wave, then one agent-scope add per workgroup: the workgroup
   // whose add comes last reads the others' entries with sc1 loads and may overwrite their rows.
+  IOU_STAMP(7);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  IOU_STAMP(8);
   if (tid == 0) S.is_last = (atomicAdd(t.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
   __syncthreads();
+  IOU_STAMP(9);
   if (!S.is_last) return;
   if (t.G <= kForcedLds)
     targets_tail<true>(t, *reinterpret_cast<TailLds *>(smem));
   else
     targets_tail<false>(t, *reinterpret_cast<TailLds *>(smem));
+  IOU_STAMP(10);
 }
 
-__global__ void k_targets_init(u64 *col_max, int *col_arg, int G, int *errflag,
+__global__ void k_targets_init(u64 *col_max, u64 *col_win, int G, int *errflag,
                                unsigned *cand_count, unsigned *ticket) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < G) {
     col_max[j] = 0ull;
-    col_arg[j] = INT_MAX;
+    col_win[j] = ~0ull;
   }
   if (j == 0) {
     *errflag = 0;
@@ -908,12 +1121,12 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard2 guard(ctx->device);
-  // scratch: [0,4096) flags/counters | col_max[Gcap] | col_arg[Gcap] | cand[workgroups * Gcap]
+  // scratch: [0,4096) flags/counters | col_max[Gcap] | col_win[Gcap] | cand[workgroups * Gcap]
   const size_t gcap = (size_t)std::max<int64_t>(G, 1);
   const size_t nwg = (size_t)((A + kTgtThreads - 1) / kTgtThreads);
-  const size_t off_cmax = 4096, off_carg = off_cmax + gcap * 8;
-  const size_t off_cand = (off_carg + gcap * 4 + 255) / 256 * 256;
-  const size_t need = off_cand + nwg * gcap * 16;
+  const size_t off_cmax = 4096, off_cwin = off_cmax + gcap * 8;
+  const size_t off_cand = (off_cwin + gcap * 8 + 255) / 256 * 256;
+  const size_t need = off_cand + nwg * gcap * sizeof(ColEntry);
   bool grew = false;
   int rc = ctx->iou_ws.ensure(need, &grew);
   if (rc) return rc;
@@ -943,8 +1156,8 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   t.cand_count = reinterpret_cast<unsigned *>(ws + 64);
   t.ticket = reinterpret_cast<unsigned *>(ws + 128);
   t.col_max = reinterpret_cast<u64 *>(ws + off_cmax);
-  t.col_arg = reinterpret_cast<int *>(ws + off_carg);
-  t.cand = reinterpret_cast<int4 *>(ws + off_cand);
+  t.col_win = reinterpret_cast<u64 *>(ws + off_cwin);
+  t.cand = reinterpret_cast<ColEntry *>(ws + off_cand);
   t.cls_targets = cls_targets;
   t.reg_targets = reg_targets;
   // The scratch words are re-armed by the kernel's tail at the end of every call; only a
@@ -952,7 +1165,7 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   const unsigned long long key = ((unsigned long long)A << 20) ^ (unsigned long long)gcap;
   if (grew || ctx->tgt_key != key) {
     const unsigned gb = (unsigned)((gcap + 255) / 256);
-    hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_arg,
+    hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_win,
                        (int)G, t.errflag, t.cand_count, t.ticket);
     ctx->tgt_key = key;
   }
@@ -1006,3 +1219,11 @@ extern "C" int pp_assign_targets_grid_dev(pp_ctx_t *ctx, void *stream_, int fm_h
                              g_centers_img, g_centers, g_wlh, g_yaw, g_class, prm, cls_targets,
                              reg_targets);
 }
+
+#ifdef PP_IOU_STAMPS
+// development builds only (tools/lab): the phase stamps of the last k_targets launch, 16 per workgroup
+extern "C" int pp_debug_iou_stamps(unsigned long long *out, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return PP_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_iou_stamps), (size_t)n_words * 8) == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+#endif
