@@ -261,8 +261,9 @@ __device__ __noinline__ Row9 target_row(BoxVals a, BoxVals g, double canvas_heig
   out[8] = (float)ort;
   return res;
 }
-__device__ __forceinline__ Row9 make_target_dev(const TargetArgs &t, int64_t i, int j) {
-  BoxVals a, g;
+
+__device__ __forceinline__ BoxVals anchor_vals(const TargetArgs &t, int64_t i) {
+  BoxVals a;
   if (t.grid) {
     const AnchorId id = anchor_id(t, i);
     const double *ty = t.types + id.d * kTypeCols;
@@ -273,10 +274,41 @@ __device__ __forceinline__ Row9 make_target_dev(const TargetArgs &t, int64_t i, 
     a.w = t.a_wlh[i * 3], a.l = t.a_wlh[i * 3 + 1], a.h = t.a_wlh[i * 3 + 2];
     a.yaw = t.a_yaw[i];
   }
+  return a;
+}
+__device__ __forceinline__ BoxVals gt_vals(const TargetArgs &t, int j) {
+  BoxVals g;
   g.x = t.g_centers[j * 3], g.y = t.g_centers[j * 3 + 1], g.z = t.g_centers[j * 3 + 2];
   g.w = t.g_wlh[j * 3], g.l = t.g_wlh[j * 3 + 1], g.h = t.g_wlh[j * 3 + 2];
   g.yaw = t.g_yaw[j];
-  return target_row(a, g, t.canvas_height);
+  return g;
+}
+
+// target_row spread over the 8 lanes of a group: lane v returns element v + 1 of the row (element 0
+// is the constant 1).  One row on one lane is a 2 us chain (a square root, six divisions, three
+// logs and a sine, one after the other); here the three quotients, the three logs and the sine
+// each run once for the whole group.  Same operations on the same operands: same bits.
+__device__ __forceinline__ float target_component(const BoxVals &a, const BoxVals &g, double canvas_height, int v) {
+  const double pi = 3.141592653589793;  // np.pi
+  const double ad = sqrt(a.w * a.w + a.l * a.l);
+  const double gy = (canvas_height - 1) - g.y;  // box_utils.py:83
+  double gt = g.yaw;
+  if (gt <= pi && gt >= pi / 2)  // box_utils.py:92-95
+    gt -= pi;
+  else if (gt >= -pi && gt <= -pi / 2)
+    gt += pi;
+  const double df = gt - a.yaw;
+  const double num = v == 0 ? g.x - a.x : v == 1 ? gy - a.y : v == 2 ? g.z - a.z : v == 3 ? g.w : v == 4 ? g.l : g.h;
+  const double den = v < 2 ? ad : v == 2 ? a.h : v == 3 ? a.w : v == 4 ? a.l : a.h;
+  double r = num / den;  // dx, dy, dz
+  if (v >= 3 && v <= 5) r = log(r);  // dw, dl, dh
+  if (v == 6) r = sin(df);
+  if (v == 7) r = ((df <= pi && df >= pi / 2) || (df >= -pi && df <= -pi / 2)) ? 1.0 : 0.0;  // :99-102
+  return (float)r;
+}
+
+__device__ __forceinline__ Row9 make_target_dev(const TargetArgs &t, int64_t i, int j) {
+  return target_row(anchor_vals(t, i), gt_vals(t, j), t.canvas_height);
 }
 
 __device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad,
@@ -638,6 +670,7 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
         const u64 m = T.colmax[j];
         float *cls = t.cls_targets + (int64_t)i * t.num_classes;
         for (int c = 0; c < t.num_classes; ++c) cls[c] = ((m >> c) & 1ull) ? 1.0f : 0.0f;
+        // (one lane per row: 8 lanes per row take two rounds of dependent loads for 40 rows -- slower)
         if (!(m >> 63)) write_row(i, j);
       }
     }
@@ -891,30 +924,60 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
   const int nrows = (int)min((int64_t)kTgtThreads, t.A - i0);
   const bool pos = live && best > t.pos_thresh;  // box_utils.py:195 (strict >)
   const int cj = pos ? t.g_class[best_j] : -1;
-  Row9 row = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
-  if (pos) row = make_target_dev(t, i, best_j);
-  const float *r = row.v;
   float *cls_dst = t.cls_targets + i0 * nc, *reg_dst = t.reg_targets + i0 * 9;
+  // the positives, lined up for the groups of 8 lanes that work their regression rows out
+  const u64 pb = __ballot(pos);
+  if (lane == 0) S.woff[wv] = __popcll(pb);
   __syncthreads();
-  if (nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0) {
+  int pbase = 0, npos = 0;
+#pragma unroll
+  for (int w = 0; w < kTgtWaves; ++w) {
+    if (w < wv) pbase += S.woff[w];
+    npos += S.woff[w];
+  }
+  if (pos) {
+    const int k = pbase + __popcll(pb & ((1ull << lane) - 1ull));
+    S.pair_lane[k] = (unsigned short)tid;
+    S.pair_gt[k] = (unsigned short)best_j;
+  }
+  const bool cls_staged = nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0;
+  if (cls_staged) {
     if (live)
       for (int c = 0; c < nc; ++c) S.stage[tid * nc + c] = (c == cj) ? 1.0f : 0.0f;
     __syncthreads();
     store_rows(cls_dst, S.stage, nrows * nc, tid);
-    __syncthreads();
   } else if (live) {
     for (int c = 0; c < nc; ++c) store_f32_sc1(&cls_dst[(int64_t)tid * nc + c], (c == cj) ? 1.0f : 0.0f);
   }
-  if (((uintptr_t)t.reg_targets & 15) == 0) {
-    if (live) {
+  __syncthreads();
+  if (live) {
 #pragma unroll
-      for (int d = 0; d < 9; ++d) S.stage[tid * 9 + d] = r[d];
+    for (int d = 0; d < 9; ++d) S.stage[tid * 9 + d] = 0.0f;
+  }
+  __syncthreads();
+  for (int k0 = 0; k0 < npos; k0 += kPairsPerRound) {
+    const int k = k0 + (tid >> 3);
+    if (k < npos) {
+      const int pl = S.pair_lane[k];
+      BoxVals a;
+      if (lds_types) {  // centre and type row are in LDS already
+        const double *ty = S.types[S.atype[pl]];
+        a.x = S.acen[pl].x, a.y = S.acen[pl].y, a.z = ty[12];
+        a.w = ty[8], a.l = ty[9], a.h = ty[10], a.yaw = ty[11];
+      } else {
+        a = anchor_vals(t, i0 + pl);
+      }
+      const float val = target_component(a, gt_vals(t, S.pair_gt[k]), t.canvas_height, v);
+      S.stage[pl * 9 + 1 + v] = val;
+      if (v == 0) S.stage[pl * 9] = 1.0f;
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (((uintptr_t)t.reg_targets & 15) == 0) {
     store_rows(reg_dst, S.stage, nrows * 9, tid);
   } else if (live) {
 #pragma unroll
-    for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], r[d]);
+    for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], S.stage[tid * 9 + d]);
   }
   IOU_STAMP(6);
   if (t.G == 0) return;
