@@ -41,6 +41,7 @@ struct DecodeArgs {
   const float *cls;
   const float *reg;
   int64_t cls_sc, cls_sp, reg_sc, reg_sp;
+  int64_t cls_sb, reg_sb;  // floats from one sample of the batch to the next (sample = blockIdx.y)
   const double *a_centers, *a_wlh, *a_yaw, *a_xy;
   int A, Ac, C, HW;
   float pos_thresh, nms_thresh;
@@ -54,6 +55,20 @@ struct DecodeArgs {
   int *count;     // number kept
   double *boxes;  // [max_out][9] x,y,z,w,l,h,yaw,score,class
 };
+
+// the arguments of sample b = blockIdx.y of the batch: its slices of the inputs, its keys and
+// counter, its output rows
+__device__ __forceinline__ DecodeArgs sample_view(DecodeArgs d) {
+  const int64_t b = blockIdx.y;
+  d.cls += b * d.cls_sb;
+  d.reg += b * d.reg_sb;
+  d.keys += b * (int64_t)d.cap;
+  d.ncand += b;
+  d.kept += b * d.max_out;
+  d.count += b;
+  d.boxes += b * (int64_t)d.max_out * 9;
+  return d;
+}
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -72,7 +87,8 @@ __device__ __forceinline__ void anchor_score(const DecodeArgs &d, int a, float &
   }
 }
 
-__global__ __launch_bounds__(256) void k_score(DecodeArgs d) {
+__global__ __launch_bounds__(256) void k_score(DecodeArgs d_) {
+  const DecodeArgs d = sample_view(d_);
   const int a = blockIdx.x * 256 + threadIdx.x;
   float s = 0.0f;
   int c;
@@ -114,7 +130,8 @@ __device__ __forceinline__ void bitonic_sort(u64 *buf, int n2, int t) {
 }
 
 // run r = candidates [r*run, (r+1)*run): sorted in LDS, written back padded with sentinels
-__global__ __launch_bounds__(kSortThreads) void k_sort_runs(DecodeArgs d, int run) {
+__global__ __launch_bounds__(kSortThreads) void k_sort_runs(DecodeArgs d_, int run) {
+  const DecodeArgs d = sample_view(d_);
   extern __shared__ __attribute__((aligned(16))) u64 s_run[];
   const int M = min(*d.ncand, d.cap);
   const int base = blockIdx.x * run;
@@ -194,8 +211,9 @@ __device__ void decode_row(const DecodeArgs &d, int i, int a) {
   o[8] = (double)klass;
 }
 
-// One workgroup; chunks of kChunkN = 256 candidates in key order, four threads per candidate.
-__global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
+// One workgroup per sample; chunks of kChunkN = 256 candidates in key order, four threads per candidate.
+__global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
+  const DecodeArgs d = sample_view(d_);
   __shared__ NmsBox s_kept[kMaxOut];
   __shared__ NmsBox s_chunk[kChunkN];
   __shared__ u64 s_mask[kChunkN][kChunkN / 64];  // s_mask[i]: later chunk members i suppresses
@@ -336,12 +354,15 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d) {
 
 using namespace pp;
 
-extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev,
-                                     const float *reg_dev, int64_t cls_stride_c,
-                                     int64_t cls_stride_pix, int64_t reg_stride_c,
-                                     int64_t reg_stride_pix, const double *a_centers, const double *a_wlh, const double *a_yaw,
-                             const double *a_xy, const pp_decode_params_t *prm, double *boxes_out,
-                             int32_t *kept_out, int32_t *count_out) {
+constexpr size_t kCounterBytes = 4096;  // one candidate counter per sample at the head of the scratch
+constexpr int kMaxDecodeBatch = (int)(kCounterBytes / 4);
+
+extern "C" int pp_decode_batch_dev(pp_ctx_t *ctx, void *stream_, int32_t batch, const float *cls_dev,
+                                   const float *reg_dev, int64_t cls_stride_b, int64_t cls_stride_c,
+                                   int64_t cls_stride_pix, int64_t reg_stride_b, int64_t reg_stride_c,
+                                   int64_t reg_stride_pix, const double *a_centers, const double *a_wlh,
+                                   const double *a_yaw, const double *a_xy, const pp_decode_params_t *prm,
+                                   double *boxes_out, int32_t *kept_out, int32_t *count_out) {
   if (!ctx || !cls_dev || !reg_dev || !a_centers || !a_wlh || !a_yaw || !a_xy || !prm || !boxes_out ||
       !kept_out || !count_out) {
     set_error("pp_decode_dev: NULL argument");
@@ -351,6 +372,10 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
   if (prm->fm_height < 1 || prm->fm_width < 1 || prm->anchors_per_cell < 1 || prm->num_classes < 1 ||
       A >= (1 << 20) || prm->max_out < 1 || prm->max_out > kMaxOut) {
     set_error("pp_decode_dev: need 1 <= anchors < 2^20 and 1 <= max_out <= %d", kMaxOut);
+    return PP_ERR_VALUE;
+  }
+  if (batch < 1 || batch > kMaxDecodeBatch) {
+    set_error("pp_decode_batch_dev: need 1 <= batch <= %d", kMaxDecodeBatch);
     return PP_ERR_VALUE;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -365,13 +390,13 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
   } restore{prev, ctx->device};
   size_t cap = 1;
   while (cap < (size_t)A) cap <<= 1;
-  const size_t keys_bytes = cap * 8;
+  // scratch: [0, 4096) candidate counters (zero between calls) | keys [batch][cap]
   bool grew = false;
-  int rc = ctx->decode_ws.ensure(keys_bytes + 256, &grew);
+  int rc = ctx->decode_ws.ensure(kCounterBytes + (size_t)batch * cap * 8, &grew);
   if (rc) return rc;
-  if (grew)  // the candidate counter starts at zero; k_nms leaves it at zero
-    PP_HIP_TRY(hipMemsetAsync(static_cast<char *>(ctx->decode_ws.ptr) + ctx->decode_ws.bytes - 256, 0, 256, stream));
   char *ws = static_cast<char *>(ctx->decode_ws.ptr);
+  if (grew)  // the counters start at zero; k_nms leaves them at zero
+    PP_HIP_TRY(hipMemsetAsync(ws, 0, kCounterBytes, stream));
   DecodeArgs d;
   d.cls = cls_dev;
   d.reg = reg_dev;
@@ -379,6 +404,8 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
   d.cls_sp = cls_stride_pix;
   d.reg_sc = reg_stride_c;
   d.reg_sp = reg_stride_pix;
+  d.cls_sb = cls_stride_b;
+  d.reg_sb = reg_stride_b;
   d.a_centers = a_centers;
   d.a_wlh = a_wlh;
   d.a_yaw = a_yaw;
@@ -395,13 +422,14 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
   d.y_step = prm->y_step;
   d.x_min = prm->x_min;
   d.y_min = prm->y_min;
-  d.keys = reinterpret_cast<u64 *>(ws);
-  d.ncand = reinterpret_cast<int *>(ws + ctx->decode_ws.bytes - 256);
+  d.keys = reinterpret_cast<u64 *>(ws + kCounterBytes);
+  d.ncand = reinterpret_cast<int *>(ws);
   d.cap = (int)cap;
   d.kept = kept_out;
   d.count = count_out;
   d.boxes = boxes_out;
-  hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, stream, d);
+  const unsigned nb = (unsigned)batch;
+  hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256), nb), dim3(256), 0, stream, d);
   d.run = (int)std::min<size_t>(kRun, cap);
   {
     static thread_local bool armed = false;  // 128 KiB of dynamic LDS needs the attribute
@@ -412,10 +440,20 @@ extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *
     }
   }
   const unsigned nrun_wgs = (unsigned)std::min<size_t>(kMaxRuns, cap / d.run);
-  hipLaunchKernelGGL(k_sort_runs, dim3(nrun_wgs), dim3(kSortThreads), (size_t)d.run * 8, stream, d, d.run);
-  hipLaunchKernelGGL(k_nms, dim3(1), dim3(kNmsThreads), 0, stream, d);  // + box decode
+  hipLaunchKernelGGL(k_sort_runs, dim3(nrun_wgs, nb), dim3(kSortThreads), (size_t)d.run * 8, stream, d, d.run);
+  hipLaunchKernelGGL(k_nms, dim3(1, nb), dim3(kNmsThreads), 0, stream, d);  // + box decode
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
+}
+
+extern "C" int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev,
+                                     const float *reg_dev, int64_t cls_stride_c,
+                                     int64_t cls_stride_pix, int64_t reg_stride_c,
+                                     int64_t reg_stride_pix, const double *a_centers, const double *a_wlh,
+                                     const double *a_yaw, const double *a_xy, const pp_decode_params_t *prm,
+                                     double *boxes_out, int32_t *kept_out, int32_t *count_out) {
+  return pp_decode_batch_dev(ctx, stream_, 1, cls_dev, reg_dev, 0, cls_stride_c, cls_stride_pix, 0, reg_stride_c,
+                             reg_stride_pix, a_centers, a_wlh, a_yaw, a_xy, prm, boxes_out, kept_out, count_out);
 }
 
 extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev, const float *reg_dev,

@@ -33,29 +33,37 @@ class Detector:
         self._ctx = _lib.Context(self.device.index)
 
     def __call__(self, cls, reg):
-        """``cls [Ac*C,H,W]``, ``reg [Ac*8,H,W]`` float32: ONE sample of PPModel's output.
-        Returns ``(boxes[max_out,9] f64, kept[max_out] i32, count[1] i32)`` device tensors:
-        car-space x,y,z,w,l,h,yaw,score,class; rows beyond ``count`` are zero."""
-        if cls.dim() == 4:
-            if cls.shape[0] != 1:
-                raise ValueError("one sample at a time (evaluate.py uses batch_size=1)")
-            cls, reg = cls[0], reg[0]
+        """``cls [Ac*C,H,W]``, ``reg [Ac*8,H,W]`` float32: ONE sample of PPModel's output -- returns
+        ``(boxes[max_out,9] f64, kept[max_out] i32, count[1] i32)`` device tensors: car-space
+        x,y,z,w,l,h,yaw,score,class; rows beyond ``count`` are zero.  With a leading batch
+        dimension (``[B,Ac*C,H,W]``, B > 1) every sample is decoded in the same three launches and
+        the results carry the batch dimension: ``boxes[B,max_out,9]``, ``kept[B,max_out]``,
+        ``count[B]`` (evaluate.py:231-245 loops over the samples)."""
+        batched = cls.dim() == 4 and cls.shape[0] > 1
+        if cls.dim() == 3:
+            cls, reg = cls[None], reg[None]
         cls, reg = self._cell_strided(cls), self._cell_strided(reg)
-        boxes = torch.empty((self.max_out, 9), dtype=torch.float64, device=self.device)
-        kept = torch.empty((self.max_out,), dtype=torch.int32, device=self.device)
-        count = torch.empty((1,), dtype=torch.int32, device=self.device)
+        B = int(cls.shape[0])
+        if reg.shape[0] != B:
+            raise ValueError("cls and reg differ in batch size")
+        boxes = torch.empty((B, self.max_out, 9), dtype=torch.float64, device=self.device)
+        kept = torch.empty((B, self.max_out), dtype=torch.int32, device=self.device)
+        count = torch.empty((B,), dtype=torch.int32, device=self.device)
         vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        rc = _lib.lib().pp_decode_strided_dev(
-            self._ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
-            vp(cls), vp(reg), cls.stride(0), cls.stride(2), reg.stride(0), reg.stride(2), vp(self.a_centers), vp(self.a_wlh), vp(self.a_yaw), vp(self.a_xy),
+        rc = _lib.lib().pp_decode_batch_dev(
+            self._ctx.handle, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), B,
+            vp(cls), vp(reg), cls.stride(0), cls.stride(1), cls.stride(3), reg.stride(0), reg.stride(1), reg.stride(3),
+            vp(self.a_centers), vp(self.a_wlh), vp(self.a_yaw), vp(self.a_xy),
             ctypes.byref(self._prm), vp(boxes), vp(kept), vp(count))
-        _lib.check(rc, "pp_decode_strided_dev")
-        return boxes, kept, count
+        _lib.check(rc, "pp_decode_batch_dev")
+        if batched:
+            return boxes, kept, count
+        return boxes[0], kept[0], count
 
     @staticmethod
     def _cell_strided(t):
-        """``t[C,H,W]`` as it is when cell y*W+x sits at a fixed pitch (NCHW planes, channels-last
+        """``t[B,C,H,W]`` as it is when cell y*W+x sits at a fixed pitch (NCHW planes, channels-last
         tensors and channel slices of them -- PPModel's eval outputs), else an NCHW copy."""
-        if t.dtype == torch.float32 and t.stride(1) == t.shape[2] * t.stride(2):
+        if t.dtype == torch.float32 and t.stride(2) == t.shape[3] * t.stride(3):
             return t
         return t.float().contiguous()

@@ -320,6 +320,17 @@ int pp_decode_strided_dev(pp_ctx_t *ctx, void *stream, const float *cls_dev, con
                           const double *a_yaw, const double *a_xy, const pp_decode_params_t *prm,
                           double *boxes_out, int32_t *kept_out, int32_t *count_out);
 
+/* A batch of samples in one call (evaluate.py:231-245 loops over the samples of a batch; here every
+ * sample gets its own workgroups of the three kernels and they run side by side): sample b of cls /
+ * reg starts b*stride_b floats after sample 0; boxes_out [batch][max_out][9], kept_out
+ * [batch][max_out], count_out [batch].  1 <= batch <= 1024. */
+int pp_decode_batch_dev(pp_ctx_t *ctx, void *stream, int32_t batch, const float *cls_dev,
+                        const float *reg_dev, int64_t cls_stride_b, int64_t cls_stride_c,
+                        int64_t cls_stride_pix, int64_t reg_stride_b, int64_t reg_stride_c,
+                        int64_t reg_stride_pix, const double *a_centers, const double *a_wlh,
+                        const double *a_yaw, const double *a_xy, const pp_decode_params_t *prm,
+                        double *boxes_out, int32_t *kept_out, int32_t *count_out);
+
 /*
  * Fused conv epilogue for the inference backbone: y = max(x + b_c, 0) * s_c + t_c in
  * place on a contiguous NCHW f32 tensor -- the ReLU -> BatchNorm2d(eval) tail (plus the

@@ -43,14 +43,44 @@ def test_postprocess_matches_restatement(gpu, oracle, fm, seed, bias):
     assert np.array_equal(got[:n, 8], ref_b[:, 8])           # classes exact
 
 
-def test_postprocess_no_detection_and_full_batch_guard(gpu, oracle):
+def test_postprocess_no_detection(gpu, oracle):
     import torch
     anchors, acfg, cls, reg, H, det = _setup(gpu, 20, 5, -30.0)
     boxes_d, kept_d, count_d = det(torch.from_numpy(cls)[None].to(gpu), torch.from_numpy(reg)[None].to(gpu))
     torch.cuda.synchronize()
     assert int(count_d.item()) == 0 and (kept_d.cpu().numpy() == -1).all() and not boxes_d.any()
     with pytest.raises(ValueError):
-        det(torch.zeros(2, 18, 20, 20, device=gpu), torch.zeros(2, 16, 20, 20, device=gpu))
+        det(torch.zeros(2, 18, 20, 20, device=gpu), torch.zeros(3, 16, 20, 20, device=gpu))
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_postprocess_batch(gpu, oracle, layout):
+    """A batch in one call (evaluate.py:231-245 loops over the samples): every sample equals its own
+    single-sample call and the oracle -- samples with none, few, and > 256 candidates side by side,
+    and a second call with a smaller batch on the same scratch."""
+    import torch
+    anchors, acfg, _, _, H, det = _setup(gpu, 64, 0, 0.0)
+    rng = np.random.default_rng(42)
+    biases = [-30.0, -4.0, -1.5, -3.0, -2.5]
+    cls = np.stack([rng.normal(b, 1.5, (acfg.per_cell * 9, 64, 64)) for b in biases]).astype(np.float32)
+    reg = rng.normal(0, 0.3, (len(biases), acfg.per_cell * 8, 64, 64)).astype(np.float32)
+    tc, tr = torch.from_numpy(cls).to(gpu), torch.from_numpy(reg).to(gpu)
+    if layout == "channels_last":
+        tc, tr = tc.contiguous(memory_format=torch.channels_last), tr.contiguous(memory_format=torch.channels_last)
+    for nb in (len(biases), 2):
+        boxes_b, kept_b, count_b = det(tc[:nb], tr[:nb])
+        torch.cuda.synchronize()
+        assert boxes_b.shape == (nb, 100, 9) and kept_b.shape == (nb, 100) and count_b.shape == (nb,)
+        for b in range(nb):
+            b1, k1, n1 = det(tc[b], tr[b])
+            assert torch.equal(boxes_b[b], b1) and torch.equal(kept_b[b], k1) and count_b[b] == n1[0]
+            ref_b, ref_k = oracle.postprocess(cls[b], reg[b], anchors["centers"], anchors["wlh"], anchors["yaw"],
+                                              anchors["xy"], H, 0.2, 0.2, -0.1 * H, -0.1 * H)
+            n = int(count_b[b].item())
+            assert n == len(ref_k)
+            assert np.array_equal(kept_b[b].cpu().numpy()[:n], ref_k.astype(np.int32))
+            assert np.allclose(boxes_b[b].cpu().numpy()[:n], ref_b, rtol=1e-5, atol=1e-5)
+    assert int(count_b[0].item()) == 0 and int(count_b[1].item()) > 0
 
 
 def test_postprocess_on_channels_last_slices(gpu, oracle):
