@@ -211,6 +211,13 @@ __device__ void decode_row(const DecodeArgs &d, int i, int a) {
   o[8] = (double)klass;
 }
 
+#ifdef PP_NMS_STAMPS
+__device__ unsigned long long g_nms_stamps[64 * 8];
+#define NMS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (c0 >> 8) < 64) g_nms_stamps[(c0 >> 8) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NMS_STAMP(k) do {} while (0)
+#endif
+
 // One workgroup per sample; chunks of kChunkN = 256 candidates in key order, four threads per candidate.
 __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
   const DecodeArgs d = sample_view(d_);
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
   while (m2 < nruns * kChunkN) m2 <<= 1;
   for (int c0 = 0; c0 < M; c0 += kChunkN) {
     const int nk = s_nkept;
+    NMS_STAMP(0);
     u64 key;
     if (merging) {
       // the next 256 keys overall are among the next 256 of every run: sort those (run id
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
     } else {
       key = (c0 + c < M) ? d.keys[c0 + c] : kSentinel;
     }
+    NMS_STAMP(1);
     const bool valid = key != kSentinel;
     const int a = (int)(key & 0xFFFFFull);
     NmsBox b = {0, 0, 0, 0, 0};
@@ -275,8 +284,21 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
     if (valid) {
       b = load_box(d, a);
       alive = 1;
-      for (int k = sub; k < nk && alive; k += 4)   // this thread's quarter of the kept list
-        if (suppresses(s_kept[k], b, d.nms_thresh)) alive = 0;
+      // this thread's quarter of the kept list, four boxes per trip: the LDS reads of a trip do
+      // not wait for each other (one at a time the test was a 100 ns round trip per kept box)
+      for (int k0 = sub; k0 < nk; k0 += 16) {
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + 4 * u;
+          const NmsBox kb = s_kept[min(k, nk - 1)];
+          hit = hit || (k < nk && suppresses(kb, b, d.nms_thresh));
+        }
+        if (hit) {
+          alive = 0;
+          break;
+        }
+      }
     }
     {
       // a candidate is alive when all four quarters say so (the four threads are adjacent lanes)
@@ -289,55 +311,108 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
         s_id[c] = a;
       }
     }
+    NMS_STAMP(2);
+    s_mask[c][sub] = 0ull;
     if (t == kNmsThreads - 1) s_full = valid;       // the chunk's last candidate exists
     __syncthreads();
-    if (t < kChunkN / 64) {
-      u64 m = 0;
-      for (int i = 0; i < 64; ++i) m |= (u64)(s_alive[t * 64 + i] != 0) << i;
-      s_alive_mask[t] = m;
+    NMS_STAMP(3);
+    if (t < kChunkN) {  // the alive flags as ballot words, for the greedy pass
+      const u64 bal = __ballot(s_alive[t] != 0);
+      if ((t & 63) == 0) s_alive_mask[t >> 6] = bal;
     }
-    // suppression matrix inside the chunk: bit j of s_mask[c] = (j > c and c suppresses j);
-    // the four threads of a row take every fourth column and OR their words together
+    // Suppression matrix inside the chunk: bit j of s_mask[r] = (j > r and r suppresses j).
+    // Row r has 255 - r entries: rows p and 255 - p together have 255, shared by eight threads
+    // (32 entries each, four per trip) -- every thread does the same amount of work.
     {
-      u64 m[kChunkN / 64] = {0, 0, 0, 0};
-      if (alive) {
-        for (int j = c + 1 + sub; j < kChunkN; j += 4)
-          if (s_alive[j] && suppresses(b, s_chunk[j], d.nms_thresh)) m[j >> 6] |= 1ull << (j & 63);
-      }
+      const int p = t >> 3, u = t & 7;
+      const int rA = p, rB = kChunkN - 1 - p, nA = kChunkN - 1 - p;
+      const NmsBox bA = s_chunk[rA], bB = s_chunk[rB];
+      const bool aA = s_alive[rA] != 0, aB = s_alive[rB] != 0;
+      if (aA || aB) {
+        for (int idx0 = u; idx0 < kChunkN - 1; idx0 += 32) {
+          // four entries per trip: all their LDS reads first, then the arithmetic, then the bits
+          NmsBox bj[4];
+          int j[4];
+          bool on[4], first[4], sup[4];
 #pragma unroll
-      for (int w = 0; w < kChunkN / 64; ++w) {
-        unsigned lo = (unsigned)m[w], hi = (unsigned)(m[w] >> 32);
-        lo |= __shfl_xor(lo, 1, 64);
-        hi |= __shfl_xor(hi, 1, 64);
-        lo |= __shfl_xor(lo, 2, 64);
-        hi |= __shfl_xor(hi, 2, 64);
-        if (sub == 0) s_mask[c][w] = ((u64)hi << 32) | lo;
-      }
-    }
-    __syncthreads();
-    if (t == 0) {
-      // greedy pass in score order over the ALIVE members only (ballot words, lowest bit first)
-      u64 removed[kChunkN / 64] = {0, 0, 0, 0};
-      int n = s_nkept;
+          for (int q = 0; q < 4; ++q) {
+            const int idx = idx0 + 8 * q;
+            const bool in = idx < kChunkN - 1;
+            first[q] = idx < nA;
+            j[q] = in ? (first[q] ? p + 1 + idx : idx + 1) : 0;
+            bj[q] = s_chunk[j[q]];
+            on[q] = in && (first[q] ? aA : aB) && s_alive[j[q]] != 0;
+          }
 #pragma unroll
-      for (int w0 = 0; w0 < kChunkN / 64; ++w0) {
-        u64 pend = s_alive_mask[w0];
-        while (pend && n < d.max_out) {
-          const int bpos = __builtin_ctzll(pend);
-          pend &= pend - 1;
-          if ((removed[w0] >> bpos) & 1ull) continue;
-          const int i = w0 * 64 + bpos;
-          s_kept[n] = s_chunk[i];
-          s_keptid[n] = s_id[i];
-          ++n;
+          for (int q = 0; q < 4; ++q) {
+            NmsBox br;
+            br.x1 = first[q] ? bA.x1 : bB.x1;
+            br.y1 = first[q] ? bA.y1 : bB.y1;
+            br.x2 = first[q] ? bA.x2 : bB.x2;
+            br.y2 = first[q] ? bA.y2 : bB.y2;
+            br.area = first[q] ? bA.area : bB.area;
+            sup[q] = on[q] && suppresses(br, bj[q], d.nms_thresh);
+          }
 #pragma unroll
-          for (int w = 0; w < kChunkN / 64; ++w) removed[w] |= s_mask[i][w];
+          for (int q = 0; q < 4; ++q)
+            if (sup[q]) atomicOr(&s_mask[first[q] ? rA : rB][j[q] >> 6], 1ull << (j[q] & 63));
         }
       }
-      s_nkept = n;
-      s_done = (n >= d.max_out) ? 1 : 0;
     }
+    NMS_STAMP(4);
     __syncthreads();
+    NMS_STAMP(5);
+    if (t < 64) {
+      // greedy pass in score order, by one wave: lane l holds the matrix row of member 64*w0 + l of
+      // block w0; the walk over the block's alive members is a scalar loop (a row's own-block word
+      // through v_readlane), the later blocks' removed words an OR over the kept lanes.
+      int n = s_nkept;
+      u64 removed[kChunkN / 64] = {0, 0, 0, 0};
+#pragma unroll
+      for (int w0 = 0; w0 < kChunkN / 64; ++w0) {
+        const int row = w0 * 64 + t;
+        u64 mr[kChunkN / 64];
+#pragma unroll
+        for (int w = 0; w < kChunkN / 64; ++w) mr[w] = s_mask[row][w];
+        const u64 am = s_alive_mask[w0] & ~removed[w0];
+        u64 pend = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(am >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(am & 0xFFFFFFFFull));
+        u64 keptbits = 0;
+        int room = d.max_out - n;
+        while (pend && room > 0) {
+          const int i = __builtin_ctzll(pend);
+          keptbits |= 1ull << i;
+          --room;
+          const u64 r0 = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(mr[w0] >> 32), i) << 32) |
+                         (unsigned)__builtin_amdgcn_readlane((int)(mr[w0] & 0xFFFFFFFFull), i);
+          pend &= ~(r0 | (1ull << i));
+        }
+        const bool mine = (keptbits >> t) & 1ull;
+        if (mine) {
+          const int pos = n + __popcll(keptbits & ((1ull << t) - 1ull));
+          s_kept[pos] = s_chunk[row];
+          s_keptid[pos] = s_id[row];
+        }
+        n += __popcll(keptbits);
+#pragma unroll
+        for (int w = w0 + 1; w < kChunkN / 64; ++w) {
+          unsigned lo = mine ? (unsigned)mr[w] : 0u, hi = mine ? (unsigned)(mr[w] >> 32) : 0u;
+#pragma unroll
+          for (int dd = 1; dd < 64; dd <<= 1) {
+            lo |= __shfl_xor(lo, dd, 64);
+            hi |= __shfl_xor(hi, dd, 64);
+          }
+          removed[w] |= ((u64)hi << 32) | lo;
+        }
+      }
+      if (t == 0) {
+        s_nkept = n;
+        s_done = (n >= d.max_out) ? 1 : 0;
+      }
+    }
+    NMS_STAMP(6);
+    __syncthreads();
+    NMS_STAMP(7);
     if (s_done || !s_full) break;  // enough boxes, or the candidates ran out inside this chunk
   }
   __syncthreads();
@@ -468,3 +543,10 @@ extern "C" int pp_decode_dev(pp_ctx_t *ctx, void *stream_, const float *cls_dev,
   return pp_decode_strided_dev(ctx, stream_, cls_dev, reg_dev, hw, 1, hw, 1, a_centers, a_wlh, a_yaw,
                                a_xy, prm, boxes_out, kept_out, count_out);
 }
+
+#ifdef PP_NMS_STAMPS
+extern "C" int pp_debug_nms_stamps(unsigned long long *out, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return PP_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_nms_stamps), (size_t)n_words * 8) == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+#endif
