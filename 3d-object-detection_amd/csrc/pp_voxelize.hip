@@ -594,6 +594,8 @@ struct EmitArgs {
 };
 
 enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 };
+constexpr int kAuxPlain = 0, kAuxSc1 = 16;           // buffer-store cache policy bits (gfx950: sc1 = 16)
+constexpr size_t kSc1MaxBytes = 128u << 20;          // write-through stores pay off up to about half the Infinity Cache
 
 constexpr int kPfnChannels = 64;  // one lane per output channel (model/model.py:28: 9 -> 64)
 
@@ -891,7 +893,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 // back-to-back buffer_store_dwordx4 per decision with no 64-bit address math.
 enum { kPassEarly = 0, kPassLate = 1, kPassAll = 2 };
 
-template <int PASS, typename TIn>
+template <int PASS, typename TIn, int AUX>
 __device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom &sg,
                                            __amdgpu_buffer_rsrc_t rs, int lane,
                                            const int segbeg[KW]) {
@@ -941,12 +943,13 @@ __device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom
       }
 #pragma unroll
       for (int d = 0; d < PP_NUM_FEATURES; ++d)
-        __builtin_amdgcn_raw_buffer_store_b128(v[d], rs, voff, d * sg.pn4_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v[d], rs, voff, d * sg.pn4_bytes, AUX);
     }
   }
 }
 
-template <typename TIn, int MODE>
+// AUX: cache policy of the dense tensor's 16-byte stores (kAuxPlain / kAuxSc1, see launch_pipeline)
+template <typename TIn, int MODE, int AUX = 0>
 #ifndef PP_EMIT_MINWAVES
 #define PP_EMIT_MINWAVES 4
 #endif
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       // 4 sweeps per launch -- the second pass's issue slots, not its bytes.)
       if (!pooled || T == 0) {
         sg.late_lines = slab_late_lines(sg, sg.pooled);
-        store_slab<kPassEarly, TIn>(L, sg, rs, lane, segbeg);
+        store_slab<kPassEarly, TIn, AUX>(L, sg, rs, lane, segbeg);
       }
     } else {
       const int rowf = kw_eff * N;
@@ -1202,7 +1205,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   }
   if (pooled) {
     emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, rec_r, segbeg, segpad, cnts, T);
-    if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn>(L, sg, rs, lane, segpad);
+    if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn, AUX>(L, sg, rs, lane, segpad);
     if constexpr (MODE == kModePfn) {
 #pragma unroll
       for (int k = 0; k < KW; ++k) pfn_fold(k, segpad[k], min(cnts[k], N));
@@ -1278,7 +1281,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
         SlabGeom s1 = sg;
         s1.pooled = gmask;
         s1.late_lines = slab_late_lines(sg, gmask);
-        store_slab<kPassLate, TIn>(L, s1, rs, lane, spg);
+        store_slab<kPassLate, TIn, AUX>(L, s1, rs, lane, spg);
         wave_sync();
       }
     }
@@ -1562,10 +1565,25 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.canvas_nhwc = canvas_nhwc;
   const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
   switch (mode) {
-    case kModeDenseVec4:
-      hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseVec4>), grid_emit, dim3(kEmitThreads), 0, stream,
-                            ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
+    case kModeDenseVec4: {
+      // Store policy of the dense tensor.  Write-through (sc1) stores leave no dirty lines for the
+      // end-of-kernel write-back: on k_emit's store pattern alone (tools/lab/fill_pattern.cpp) 43.2 MB take
+      // 6.3 us against 7.4 us plain, 172.8 MB 20.8 / 22.6 us, 432 MB (beyond the Infinity Cache) 84 / 80 us.
+      // In k_emit itself: 43.2 MB 10.4 / 11.5 us, 108 MB 21.5 / 22.0 us, 172.8 MB 29.3 / 29.0 us -- the
+      // larger launches are not bound by their tail.  Write-through up to 128 MB.
+      static const int forced = [] {  // development knob: PP_EMIT_SC1=0/1
+        const char *e = getenv("PP_EMIT_SC1");
+        return e ? (atoi(e) ? 1 : 0) : -1;
+      }();
+      const bool sc1 = forced >= 0 ? forced == 1 : (size_t)B * 36u * (size_t)P * (size_t)N <= kSc1MaxBytes;
+      if (sc1)
+        hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseVec4, kAuxSc1>), grid_emit, dim3(kEmitThreads), 0, stream,
+                              ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
+      else
+        hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseVec4, kAuxPlain>), grid_emit, dim3(kEmitThreads), 0, stream,
+                              ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);
       break;
+    }
     case kModeDenseScalar:
       hipExtLaunchKernelGGL((k_emit<TIn, kModeDenseScalar>), grid_emit, dim3(kEmitThreads), 0, stream,
                             ev0[PP_KERNEL_EMIT], ev1[PP_KERNEL_EMIT], 0, a);

@@ -1,0 +1,104 @@
+// tools/lab/fill_pattern.cpp: store-only kernels at the C5 output shape (B x 9 x P x N f32) -- a linear fill
+// against k_emit's pattern (a wave writes its 4 pillars' 1600 bytes in each of the 9 feature planes).
+// build: hipcc -O3 --offload-arch=gfx950 tools/lab/fill_pattern.cpp -o tools/lab/_build/fill_pattern
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_linear(float4 *out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = make_float4(0, 0, 0, 0);
+}
+
+// KW pillars per wave, N floats each: the wave's slab in plane d starts at ((b*9 + d)*P + p0)*N
+typedef unsigned v4u __attribute__((__vector_size__(16)));
+// the same with the buffer-store cache policy bits: 0 plain, 1 sc0, 2 nt, 16 sc1, 3 sc0 nt, 18 sc1 nt
+template <int AUX>
+__global__ __launch_bounds__(256) void k_pattern_aux(float *out, int P, int N) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+  const int p0 = (blockIdx.x * 4 + w) * 4;
+  if (p0 >= P) return;
+  const int n4 = 4 * N / 4;
+  const v4u z = {0, 0, 0, 0};
+  for (int d = 0; d < 9; ++d) {
+    float *dst = out + (((size_t)b * 9 + d) * P + p0) * N;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, n4 * 16, 0x00020000);
+    for (int i = lane; i < n4; i += 64) __builtin_amdgcn_raw_buffer_store_b128(z, rs, i * 16, 0, AUX);
+  }
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void k_pattern(float *out, int P, int N, int delay) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+  const int p0 = (blockIdx.x * 4 + w) * KW;
+  if (p0 >= P) return;
+  if (delay) {  // a dependent load chain in front of the stores, like k_emit's prologue
+    volatile float *q = out;
+    float s = 0;
+    for (int k = 0; k < delay; ++k) s += q[(size_t)(lane + k * 64 + (int)s) & 1023];
+    if (s == 12345.f) out[0] = s;
+  }
+  const int n4 = KW * N / 4;
+  for (int d = 0; d < 9; ++d) {
+    float4 *dst = reinterpret_cast<float4 *>(out + (((size_t)b * 9 + d) * P + p0) * N);
+    for (int i = lane; i < n4; i += 64) dst[i] = make_float4(0, 0, 0, 0);
+  }
+}
+
+int main(int argc, char **argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 4, P = argc > 2 ? atoi(argv[2]) : 30000, N = 100;
+  const size_t n = (size_t)B * 9 * P * N;
+  float *out;
+  CK(hipMalloc(&out, n * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const bool cold = argc > 3 && atoi(argv[3]);  // 1 GiB of other traffic between the launches
+  float *junk = nullptr, *junk2 = nullptr;
+  const size_t jn = 256u << 20;
+  if (cold) {
+    CK(hipMalloc(&junk, jn * 4));
+    CK(hipMalloc(&junk2, jn * 4));
+  }
+  auto run = [&](const char *name, auto launch) {
+    if (cold) {
+      float tot = 0;
+      for (int i = 0; i < 20; ++i) {
+        CK(hipMemcpyAsync(junk2, junk, jn * 4, hipMemcpyDeviceToDevice, 0));
+        CK(hipEventRecord(e0));
+        launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 4) tot += ms;
+      }
+      printf("%-28s %7.2f us  %.2f TB/s (cold)\n", name, tot / 16 * 1e3, n * 4 / (tot / 16 * 1e-3) / 1e12);
+      return;
+    }
+    for (int i = 0; i < 10; ++i) launch();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 100; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s %7.2f us  %.2f TB/s\n", name, ms * 10, n * 4 / (ms * 1e-5) / 1e12);
+  };
+  run("linear, 2048 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  run("linear, 8192 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(8192), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  run("pattern KW=4", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 0); });
+  run("pattern KW=4 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 2); });
+  run("pattern KW=4 buffer plain", [&] { hipLaunchKernelGGL(k_pattern_aux<0>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("pattern KW=4 buffer sc0", [&] { hipLaunchKernelGGL(k_pattern_aux<1>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("pattern KW=4 buffer nt", [&] { hipLaunchKernelGGL(k_pattern_aux<2>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("pattern KW=4 buffer sc1", [&] { hipLaunchKernelGGL(k_pattern_aux<16>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("pattern KW=4 buffer sc0 nt", [&] { hipLaunchKernelGGL(k_pattern_aux<3>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("pattern KW=4 buffer sc1 nt", [&] { hipLaunchKernelGGL(k_pattern_aux<18>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("pattern KW=4 buffer sc0 sc1", [&] { hipLaunchKernelGGL(k_pattern_aux<17>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  run("hipMemsetAsync", [&] { CK(hipMemsetAsync(out, 0, n * 4, 0)); });
+  run("pattern KW=8", [&] { hipLaunchKernelGGL(k_pattern<8>, dim3((P + 31) / 32, B), dim3(256), 0, 0, out, P, N, 0); });
+  run("pattern KW=16", [&] { hipLaunchKernelGGL(k_pattern<16>, dim3((P + 63) / 64, B), dim3(256), 0, 0, out, P, N, 0); });
+  run("pattern KW=32", [&] { hipLaunchKernelGGL(k_pattern<32>, dim3((P + 127) / 128, B), dim3(256), 0, 0, out, P, N, 0); });
+  return 0;
+}
