@@ -10,6 +10,22 @@ __global__ __launch_bounds__(256) void k_linear(float4 *out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = make_float4(0, 0, 0, 0);
 }
 
+// blocked: workgroup b streams one contiguous range, 4 KB per trip
+__global__ __launch_bounds__(256) void k_blocked(float4 *out, size_t n4) {
+  const size_t per = (n4 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) out[i] = make_float4(0, 0, 0, 0);
+}
+// blocked, U stores per thread in flight per trip
+template <int U>
+__global__ __launch_bounds__(256) void k_blocked_u(float4 *out, size_t n4) {
+  const size_t per = (n4 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256 * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i + u * 256 < hi) out[i + u * 256] = make_float4(0, 0, 0, 0);
+  }
+}
+
 // KW pillars per wave, N floats each: the wave's slab in plane d starts at ((b*9 + d)*P + p0)*N
 typedef unsigned v4u __attribute__((__vector_size__(16)));
 // the same with the buffer-store cache policy bits: 0 plain, 1 sc0, 2 nt, 16 sc1, 3 sc0 nt, 18 sc1 nt
@@ -85,8 +101,18 @@ int main(int argc, char **argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-28s %7.2f us  %.2f TB/s\n", name, ms * 10, n * 4 / (ms * 1e-5) / 1e12);
   };
+  run("linear, 256 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(256), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  run("linear, 512 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(512), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  run("linear, 1024 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(1024), dim3(256), 0, 0, (float4 *)out, n / 4); });
   run("linear, 2048 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, (float4 *)out, n / 4); });
   run("linear, 8192 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(8192), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  for (int wg : {256, 512, 1024, 2048, 4096}) {
+    char nm[64];
+    snprintf(nm, sizeof nm, "blocked, %d WGs", wg);
+    run(nm, [&] { hipLaunchKernelGGL(k_blocked, dim3(wg), dim3(256), 0, 0, (float4 *)out, n / 4); });
+    snprintf(nm, sizeof nm, "blocked x4, %d WGs", wg);
+    run(nm, [&] { hipLaunchKernelGGL(k_blocked_u<4>, dim3(wg), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  }
   run("pattern KW=4", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 0); });
   run("pattern KW=4 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 2); });
   run("pattern KW=4 buffer plain", [&] { hipLaunchKernelGGL(k_pattern_aux<0>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
