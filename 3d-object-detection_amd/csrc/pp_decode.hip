@@ -225,7 +225,9 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
   __shared__ NmsBox s_chunk[kChunkN];
   __shared__ u64 s_mask[kChunkN][kChunkN / 64];  // s_mask[i]: later chunk members i suppresses
   __shared__ int s_alive[kChunkN];
-  __shared__ u64 s_alive_mask[kChunkN / 64];     // the same as ballots, for the serial pass
+  __shared__ NmsBox s_cbox[kChunkN];             // the chunk's survivors of the kept-list test, packed
+  __shared__ int s_cid[kChunkN];
+  __shared__ int s_acnt[kChunkN / 64];
   __shared__ int s_id[kChunkN];
   __shared__ int s_keptid[kMaxOut];
   __shared__ int s_nkept, s_done, s_full;
@@ -316,32 +318,42 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
     if (t == kNmsThreads - 1) s_full = valid;       // the chunk's last candidate exists
     __syncthreads();
     NMS_STAMP(3);
-    if (t < kChunkN) {  // the alive flags as ballot words, for the greedy pass
+    // The members the kept list left alive, packed to the front (score order kept): the matrix and the
+    // greedy pass then cost what the survivors cost -- 30 to 100 of 256 in all chunks but the first.
+    int my_pos = -1;
+    if (t < kChunkN) {
       const u64 bal = __ballot(s_alive[t] != 0);
-      if ((t & 63) == 0) s_alive_mask[t >> 6] = bal;
+      if ((t & 63) == 0) s_acnt[t >> 6] = __popcll(bal);
+      if (s_alive[t]) my_pos = __popcll(bal & ((1ull << (t & 63)) - 1ull));
     }
-    // Suppression matrix inside the chunk: bit j of s_mask[r] = (j > r and r suppresses j).
-    // Row r has 255 - r entries: rows p and 255 - p together have 255, shared by eight threads
-    // (32 entries each, four per trip) -- every thread does the same amount of work.
+    __syncthreads();
+    const int na = s_acnt[0] + s_acnt[1] + s_acnt[2] + s_acnt[3];
+    if (my_pos >= 0) {
+      for (int w = 0; w < (t >> 6); ++w) my_pos += s_acnt[w];
+      s_cbox[my_pos] = s_chunk[t];
+      s_cid[my_pos] = s_id[t];
+    }
+    __syncthreads();
+    // Suppression matrix among the survivors: bit j of s_mask[r] = (j > r and r suppresses j).  Row r has
+    // na - 1 - r entries: rows p and na - 1 - p together have na - 1, shared by eight threads, four
+    // entries per trip (all their LDS reads first, then the arithmetic, then the bits).
     {
       const int p = t >> 3, u = t & 7;
-      const int rA = p, rB = kChunkN - 1 - p, nA = kChunkN - 1 - p;
-      const NmsBox bA = s_chunk[rA], bB = s_chunk[rB];
-      const bool aA = s_alive[rA] != 0, aB = s_alive[rB] != 0;
-      if (aA || aB) {
-        for (int idx0 = u; idx0 < kChunkN - 1; idx0 += 32) {
-          // four entries per trip: all their LDS reads first, then the arithmetic, then the bits
+      const int rA = p, rB = na - 1 - p;
+      if (rA <= rB) {
+        const int nA = na - 1 - p, total = (rA == rB) ? nA : na - 1;
+        const NmsBox bA = s_cbox[rA], bB = s_cbox[rB];
+        for (int idx0 = u; idx0 < total; idx0 += 32) {
           NmsBox bj[4];
           int j[4];
-          bool on[4], first[4], sup[4];
+          bool in[4], first[4], sup[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int idx = idx0 + 8 * q;
-            const bool in = idx < kChunkN - 1;
+            in[q] = idx < total;
             first[q] = idx < nA;
-            j[q] = in ? (first[q] ? p + 1 + idx : idx + 1) : 0;
-            bj[q] = s_chunk[j[q]];
-            on[q] = in && (first[q] ? aA : aB) && s_alive[j[q]] != 0;
+            j[q] = in[q] ? (first[q] ? p + 1 + idx : idx + 1) : 0;
+            bj[q] = s_cbox[j[q]];
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
             br.x2 = first[q] ? bA.x2 : bB.x2;
             br.y2 = first[q] ? bA.y2 : bB.y2;
             br.area = first[q] ? bA.area : bB.area;
-            sup[q] = on[q] && suppresses(br, bj[q], d.nms_thresh);
+            sup[q] = in[q] && suppresses(br, bj[q], d.nms_thresh);
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -374,7 +386,8 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
         u64 mr[kChunkN / 64];
 #pragma unroll
         for (int w = 0; w < kChunkN / 64; ++w) mr[w] = s_mask[row][w];
-        const u64 am = s_alive_mask[w0] & ~removed[w0];
+        const int nw = na - w0 * 64;  // survivors in this block
+        const u64 am = (nw >= 64 ? ~0ull : nw > 0 ? (1ull << nw) - 1ull : 0ull) & ~removed[w0];
         u64 pend = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(am >> 32)) << 32) |
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(am & 0xFFFFFFFFull));
         u64 keptbits = 0;
@@ -390,8 +403,8 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
         const bool mine = (keptbits >> t) & 1ull;
         if (mine) {
           const int pos = n + __popcll(keptbits & ((1ull << t) - 1ull));
-          s_kept[pos] = s_chunk[row];
-          s_keptid[pos] = s_id[row];
+          s_kept[pos] = s_cbox[row];
+          s_keptid[pos] = s_cid[row];
         }
         n += __popcll(keptbits);
 #pragma unroll
