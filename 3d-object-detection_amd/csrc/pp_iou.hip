@@ -4,7 +4,10 @@
 // Replaces make_ious + iou (/root/reference data/pillars.cpp:400-427, 132-172)
 // and, fused on the device-resident path, create_target + make_target
 // (utils/box_utils.py:162-232, 70-109) so that the [A,G] IoU matrix is never
-// materialised.
+// materialised.  Kernels: k_make_ious (the dense matrix of the compatibility API, one lane
+// per entry, serial clip), k_targets (the whole of create_target in one launch: gate, pair
+// queue, clip with 8 lanes per pair, row / column reductions, target rows, and the forced
+// rows by the last workgroup to finish), k_targets_init (arms the scratch words once).
 //
 // Boost.Geometry (bg::intersection / bg::area, pillars.cpp:160,164,165) is an
 // absent, unpinned third-party dependency of the reference; its published
@@ -529,9 +532,6 @@ __device__ __forceinline__ void clip_round(const TargetArgs &t, TgtLds &S, int r
 }
 
 __device__ __forceinline__ u64 ld_agent(const u64 *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int ld_agent(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
