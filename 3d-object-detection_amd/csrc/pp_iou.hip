@@ -4,10 +4,11 @@
 // Replaces make_ious + iou (/root/reference data/pillars.cpp:400-427, 132-172)
 // and, fused on the device-resident path, create_target + make_target
 // (utils/box_utils.py:162-232, 70-109) so that the [A,G] IoU matrix is never
-// materialised.  Kernels: k_make_ious (the dense matrix of the compatibility API, one lane
-// per entry, serial clip), k_targets (the whole of create_target in one launch: gate, pair
-// queue, clip with 8 lanes per pair, row / column reductions, target rows, and the forced
-// rows by the last workgroup to finish), k_targets_init (arms the scratch words once).
+// materialised.  Kernels: k_targets<false> (the whole of create_target in one launch: gate,
+// pair queue, clip with 8 lanes per pair, row / column reductions, target rows, and the forced
+// rows by the last workgroup to finish), k_targets<true> (the dense matrix of the
+// compatibility API: the same gate / queue / clip, the pairs' values written into a zeroed
+// matrix), k_targets_init (arms the scratch words once).
 //
 // Boost.Geometry (bg::intersection / bg::area, pillars.cpp:160,164,165) is an
 // absent, unpinned third-party dependency of the reference; its published
@@ -23,7 +24,6 @@
 
 namespace pp {
 
-constexpr int kIouThreads = 128;  // 16 LDS vertex slots x 16 B per thread = 32 KB per workgroup
 using u64 = unsigned long long;
 
 __device__ __forceinline__ double shoelace_dev(const double *q, int n) {
@@ -35,114 +35,9 @@ __device__ __forceinline__ double shoelace_dev(const double *q, int n) {
   return 0.5 * s;
 }
 
-// pillars.cpp:132-172 for one pair.  a: anchor corners, declared counter-
-// clockwise; g: ground-truth corners, declared clockwise.  *bad is set when a
-// declared-orientation area is negative (the reference's "IOU < 0" exit).
-// The two ping-pong vertex lists (at most 8 vertices each) live in LDS, slot-major
-// ([16 slots][block threads], 16 B per vertex): lanes of a wave touch consecutive
-// 16-byte words, and a dynamically indexed private array would go to scratch
-// (global memory) -- the clip is a chain of dependent reads and writes.
-struct PolyLds {
-  double2 *base;  // &lds[threadIdx.x]
-  int stride;     // block threads
-  __device__ __forceinline__ double2 &at(int list, int v) const {
-    return base[(list * 8 + v) * stride];
-  }
-};
-
-__device__ double iou_pair_dev(const double a[8], const double g[8], bool *bad, const PolyLds &pl) {
-  const double area_a = shoelace_dev(a, 4);
-  const double area_g = -shoelace_dev(g, 4);
-  if (area_a < 0.0 || area_g < 0.0) {
-    *bad = true;
-    return -1.0;
-  }
-  int n = 4, cur = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) pl.at(0, k) = make_double2(a[2 * k], a[2 * k + 1]);
-  for (int e = 0; e < 4 && n > 0; ++e) {
-    const int ia = (4 - e) & 3, ib = (3 - e) & 3;
-    double ax = 0, ay = 0, bx = 0, by = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {  // static indexing keeps g[] in registers
-      ax = (k == ia) ? g[2 * k] : ax;
-      ay = (k == ia) ? g[2 * k + 1] : ay;
-      bx = (k == ib) ? g[2 * k] : bx;
-      by = (k == ib) ? g[2 * k + 1] : by;
-    }
-    const double ex = bx - ax, ey = by - ay;
-    int m = 0;
-    const double2 last = pl.at(cur, n - 1);
-    double px = last.x, py = last.y;
-    double dp = ex * (py - ay) - ey * (px - ax);
-    for (int i = 0; i < n; ++i) {
-      const double2 c = pl.at(cur, i);
-      const double cx = c.x, cy = c.y;
-      const double dc = ex * (cy - ay) - ey * (cx - ax);
-      if ((dc >= 0.0) != (dp >= 0.0)) {
-        const double t = dp / (dp - dc);
-        pl.at(cur ^ 1, m) = make_double2(px + t * (cx - px), py + t * (cy - py));
-        ++m;
-      }
-      if (dc >= 0.0) {
-        pl.at(cur ^ 1, m) = make_double2(cx, cy);
-        ++m;
-      }
-      px = cx;
-      py = cy;
-      dp = dc;
-    }
-    n = m;
-    cur ^= 1;
-  }
-  if (n < 3) return 0.0;
-  // shoelace over the clipped ring, same operation order as shoelace_dev
-  double s = 0.0;
-  for (int k = 0; k < n; ++k) {
-    const int j = (k + 1 == n) ? 0 : k + 1;
-    const double2 vk = pl.at(cur, k), vj = pl.at(cur, j);
-    s = s + (vk.x * vj.y - vj.x * vk.y);
-  }
-  const double inter = 0.5 * s;
-  if (!(inter > 0.0)) return 0.0;
-  return inter / (area_a + area_g - inter);
-}
-
 // the +-10 cell centre gate of pillars.cpp:418-419
 __device__ __forceinline__ bool gate_far(double acx, double acy, double gcx, double gcy) {
   return (fabs(acx - gcx) > 10.0) || (fabs(acy - gcy) > 10.0);
-}
-
-// ------------------------------------------------------------------------- //
-// make_ious: one lane per (anchor, gt) entry, coalesced f64 stores           //
-// ------------------------------------------------------------------------- //
-__global__ __launch_bounds__(kIouThreads) void k_make_ious(
-    const double *__restrict__ a_corners, const double *__restrict__ a_centers, int acols,
-    int64_t A, const double *__restrict__ g_corners, const double *__restrict__ g_centers,
-    int gcols, int G, double *__restrict__ ious, int *errflag) {
-  __shared__ double2 s_poly[16 * kIouThreads];
-  const PolyLds pl{s_poly + threadIdx.x, kIouThreads};
-  const int64_t total = A * G;
-  for (int64_t e = (int64_t)blockIdx.x * kIouThreads + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * kIouThreads) {
-    const int64_t i = e / G;
-    const int j = (int)(e - i * G);
-    const double acx = a_centers[i * acols], acy = a_centers[i * acols + 1];
-    const double gcx = g_centers[(int64_t)j * gcols], gcy = g_centers[(int64_t)j * gcols + 1];
-    double v = 0.0;
-    if (!gate_far(acx, acy, gcx, gcy)) {
-      double a[8], g[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        a[k] = a_corners[i * 8 + k];
-        g[k] = g_corners[(int64_t)j * 8 + k];
-      }
-      bool bad = false;
-      v = iou_pair_dev(a, g, &bad, pl);
-      if (bad) atomicExch(errflag, 1);
-    }
-    ious[e] = v;
-  }
 }
 
 // ------------------------------------------------------------------------- //
@@ -163,8 +58,10 @@ struct TargetArgs {
   int grid, fm_w, per_cell;
   double fm_scale;
   const double *types;  // [per_cell][kTypeCols]: corner offsets x0,y0..x3,y3, w, l, h, yaw, z
+  int a_center_cols, g_center_cols;  // doubles per row of a_centers / g_centers_img (3; the dense-matrix API: >= 2)
   const double *g_corners, *g_centers_img, *g_centers, *g_wlh, *g_yaw;
   const int *g_class;
+  double *ious;  // matrix mode: [A][G] f64, zeroed by the host; the pairs past the gate are written here
   double pos_thresh, canvas_height;
   int num_classes;
   // scratch
@@ -198,8 +95,8 @@ __device__ __forceinline__ AnchorId anchor_id(const TargetArgs &t, int64_t i) {
     a.cy = ((double)y + 0.5) / t.fm_scale;
   } else {
     a.d = 0;
-    a.cx = t.a_centers[i * 3];
-    a.cy = t.a_centers[i * 3 + 1];
+    a.cx = t.a_centers[i * t.a_center_cols];
+    a.cy = t.a_centers[i * t.a_center_cols + 1];
   }
   return a;
 }
@@ -312,15 +209,6 @@ __device__ __forceinline__ float target_component(const BoxVals &a, const BoxVal
 
 __device__ __forceinline__ Row9 make_target_dev(const TargetArgs &t, int64_t i, int j) {
   return target_row(anchor_vals(t, i), gt_vals(t, j), t.canvas_height);
-}
-
-__device__ __forceinline__ double pair_iou(const TargetArgs &t, int64_t i, int j, bool *bad,
-                                           const PolyLds &pl) {
-  double a[8], g[8];
-  anchor_corners(t, i, a);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) g[k] = t.g_corners[(int64_t)j * 8 + k];
-  return iou_pair_dev(a, g, bad, pl);
 }
 
 // ------------------------------------------------------------------------- //
@@ -712,6 +600,9 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
   }
 }
 
+// MATRIX: make_ious (data/pillars.cpp:400-427) on the same gate / queue / clip machinery -- the
+// pairs past the gate are written into the host-zeroed [A][G] matrix, nothing else is computed.
+template <bool MATRIX>
 __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
   __shared__ __align__(16) unsigned char smem[kTgtLdsBytes];
   TgtLds &S = *reinterpret_cast<TgtLds *>(smem);
@@ -799,7 +690,8 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
     const int gn = min(kGtChunk, t.G - j0);
     __syncthreads();
     if (tid < gn) {
-      S.gc[tid] = make_double2(t.g_centers_img[(int64_t)(j0 + tid) * 3], t.g_centers_img[(int64_t)(j0 + tid) * 3 + 1]);
+      S.gc[tid] = make_double2(t.g_centers_img[(int64_t)(j0 + tid) * t.g_center_cols],
+                               t.g_centers_img[(int64_t)(j0 + tid) * t.g_center_cols + 1]);
       S.cmax[tid] = 0ull;
       S.cseen[tid] = 0ull;
       S.carg[tid] = INT_MAX;
@@ -880,6 +772,12 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       }
       __syncthreads();
       IOU_STAMP(4);
+      if constexpr (MATRIX) {
+        for (int q = tid; q < wn; q += kTgtThreads)
+          t.ious[(i0 + S.pair_lane[q]) * t.G + j0 + S.pair_gt[q]] = S.iou[q];
+        __syncthreads();
+        continue;
+      }
       // rows: this anchor's slice of the window, ascending gt; strict >: first maximum wins
       if (cnt > 0) {
         const int qa = max(my_off, wb), qb = min(my_off + cnt, wb + wn);
@@ -910,6 +808,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       }
       __syncthreads();
     }
+    if constexpr (MATRIX) continue;
     if (j0 + kGtChunk < t.G) {
       append_columns(j0, gn);
     } else {
@@ -919,6 +818,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
   }
   IOU_STAMP(5);
   if (bad) atomicExch(t.errflag, 1);
+  if constexpr (MATRIX) return;
   // rows: positives of both targets, zero rows otherwise
   const int nc = t.num_classes;
   const int nrows = (int)min((int64_t)kTgtThreads, t.A - i0);
@@ -1044,8 +944,8 @@ extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_co
     set_error("ctx is NULL");
     return PP_ERR_VALUE;
   }
-  if (A < 0 || G < 0 || G > INT_MAX / 16 || A > (1ll << 40) || a_center_cols < 2 ||
-      g_center_cols < 2) {
+  if (A < 0 || G < 0 || G > INT_MAX / 16 || A > (1ll << 38) || a_center_cols < 2 || a_center_cols > 64 ||
+      g_center_cols < 2 || g_center_cols > 64) {
     set_error("pp_make_ious_dev: bad sizes (A=%lld G=%lld)", (long long)A, (long long)G);
     return PP_ERR_VALUE;
   }
@@ -1060,11 +960,22 @@ extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_co
   if (rc) return rc;
   int *errflag = static_cast<int *>(ctx->iou_ws.ptr);
   PP_HIP_TRY(hipMemsetAsync(errflag, 0, 4, stream));
-  const int64_t total = A * G;
-  const unsigned blocks = (unsigned)std::min<int64_t>((total + kIouThreads - 1) / kIouThreads, 1 << 20);
-  hipLaunchKernelGGL(k_make_ious, dim3(blocks), dim3(kIouThreads), 0, stream, a_corners_dev,
-                     a_centers_dev, (int)a_center_cols, A, g_corners_dev, g_centers_dev,
-                     (int)g_center_cols, (int)G, ious_dev, errflag);
+  // every entry is written (pillars.cpp:421,424): zeros by this fill, the 0.16 % of the pairs that
+  // pass the centre gate by the kernel behind it on the same stream
+  PP_HIP_TRY(hipMemsetAsync(ious_dev, 0, (size_t)A * (size_t)G * 8, stream));
+  TargetArgs t{};
+  t.A = A;
+  t.G = (int)G;
+  t.a_corners = a_corners_dev;
+  t.a_centers = a_centers_dev;
+  t.a_center_cols = (int)a_center_cols;
+  t.g_center_cols = (int)g_center_cols;
+  t.g_corners = g_corners_dev;
+  t.g_centers_img = g_centers_dev;
+  t.ious = ious_dev;
+  t.errflag = errflag;
+  const unsigned nwg = (unsigned)((A + kTgtThreads - 1) / kTgtThreads);
+  hipLaunchKernelGGL(k_targets<true>, dim3(nwg), dim3(kTgtThreads), 0, stream, t);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -1201,6 +1112,9 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   t.a_centers = an.centers;
   t.a_wlh = an.wlh;
   t.a_yaw = an.yaw;
+  t.a_center_cols = 3;
+  t.g_center_cols = 3;
+  t.ious = nullptr;
   t.grid = an.grid;
   t.fm_w = an.fm_w;
   t.per_cell = an.per_cell;
@@ -1232,7 +1146,7 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
                        (int)G, t.errflag, t.cand_count, t.ticket);
     ctx->tgt_key = key;
   }
-  hipLaunchKernelGGL(k_targets, dim3((unsigned)nwg), dim3(kTgtThreads), 0, stream, t);
+  hipLaunchKernelGGL(k_targets<false>, dim3((unsigned)nwg), dim3(kTgtThreads), 0, stream, t);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
