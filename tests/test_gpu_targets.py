@@ -219,3 +219,34 @@ def test_targets_into_unaligned_outputs(gpu, oracle):
     assert torch.equal(cbuf[1:1 + ta.A * 9].view(ta.A, 9), c0) and torch.equal(rbuf[3:].view(ta.A, 9), r0)
     assert cbuf[0] == 7 and (cbuf[1 + ta.A * 9:] == 7).all() and (rbuf[:3] == 7).all()
     assert (r0[:, 0] == 1).sum().item() > 0
+
+
+@pytest.mark.parametrize("fm,per_cell,G,classes", [(24, 10, 7, 9),     # type table beyond its LDS copy (> 8 types)
+                                                   (9, 1, 1, 1),       # fewer anchors than one workgroup, one box, one class
+                                                   (33, 5, 64, 3),     # exactly one full chunk of ground truths
+                                                   (33, 2, 65, 12)])   # one box into the second chunk
+def test_small_and_odd_shapes(gpu, oracle, fm, per_cell, G, classes):
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    rng = np.random.default_rng(fm * 100 + per_cell)
+    dims = tuple((float(rng.uniform(3, 9)), float(rng.uniform(6, 16)), float(rng.uniform(1, 3))) for _ in range(per_cell))
+    yaws = tuple(float(rng.choice([0.0, 90.0, 45.0, 20.0])) for _ in range(per_cell))
+    zs = tuple(float(rng.uniform(0.2, 1.5)) for _ in range(per_cell))
+    cfg = boxes.AnchorConfig(fm, fm, 0.5, dims, yaws, zs)
+    anchors = boxes.make_anchors(cfg)
+    H = 2 * fm
+    gt = {"centers": np.column_stack([rng.uniform(2, H - 2, G), rng.uniform(2, H - 2, G), rng.uniform(0, 2, G)]),
+          "wlh": np.column_stack([rng.uniform(3, 9, G), rng.uniform(6, 16, G), rng.uniform(1, 3, G)]),
+          "yaw": rng.uniform(-np.pi, np.pi, G), "classes": rng.integers(0, classes, G).astype(np.int32)}
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
+    ref_c, ref_r, ious = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                              anchors["yaw"], gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], H,
+                                              pos_thresh=0.5, num_classes=classes)
+    for src in (cfg, anchors):
+        ta = TargetAssigner(src, canvas_height=H, pos_thresh=0.5, num_classes=classes, device=gpu)
+        cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+        torch.cuda.synchronize()
+        _check(cls_t, reg_t, ref_c, ref_r)
+    d = TargetAssigner(anchors, canvas_height=H, device=gpu).ious(k_img, c_img).cpu().numpy()
+    assert np.array_equal(d, ious)
