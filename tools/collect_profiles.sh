@@ -34,3 +34,7 @@ pmc pmc_c2_b1_fetch FETCH_SIZE $V --batch 1 --iters 50
 pmc pmc_c2_b1_write WRITE_SIZE $V --batch 1 --iters 50
 pmc pmc_c5_b4_fetch FETCH_SIZE $V --batch 4 --n 200000 --half 100 --P 30000 --iters 50
 pmc pmc_c5_b4_write WRITE_SIZE $V --batch 4 --n 200000 --half 100 --P 30000 --iters 50
+T="python3 $R/tools/bench_targets.py"
+stats targets_c3 $T
+pmc pmc_targets_c3_fetch FETCH_SIZE $T
+pmc pmc_targets_c3_write WRITE_SIZE $T
