@@ -118,16 +118,16 @@ __device__ __forceinline__ void anchor_corners(const TargetArgs &t, int64_t i, d
   }
 }
 
-// utils/box_utils.py:70-109.  The arithmetic is ONE out-of-line function on plain values (three
-// logs, a sine and a square root in f64 inlined at every use were most of the kernel's code, and a
-// by-reference argument would put the whole TargetArgs on the stack).
+// utils/box_utils.py:70-109 on plain values: one whole row on one lane -- the tail's forced rows (its
+// only use: inlined there; as an out-of-line function its callee-saved registers went through scratch
+// memory).  The workgroups' positives use target_component, 8 lanes per row.
 struct Row9 {
   float v[9];
 };
 struct BoxVals {
   double x, y, z, w, l, h, yaw;
 };
-__device__ __noinline__ Row9 target_row(BoxVals a, BoxVals g, double canvas_height) {
+__device__ __forceinline__ Row9 target_row(const BoxVals &a, const BoxVals &g, double canvas_height) {
   Row9 res;
   float *out = res.v;
   const double ax = a.x, ay = a.y, az = a.z, aw = a.w, al = a.l, ah = a.h, at = a.yaw;
