@@ -20,12 +20,13 @@ PP_ERR_NOMEM, PP_ERR_HIP, PP_ERR_INTERNAL = -5, -6, -7
 ORDER_ROW_MAJOR, ORDER_SCRAMBLED = 0, 1
 NUM_FEATURES = 9
 MAX_BATCH = 32
+MAX_INGEST_SWEEPS = 16       # PP_MAX_INGEST_SWEEPS
 KERNEL_SPLIT, KERNEL_TILE, KERNEL_EMIT = 0, 1, 2
 
 EXPORTS = [
     "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
     "pp_voxelize_reserve", "pp_voxelize_dev", "pp_subtract_mean_dev", "pp_voxelize_pfn_dev", "pp_voxelize_pfn_canvas_dev", "pp_pfn_dense_dev", "pp_scatter_canvas_dev", "pp_pfn_train_stats_dev", "pp_pfn_train_backward_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
-    "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_ingest_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_decode_batch_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_relu_bn_train_fwd_dev", "pp_relu_bn_train_bwd_dev", "pp_ctx_set_timing",
+    "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_ingest_dev", "pp_ingest_sweeps_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_decode_batch_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_relu_bn_train_fwd_dev", "pp_relu_bn_train_bwd_dev", "pp_ctx_set_timing",
     "pp_ctx_read_emit_ms", "pp_ctx_read_kernel_ms", "pp_voxelize_check",
 ]
 
@@ -159,6 +160,7 @@ def lib():
                                                  vp, vp, vp, vp, ctypes.POINTER(TargetParams), vp, vp]
         L.pp_ingest_dev.argtypes = [vp, vp, vp, i64, c_int, ctypes.POINTER(ctypes.c_double),
                                     ctypes.c_double, vp]
+        L.pp_ingest_sweeps_dev.argtypes = [vp, vp, c_int, vp, vp, c_int, vp, ctypes.c_double, vp]
         L.pp_decode_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(DecodeParams), vp, vp, vp]
         L.pp_decode_strided_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp,
                                             ctypes.POINTER(DecodeParams), vp, vp, vp]

@@ -51,14 +51,19 @@ class LidarIngest:
         total = sum(int(r.shape[0]) for r in raws)
         out = torch.empty((total, 4), dtype=torch.float32, device=self.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        cols = {int(r.shape[1]) for r in raws}
         off = 0
-        for r, (_, mat) in zip(raws, sweeps):
-            m = np.ascontiguousarray(np.asarray(mat, np.float64).reshape(4, 4))
-            n = int(r.shape[0])
-            rc = _lib.lib().pp_ingest_dev(
-                self._ctx.handle, stream, ctypes.c_void_p(r.data_ptr()), n, int(r.shape[1]),
-                m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self.min_dist,
-                ctypes.c_void_p(out.data_ptr() + off * 16))
-            _lib.check(rc, "pp_ingest_dev")
-            off += n
+        # sweeps with the same row width go sixteen at a time in one launch
+        for lo in range(0, len(raws), _lib.MAX_INGEST_SWEEPS if len(cols) == 1 else 1):
+            grp = raws[lo:lo + (_lib.MAX_INGEST_SWEEPS if len(cols) == 1 else 1)]
+            k = len(grp)
+            ptrs = (ctypes.c_void_p * k)(*[r.data_ptr() for r in grp])
+            ns = (ctypes.c_int64 * k)(*[int(r.shape[0]) for r in grp])
+            mats = np.ascontiguousarray(np.stack([np.asarray(m, np.float64).reshape(4, 4)
+                                                  for _, m in sweeps[lo:lo + k]]))
+            rc = _lib.lib().pp_ingest_sweeps_dev(
+                self._ctx.handle, stream, k, ptrs, ns, int(grp[0].shape[1]),
+                mats.ctypes.data_as(ctypes.c_void_p), self.min_dist, ctypes.c_void_p(out.data_ptr() + off * 16))
+            _lib.check(rc, "pp_ingest_sweeps_dev")
+            off += sum(int(r.shape[0]) for r in grp)
         return out

@@ -284,6 +284,15 @@ int pp_ingest_dev(pp_ctx_t *ctx, void *stream, const float *raw_dev, int64_t n_p
                   int raw_cols, const double *transform_rowmajor4x4, double min_dist,
                   float *points_out_dev);
 
+/* All sweeps of a sample in one launch (dataset.py:65-82 loops over num_sweeps files and hstacks):
+ * raw_dev[s] / n_points[s] / transforms_rowmajor4x4 + 16*s describe sweep s (HOST arrays of device
+ * pointers, sizes, 4x4 f64 matrices); sweep s lands at points_out_dev + 4 * (n_points[0] + ... +
+ * n_points[s-1]).  Same arithmetic as pp_ingest_dev.  1 <= n_sweeps <= PP_MAX_INGEST_SWEEPS. */
+#define PP_MAX_INGEST_SWEEPS 16
+int pp_ingest_sweeps_dev(pp_ctx_t *ctx, void *stream, int32_t n_sweeps, const float *const *raw_dev,
+                         const int64_t *n_points, int raw_cols, const double *transforms_rowmajor4x4,
+                         double min_dist, float *points_out_dev);
+
 /*
  * Inference post-processing on the device: replaces the
  * per-sample tail of evaluate() (evaluate.py:231-245): sigmoid / tanh / class max /

@@ -74,3 +74,34 @@ def test_ingest_argument_checks(gpu):
     out = ing([(np.zeros((0, 5), np.float32), np.eye(4)), (np.ones((3, 4), np.float32), np.eye(4))])
     torch.cuda.synchronize()
     assert out.shape == (3, 4) and torch.equal(out.cpu(), torch.ones(3, 4))
+
+
+def test_sweeps_in_one_launch_equal_the_per_sweep_calls(gpu):
+    """pp_ingest_sweeps_dev (all sweeps of a sample per launch, sixteen at a time) against
+    pp_ingest_dev sweep by sweep: the same bits, ragged sizes and an empty sweep included."""
+    import ctypes
+    import torch
+    from pp_amd import _lib
+    from pp_amd.ingest import LidarIngest
+    rng = np.random.default_rng(11)
+    sizes = [int(v) for v in rng.integers(0, 5000, 19)]
+    sizes[3] = 0
+    sweeps = [(rng.normal(0, 25, (n, 5)).astype(np.float32), _transmat(rng)) for n in sizes]
+    ing = LidarIngest(device=gpu, min_dist=1.5)
+    got = ing(sweeps)                                        # 16 + 3 sweeps: two launches
+    ref = torch.empty_like(got)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(ing.device).cuda_stream)
+    off = 0
+    for raw, mat in sweeps:
+        r = torch.from_numpy(raw).to(gpu)
+        m = np.ascontiguousarray(mat, np.float64)
+        rc = _lib.lib().pp_ingest_dev(ing._ctx.handle, stream, ctypes.c_void_p(r.data_ptr()), len(raw), 5,
+                                      m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1.5,
+                                      ctypes.c_void_p(ref.data_ptr() + off * 16))
+        _lib.check(rc, "pp_ingest_dev")
+        off += len(raw)
+    torch.cuda.synchronize()
+    a, b = got.cpu().numpy(), ref.cpu().numpy()
+    assert off == len(a) == sum(sizes)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))      # NaN-poisoned rows included
+    assert np.isnan(a[:, 0]).sum() > 0
