@@ -67,6 +67,7 @@ struct pp_ctx {
   // dynamic-LDS attribute set so far, per kernel instance: k_tile [f64 input][4/8/16 waves], k_split [f64 input]
   size_t tile_lds_armed[2][3] = {{0, 0, 0}, {0, 0, 0}};
   size_t split_lds_armed[2] = {0, 0};
+  bool sort_lds_armed = false;     // k_sort_runs' dynamic-LDS attribute set on this context's device
   int force_tile_waves = 0;  // development knob: PP_TILE_WAVES in the environment
   size_t dbg_stamps_off = 0, dbg_stamps_bytes = 0;  // PP_STAMPS builds (tools/lab)
   // host drop-in staging

@@ -520,11 +520,11 @@ extern "C" int pp_decode_batch_dev(pp_ctx_t *ctx, void *stream_, int32_t batch, 
   hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256), nb), dim3(256), 0, stream, d);
   d.run = (int)std::min<size_t>(kRun, cap);
   {
-    static thread_local bool armed = false;  // 128 KiB of dynamic LDS needs the attribute
-    if (!armed) {
+    // 128 KiB of dynamic LDS needs the attribute, once per device: kept with the context
+    if (!ctx->sort_lds_armed) {
       PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_runs),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRun * 8));
-      armed = true;
+      ctx->sort_lds_armed = true;
     }
   }
   const unsigned nrun_wgs = (unsigned)std::min<size_t>(kMaxRuns, cap / d.run);
