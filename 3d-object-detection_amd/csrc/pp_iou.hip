@@ -241,7 +241,8 @@ constexpr int kPairsPerRound = kTgtThreads / kGroup;
 constexpr int kStageCols = 16;  // widest target row staged in LDS
 constexpr int kForcedLds = 2048;  // ground truths whose column results the tail keeps in LDS
 
-constexpr int kMaxNP = 2;        // pairs a group of 8 lanes clips side by side (independent chains interleave)
+constexpr int kMaxNP = 1;        // pairs a group of 8 lanes clips side by side: 2 (and 3) measured no faster than
+                                 // as many rounds of one -- a round is issue-bound -- and cost 30 VGPRs
 constexpr int kLdsTypes = 8;     // anchor types per cell whose table is kept in LDS
 constexpr int kTailBatch = 8;    // list entries per thread the tail keeps in registers
 
@@ -298,8 +299,7 @@ __device__ __forceinline__ double group_shoelace(double x, double y, int n, int 
 // vertex goes through the same operations in the same order as in the serial loop (dp of vertex
 // i is dc of vertex i-1, the same function of the same operands), and the output ring is laid
 // out in the serial order (crossing point before the kept vertex, vertices ascending): same
-// bits.  A group clips NP pairs side by side: the chain of one pair is latency, not issue
-// slots alone, so two cost less than twice one.  (cx, cy): this lane's anchor corner of
+// bits.  A group clips NP pairs side by side (NP = 1 is what ships, see kMaxNP).  (cx, cy): this lane's anchor corner of
 // pair u (v < 4); gk: that pair's ground-truth corners in LDS; area_g: its area.  All 64 lanes
 // call it together; lanes of idle groups / idle pairs pass zeros.
 template <int NP>
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       }
       __syncthreads();
       IOU_STAMP(3);
-      // clip: 32 groups of 8 lanes, one or two pairs each per round
+      // clip: 32 groups of 8 lanes, one pair each per round
       for (int r0 = 0; r0 < wn; r0 += kMaxNP * kPairsPerRound) {
         if (wn - r0 <= kPairsPerRound)
           clip_round<1>(t, S, r0, wn, i0, tid, v, gbase, lds_types, bad);
