@@ -129,3 +129,22 @@ def test_postprocess_low_score_thresholds(gpu, oracle, fm, bias, thresh):
         assert n < 100 and (ref_b[:, 7] <= 0.25).any()      # low scores do make it into the output
     assert np.array_equal(kept_d.cpu().numpy()[:n], ref_k.astype(np.int32))
     assert np.allclose(boxes_d.cpu().numpy()[:n], ref_b, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("max_out,nms_thresh", [(1, 0.1), (7, 0.1), (300, 0.3), (1024, 0.6)])
+def test_postprocess_other_caps_and_nms_thresholds(gpu, oracle, max_out, nms_thresh):
+    """evaluate.py:241 keeps the first 100; the cap and the NMS threshold are parameters here: the kept
+    list (in LDS) grows to 1024 entries, the greedy pass stops in the middle of a block of 64."""
+    import torch
+    from pp_amd.postprocess import Detector
+    anchors, acfg, cls, reg, H, _ = _setup(gpu, 100, 21, -1.0)
+    det = Detector(anchors, acfg, H, 0.2, 0.2, -0.1 * H, -0.1 * H, nms_thresh=nms_thresh, max_out=max_out, device=gpu)
+    boxes_d, kept_d, count_d = det(torch.from_numpy(cls).to(gpu), torch.from_numpy(reg).to(gpu))
+    torch.cuda.synchronize()
+    ref_b, ref_k = oracle.postprocess(cls, reg, anchors["centers"], anchors["wlh"], anchors["yaw"], anchors["xy"],
+                                      H, 0.2, 0.2, -0.1 * H, -0.1 * H, nms_thresh=nms_thresh, max_out=max_out)
+    n = int(count_d.item())
+    assert n == len(ref_k) and (max_out > 300 or n == max_out)
+    assert np.array_equal(kept_d.cpu().numpy()[:n], ref_k.astype(np.int32))
+    assert (kept_d.cpu().numpy()[n:] == -1).all()
+    assert np.allclose(boxes_d.cpu().numpy()[:n], ref_b, rtol=1e-5, atol=1e-5)
