@@ -250,3 +250,27 @@ def test_small_and_odd_shapes(gpu, oracle, fm, per_cell, G, classes):
         _check(cls_t, reg_t, ref_c, ref_r)
     d = TargetAssigner(anchors, canvas_height=H, device=gpu).ious(k_img, c_img).cpu().numpy()
     assert np.array_equal(d, ious)
+
+
+def test_repeated_calls_are_identical(gpu, oracle):
+    """The kernel's tail reads what the other workgroups (other XCDs) published through write-through
+    stores and a ticket -- 300 back-to-back calls, with unrelated traffic on the chip in between, must
+    all give the first call's bits (a stale read would show as a missing forced row or a wrong argmax)."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    for cfg, H, n_gt in ((boxes.AnchorConfig(250, 250), 500, 40), (boxes.AnchorConfig.reference_default(), 600, 35)):
+        ta = TargetAssigner(cfg, canvas_height=H, device=gpu)
+        gt = synth.gt_boxes(n_gt, H, 13)
+        g = ta._gt_to_device(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"])
+        c0, r0 = ta.assign_device(*g)
+        junk = torch.empty((64 << 20,), dtype=torch.float32, device=gpu)
+        bad = 0
+        for it in range(300):
+            if it % 3 == 0:
+                junk.add_(1.0)                      # 512 MB of traffic: flushes L2 / the Infinity Cache
+            c, r = ta.assign_device(*g)
+            bad += int(not (torch.equal(c, c0) and torch.equal(r, r0)))
+        torch.cuda.synchronize()
+        assert bad == 0
+        assert (r0[:, 0] == 1).sum().item() >= n_gt // 2
