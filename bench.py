@@ -253,6 +253,12 @@ def main():
     rm_us, _ = kernel_means_us(vox_rm)
     vox_rm.set_timing(0)
     del vox_rm
+    # ... and at ONE sweep per launch: BASELINE configs[3]'s shape (one sweep per GPU), the short launch
+    vox1_dt = voxelizer_wall(pipe.voxelizer, points[:1], pipe._buffers(1), iters=200, warm=10)
+    pipe.voxelizer.set_timing(64)                    # the kernels, in a pass of their own
+    voxelizer_wall(pipe.voxelizer, points[:1], pipe._buffers(1), iters=64, warm=0)
+    one_us, _ = kernel_means_us(pipe.voxelizer)
+    pipe.voxelizer.set_timing(0)
 
     # next row: the feature net fused into the voxelizer -- the dense
     # [9,P,N] tensor is never built.  Reported beside the headline, not as it.
@@ -373,7 +379,13 @@ def main():
                                "row_major_order": {"sweeps_per_s": a.batch / vox_rm_dt,
                                                    "us_per_step": vox_rm_dt * 1e6,
                                                    "wall_frac": bytes_per_launch / vox_rm_dt / HBM_PEAK,
-                                                   "kernels_us": rm_us}},
+                                                   "kernels_us": rm_us},
+                               "one_sweep_per_launch": {"sweeps_per_s": 1.0 / vox1_dt, "us_per_step": vox1_dt * 1e6,
+                                                        "wall_frac": bytes_per_launch / a.batch / vox1_dt / HBM_PEAK,
+                                                        "kernels_us": one_us,
+                                                        "pipeline_frac": bytes_per_launch / a.batch
+                                                        / (sum(one_us.values()) * 1e-6) / HBM_PEAK
+                                                        if one_us else None}},
         }
         if fused is not None:
             out["fused_feature_net"] = fused
