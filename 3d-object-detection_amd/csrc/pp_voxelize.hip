@@ -151,7 +151,7 @@ __device__ __forceinline__ u64 wave_peers(unsigned key, int bits, bool valid) {
 
 __device__ __forceinline__ int shfl_up_i(int v, int d) { return __shfl_up(v, d, kWave); }
 
-#ifdef PP_STAMPS  // tools/lab builds: PP_STAMPS=1 stamps k_tile, =2 k_split (8 stamps per wave)
+#ifdef PP_STAMPS  // tools/lab builds: PP_STAMPS=1 stamps k_tile, =2 k_split, =3 k_emit (8 stamps per wave)
 #define PP_STAMP_AT(which, k)                                                        \
   do {                                                                               \
     if (PP_STAMPS == (which) && stamps && lane == 0)                                  \
@@ -162,6 +162,7 @@ __device__ __forceinline__ int shfl_up_i(int v, int d) { return __shfl_up(v, d, 
 #endif
 #define PP_STAMP(k) PP_STAMP_AT(1, k)
 #define PP_STAMP_S(k) PP_STAMP_AT(2, k)
+#define PP_STAMP_E(k) PP_STAMP_AT(3, k)
 
 // LDS of k_split: byte histograms [kSplitWaves][Tp], bin offsets u16 [Tp], wave totals.
 __host__ __device__ inline int split_tp(int ntiles) { return (ntiles + 3) & ~3; }
@@ -591,6 +592,7 @@ struct EmitArgs {
   // ... scattered straight into the BEV canvas (PPScatter, model/model.py:53-62)
   float *canvas;       // NULL, [B][H][W][64] (channels last) or [B][64][H][W]
   int canvas_h, canvas_w, canvas_nhwc;
+  u64 *stamps;         // tools/lab builds only
 };
 
 enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 };
@@ -964,6 +966,9 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   // derived from it (slab geometry, line masks, buffer offsets) in SGPRs
   const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kEmitWaves + w) * KW);
   if (p0 >= P) return;
+  [[maybe_unused]] u64 *stamps = a.stamps;
+  [[maybe_unused]] const int stamp_nx = gridDim.x;
+  PP_STAMP_E(0);
   const int kw_eff = min(KW, P - p0);
   // (1) pillar descriptors.  The pillar index of a cell = occupied cells of all earlier
   //     tiles + its place in its tile's list; k_tile left the former open, so every wave
@@ -996,6 +1001,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   if (blockIdx.x == 0 && w == 0 && lane == 0)
     a.totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
   const int npil = min((int)(tot & 0xFFFFFFFFull), P);
+  PP_STAMP_E(1);
   int4 m = make_int4(-1, 0, 0, 0);
 #pragma unroll
   for (int k = 0; k < KW; ++k) {
@@ -1057,6 +1063,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     L.cy[lane] = cy;
   }
   wave_sync();
+  PP_STAMP_E(2);
   int cnts[KW], segbeg[KW], segpad[KW];
   int T = 0, Tpad = 0;
 #pragma unroll
@@ -1203,8 +1210,10 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     if constexpr (MODE == kModePfn) pfn_finish();
     return;
   }
+  PP_STAMP_E(3);
   if (pooled) {
     emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, rec_r, segbeg, segpad, cnts, T);
+    PP_STAMP_E(4);
     if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn, AUX>(L, sg, rs, lane, segpad);
     if constexpr (MODE == kModePfn) {
 #pragma unroll
@@ -1286,7 +1295,9 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       }
     }
   }
+  PP_STAMP_E(5);
   if constexpr (MODE == kModePfn) pfn_finish();
+  PP_STAMP_E(6);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1427,7 +1438,7 @@ VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int re
   off = align_up(off + (size_t)B * 8, 256);
   l.stamps = off;
 #ifdef PP_STAMPS
-  off = align_up(off + (size_t)B * std::max(g.ntiles, l.nchunks_cap) * 16 * 64, 256);
+  off = align_up(off + (size_t)B * std::max(std::max(g.ntiles, l.nchunks_cap), (P + KW * kEmitWaves - 1) / (KW * kEmitWaves)) * 16 * 64, 256);
 #endif
   l.bytes = off;
   return l;
@@ -1517,7 +1528,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
 #ifdef PP_STAMPS
   stamps = reinterpret_cast<u64 *>(ws + l.stamps);
   ctx->dbg_stamps_off = l.stamps;
-  ctx->dbg_stamps_bytes = (size_t)B * (PP_STAMPS == 2 ? nchunks : g.ntiles) * 16 * 64;
+  ctx->dbg_stamps_bytes = (size_t)B * (PP_STAMPS == 2 ? nchunks : PP_STAMPS == 3 ? (P + KW * kEmitWaves - 1) / (KW * kEmitWaves) : g.ntiles) * 16 * 64;
 #endif
   // When the timing ring is armed every launch carries its own start/stop events
   // (hipExtLaunchKernelGGL binds them to the dispatch packet, so a pair brackets the
@@ -1563,6 +1574,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.canvas_h = canvas_h;
   a.canvas_w = canvas_w;
   a.canvas_nhwc = canvas_nhwc;
+  a.stamps = stamps;
   const dim3 grid_emit((unsigned)((P + KW * kEmitWaves - 1) / (KW * kEmitWaves)), (unsigned)B);
   switch (mode) {
     case kModeDenseVec4: {
