@@ -58,7 +58,34 @@ out.update(tgt_gt_centers=gt["centers"], tgt_gt_wlh=gt["wlh"], tgt_gt_yaw=gt["ya
            tgt_gt_classes=gt["classes"].astype(np.int32), tgt_gt_corners_img=k_img, tgt_gt_centers_img=c_img,
            tgt_anchor_corners=anchors["corners"], tgt_anchor_centers=anchors["centers"],
            tgt_ious=ious, tgt_cls=cls_t, tgt_reg=reg_t, tgt_geom=np.array([12, 12, H, 0.5]))
+# inference post-processing: a 16x16x2 head output, threshold 0.3 (evaluate.py:231-245)
+rng = np.random.default_rng(77)
+dcfg = boxes.AnchorConfig(16, 16)
+danch = boxes.make_anchors(dcfg)
+dcls = rng.normal(-1.6, 1.5, (dcfg.per_cell * 9, 16, 16)).astype(np.float32)
+dreg = rng.normal(0.0, 0.3, (dcfg.per_cell * 8, 16, 16)).astype(np.float32)
+dboxes, dkept = O.postprocess(dcls, dreg, danch["centers"], danch["wlh"], danch["yaw"], danch["xy"], 32, 0.2, 0.2,
+                              -3.2, -3.2, pos_thresh=0.3, nms_thresh=0.1)
+out.update(dec_cls=dcls, dec_reg=dreg, dec_boxes=dboxes, dec_kept=dkept.astype(np.int32))
+
+# lidar ingest: two sweeps of 5-column rows, rigid transforms, remove_close (dataset.py:51-88)
+def _tm(t, yaw):
+    m = np.eye(4)
+    m[:3, :3] = [[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]]
+    m[:3, 3] = t
+    return m
+sweeps = []
+for sidx in range(2):
+    raw = np.zeros((400, 5), np.float32)
+    raw[:, :4] = synth.lidar_like(400, 8.0, 300 + sidx)
+    raw[:, 4] = rng.integers(0, 64, 400)
+    mat = _tm([0.4 * sidx, -0.2, 0.1], 0.03 * (sidx + 1))
+    raw[10:20, :3] = (np.linalg.inv(mat) @ np.column_stack([rng.uniform(-0.4, 0.4, (10, 2)), np.zeros(10), np.ones(10)]).T).T[:, :3]
+    sweeps.append((raw, mat))
+ing = O.lidar_ingest(sweeps, min_dist=0.5)
+out.update(ing_raw=np.stack([r for r, _ in sweeps]), ing_mats=np.stack([m for _, m in sweeps]), ing_points=ing)
 np.savez_compressed(OUT, **out)
 print("wrote", OUT, os.path.getsize(OUT), "bytes;",
       {k: v.shape for k, v in out.items() if k.startswith(("vox_pillars", "tgt_ious", "tgt_reg"))},
-      "positives", int((reg_t[:, 0] == 1).sum()), "nonzero ious", int((ious > 0).sum()))
+      "positives", int((reg_t[:, 0] == 1).sum()), "nonzero ious", int((ious > 0).sum()),
+      "decoded", len(dkept), "ingested", ing.shape)

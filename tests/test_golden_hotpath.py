@@ -34,6 +34,17 @@ def test_oracle_reproduces_the_committed_vectors(oracle, gold):
     assert np.allclose(reg_t, gold["tgt_reg"], rtol=0, atol=1e-12)  # log / sin: libm
 
 
+def test_oracle_reproduces_decode_and_ingest_vectors(oracle, gold):
+    from pp_amd import boxes
+    a = boxes.make_anchors(boxes.AnchorConfig(16, 16))
+    b, k = oracle.postprocess(gold["dec_cls"], gold["dec_reg"], a["centers"], a["wlh"], a["yaw"], a["xy"], 32, 0.2, 0.2,
+                              -3.2, -3.2, pos_thresh=0.3, nms_thresh=0.1)
+    assert np.array_equal(k.astype(np.int32), gold["dec_kept"]) and len(k) >= 5
+    assert np.allclose(b, gold["dec_boxes"], rtol=1e-6, atol=1e-6)         # exp / tanh / asin: libm
+    sweeps = [(gold["ing_raw"][s], gold["ing_mats"][s]) for s in range(2)]
+    assert np.array_equal(oracle.lidar_ingest(sweeps, min_dist=0.5), gold["ing_points"])
+
+
 def _anchor_wlh_yaw(gold):
     from pp_amd import boxes
     a = boxes.make_anchors(boxes.AnchorConfig(int(gold["tgt_geom"][0]), int(gold["tgt_geom"][1])))
@@ -67,3 +78,26 @@ def test_hip_path_produces_the_committed_vectors(gpu, gold):
         if not isinstance(src, boxes.AnchorConfig):
             d = ta.ious(gold["tgt_gt_corners_img"], gold["tgt_gt_centers_img"]).cpu().numpy()
             assert np.array_equal(d, gold["tgt_ious"])
+
+
+@pytest.mark.gpu
+def test_hip_decode_and_ingest_produce_the_committed_vectors(gpu, gold):
+    import torch
+    from pp_amd import boxes
+    from pp_amd.ingest import LidarIngest
+    from pp_amd.postprocess import Detector
+    acfg = boxes.AnchorConfig(16, 16)
+    det = Detector(boxes.make_anchors(acfg), acfg, 32, 0.2, 0.2, -3.2, -3.2, pos_thresh=0.3, nms_thresh=0.1, device=gpu)
+    b, k, n = det(torch.from_numpy(gold["dec_cls"]).to(gpu), torch.from_numpy(gold["dec_reg"]).to(gpu))
+    torch.cuda.synchronize()
+    n = int(n.item())
+    assert n == len(gold["dec_kept"]) and np.array_equal(k.cpu().numpy()[:n], gold["dec_kept"])
+    assert np.allclose(b.cpu().numpy()[:n], gold["dec_boxes"], rtol=1e-5, atol=1e-5)
+    out = LidarIngest(device=gpu, min_dist=0.5)([(gold["ing_raw"][s], gold["ing_mats"][s]) for s in range(2)])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    keep = ~np.isnan(got[:, 0])
+    ref = gold["ing_points"]
+    assert keep.sum() == len(ref) and (~keep).sum() >= 10
+    assert np.abs(got[keep].astype(np.float64) - ref).max() <= 2e-6 * max(1.0, np.abs(ref[:, :3]).max())
+    assert np.array_equal(got[keep][:, 3], ref[:, 3].astype(np.float32))
