@@ -149,7 +149,27 @@ __device__ __forceinline__ u64 wave_peers(unsigned key, int bits, bool valid) {
   return peers;
 }
 
-__device__ __forceinline__ int shfl_up_i(int v, int d) { return __shfl_up(v, d, kWave); }
+
+// Inclusive prefix sum over the wave's 64 lanes on the DPP path (row shifts inside the rows of 16,
+// then the two row broadcasts of gfx9): 6 VALU adds with DPP operands instead of 6 ds_bpermute
+// round trips through the LDS pipeline.
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
+#define PP_DPP_ADD(ctrl, rmask)                                                              \
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false)
+  PP_DPP_ADD(0x111, 0xF);  // row_shr:1
+  PP_DPP_ADD(0x112, 0xF);  // row_shr:2
+  PP_DPP_ADD(0x114, 0xF);  // row_shr:4
+  PP_DPP_ADD(0x118, 0xF);  // row_shr:8
+  PP_DPP_ADD(0x142, 0xA);  // row_bcast:15 -> rows 1 and 3
+  PP_DPP_ADD(0x143, 0xC);  // row_bcast:31 -> rows 2 and 3
+#undef PP_DPP_ADD
+  return v;
+}
+// two independent 32-bit counts packed in one word (no carry between the halves)
+__device__ __forceinline__ unsigned long long wave_scan_2x32(unsigned long long v) {
+  const unsigned lo = wave_scan_u32((unsigned)(v & 0xFFFFFFFFull)), hi = wave_scan_u32((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 #ifdef PP_STAMPS  // tools/lab builds: PP_STAMPS=1 stamps k_tile, =2 k_split, =3 k_emit (8 stamps per wave)
 #define PP_STAMP_AT(which, k)                                                        \
@@ -227,12 +247,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
       mine += t;
     }
   }
-  int inc = (int)mine;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const int o = shfl_up_i(inc, d);
-    if (lane >= d) inc += o;
-  }
+  const int inc = (int)wave_scan_u32(mine);
   if (lane == kWave - 1) wtot[w] = (unsigned)inc;
   PP_STAMP_S(4);
   __syncthreads();
@@ -266,21 +281,6 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
 // ------------------------------------------------------------------------- //
 // k_tile                                                                      //
 // ------------------------------------------------------------------------- //
-__device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
-  int lo = __shfl_up((int)(v & 0xFFFFFFFFull), d, kWave);
-  int hi = __shfl_up((int)(v >> 32), d, kWave);
-  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
-}
-__device__ __forceinline__ u64 wave_sum64(u64 v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    int lo = __shfl_xor((int)(v & 0xFFFFFFFFull), d, kWave);
-    int hi = __shfl_xor((int)(v >> 32), d, kWave);
-    v += ((u64)(unsigned)hi << 32) | (unsigned)lo;
-  }
-  return v;
-}
-
 // A tile's points, in INPUT order, are the concatenation over the chunks of the
 // chunk's run for that tile.  The workgroup walks them through "windows" of kWin
 // chunks: one wave takes four {offset,count} entries per lane, prefix sums across
@@ -311,14 +311,9 @@ __device__ __forceinline__ int tile_stage_window(const int2 *__restrict__ row, i
 #pragma unroll
   for (int i = 0; i < 4; ++i) e[i] = (c0 + i < nch) ? row[c0 + i] : make_int2(0, 0);
   // the runs' offsets in their chunks = points of all earlier tiles in those chunks
-  *offsets = (unsigned)(wave_sum64((u64)(unsigned)(e[0].x + e[1].x + e[2].x + e[3].x)) & 0xFFFFFFFFull);
+  *offsets = (unsigned)__builtin_amdgcn_readlane((int)wave_scan_u32((unsigned)(e[0].x + e[1].x + e[2].x + e[3].x)), kWave - 1);
   const int loc = e[0].y + e[1].y + e[2].y + e[3].y;
-  int incl = loc;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const int o = shfl_up_i(incl, d);
-    if (lane >= d) incl += o;
-  }
+  const int incl = (int)wave_scan_u32((unsigned)loc);
   const int G = __builtin_amdgcn_readlane(incl, kWave - 1);
   int run = incl - loc;  // exclusive
 #pragma unroll
@@ -441,12 +436,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
       const unsigned c = L.cur[tid * cpt + e];
       mine += ((u64)c << 32) | (u64)(c > 0);
     }
-  u64 inc = mine;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const u64 o = shfl_up64(inc, d);
-    if (lane >= d) inc += o;
-  }
+  const u64 inc = wave_scan_2x32(mine);  // {points, occupied cells}: two independent counts
   if (lane == kWave - 1) s_wave[w] = inc;
   PP_STAMP(3);
   __syncthreads();
@@ -989,12 +979,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
         if (e == i) cv[i] = (unsigned)(v & 0xFFFFFFFFull);
     }
   }
-  u64 inc = mine;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const u64 o = shfl_up64(inc, d);
-    if (lane >= d) inc += o;
-  }
+  const u64 inc = wave_scan_2x32(mine);
   const u64 tot = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(inc >> 32), kWave - 1) << 32) |
                   (unsigned)__builtin_amdgcn_readlane((int)(inc & 0xFFFFFFFFull), kWave - 1);
   const unsigned lane_excl = (unsigned)((inc - mine) & 0xFFFFFFFFull);  // occupied cells before my tiles
@@ -1032,8 +1017,9 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       }
       before_k = run;
     }
-    tile_k = __shfl(tile_k, owner, kWave);
-    before_k = (unsigned)__shfl((int)before_k, owner, kWave);
+    const int owner_s = __builtin_amdgcn_readfirstlane(owner);  // uniform: v_readlane, not a permute
+    tile_k = __builtin_amdgcn_readlane(tile_k, owner_s);
+    before_k = (unsigned)__builtin_amdgcn_readlane((int)before_k, owner_s);
     if (lane == k) {
       m = a.tile_meta[((int64_t)b * ntiles + tile_k) * (1 << a.g.tile_shift) + (p - before_k)];
       if (MODE == kModeCompact) a.pillar_meta[(int64_t)b * P + p] = m;
