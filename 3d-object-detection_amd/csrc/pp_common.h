@@ -57,6 +57,42 @@ struct GridGeom {
 
 int make_grid(const pp_voxel_params_t *prm, GridGeom *g);
 
+#ifdef __HIPCC__
+// Inclusive prefix sum over the wave's 64 lanes on the DPP path (row shifts inside the rows of 16,
+// then the two row broadcasts of gfx9): 6 VALU adds with DPP operands instead of 6 ds_bpermute
+// round trips through the LDS pipeline.
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
+#define PP_DPP_ADD(ctrl, rmask)                                                              \
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false)
+  PP_DPP_ADD(0x111, 0xF);  // row_shr:1
+  PP_DPP_ADD(0x112, 0xF);  // row_shr:2
+  PP_DPP_ADD(0x114, 0xF);  // row_shr:4
+  PP_DPP_ADD(0x118, 0xF);  // row_shr:8
+  PP_DPP_ADD(0x142, 0xA);  // row_bcast:15 -> rows 1 and 3
+  PP_DPP_ADD(0x143, 0xC);  // row_bcast:31 -> rows 2 and 3
+#undef PP_DPP_ADD
+  return v;
+}
+// two independent 32-bit counts packed in one word (no carry between the halves)
+__device__ __forceinline__ unsigned long long wave_scan_2x32(unsigned long long v) {
+  const unsigned lo = wave_scan_u32((unsigned)(v & 0xFFFFFFFFull)), hi = wave_scan_u32((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// OR of a word over the wave's 64 lanes, the same way; the result is wave-uniform (an SGPR)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+#define PP_DPP_OR(ctrl, rmask) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false)
+  PP_DPP_OR(0x111, 0xF);
+  PP_DPP_OR(0x112, 0xF);
+  PP_DPP_OR(0x114, 0xF);
+  PP_DPP_OR(0x118, 0xF);
+  PP_DPP_OR(0x142, 0xA);
+  PP_DPP_OR(0x143, 0xC);
+#undef PP_DPP_OR
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+#endif  // __HIPCC__
+
 }  // namespace pp
 
 struct pp_ctx {

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_score(DecodeArgs d_) {
   const int lane = threadIdx.x & 63;
   int base = 0;
   if (lane == 0) base = atomicAdd(d.ncand, __popcll(m));
-  base = __shfl(base, 0, 64);
+  base = __builtin_amdgcn_readfirstlane(base);
   if (cand) {
     // decreasing score, then increasing anchor id; s in (0,1] so its bit pattern orders like s
     // (30 significant bits of 0x3F800000 - bits(s), 20 bits of anchor id: unique 50-bit keys)
@@ -409,12 +409,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
         n += __popcll(keptbits);
 #pragma unroll
         for (int w = w0 + 1; w < kChunkN / 64; ++w) {
-          unsigned lo = mine ? (unsigned)mr[w] : 0u, hi = mine ? (unsigned)(mr[w] >> 32) : 0u;
-#pragma unroll
-          for (int dd = 1; dd < 64; dd <<= 1) {
-            lo |= __shfl_xor(lo, dd, 64);
-            hi |= __shfl_xor(hi, dd, 64);
-          }
+          const unsigned lo = wave_or_u32(mine ? (unsigned)mr[w] : 0u), hi = wave_or_u32(mine ? (unsigned)(mr[w] >> 32) : 0u);
           removed[w] |= ((u64)hi << 32) | lo;
         }
       }

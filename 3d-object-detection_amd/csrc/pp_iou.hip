@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
     if (!tb) return;
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(t.cand_count, (unsigned)__popcll(tb));
-    base = (unsigned)__shfl((int)base, 0, 64);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     if (touched) {
       const unsigned pos = base + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
       ColEntry *ce = t.cand + pos;
@@ -728,12 +728,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       }
     const int cnt = __popcll(mask);
     // exclusive prefix sum of the counts over the workgroup (wave scans + wave totals)
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
+    const int inc = (int)wave_scan_u32((unsigned)cnt);
     if (lane == 63) S.woff[wv] = inc;
     __syncthreads();
     int wave_base = 0, total = 0;
