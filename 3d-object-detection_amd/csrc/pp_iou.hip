@@ -254,6 +254,7 @@ struct TgtLds {
     double2 poly[kMaxNP][kPairsPerRound][kGroup + 1];  // hand-over of a clip pass's output rings (+ a spare slot)
     float stage[kTgtThreads * kStageCols];         // target rows on their way out
   };
+  double terms[kMaxNP][kPairsPerRound][kGroup];  // shoelace terms on their way to the ordered sum
   double iou[kPairCap];
   u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
   int carg[kGtChunk];                     // first anchor reaching it
@@ -279,38 +280,47 @@ __device__ __forceinline__ void iou_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// shoelace_dev over a ring held one vertex per lane (lanes gbase .. gbase+n-1): the terms are
-// formed in parallel, the sum runs in the serial order
+// shoelace_dev over a ring of n vertices in LDS (ring[0..n), this group's slots), lane v holding
+// vertex v in (x, y): the terms are formed in parallel, handed over through LDS (terms[0..8)) and
+// summed in the serial order by every lane.  (Neighbour vertices and the terms come from LDS reads,
+// not from ds_bpermute shuffles: five LDS instructions instead of twenty.)
 template <int KMAX = kGroup>
-__device__ __forceinline__ double group_shoelace(double x, double y, int n, int v, int gbase) {
-  const int succ = gbase + ((v + 1 >= n) ? 0 : v + 1);
-  const double jx = __shfl(x, succ, 64), jy = __shfl(y, succ, 64);
-  const double term = x * jy - jx * y;
+__device__ __forceinline__ double group_shoelace(double x, double y, int n, int v, const double2 *ring,
+                                                 double *terms) {
+  const double2 j = ring[(v + 1 >= n) ? 0 : v + 1];
+  terms[v] = x * j.y - j.x * y;
+  iou_wave_sync();
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const double tk = __shfl(term, gbase + k, 64);
-    if (k < n) s = s + tk;
+  for (int k = 0; k < KMAX; k += 2) {
+    const double2 t2 = *reinterpret_cast<const double2 *>(terms + k);
+    if (k < n) s = s + t2.x;
+    if (k + 1 < n) s = s + t2.y;
   }
+  iou_wave_sync();
   return 0.5 * s;
 }
 
-// iou_pair_dev with the ring spread over the 8 lanes of a group: lane v holds vertex v.  Every
-// vertex goes through the same operations in the same order as in the serial loop (dp of vertex
-// i is dc of vertex i-1, the same function of the same operands), and the output ring is laid
-// out in the serial order (crossing point before the kept vertex, vertices ascending): same
-// bits.  A group clips NP pairs side by side (NP = 1 is what ships, see kMaxNP).  (cx, cy): this lane's anchor corner of
-// pair u (v < 4); gk: that pair's ground-truth corners in LDS; area_g: its area.  All 64 lanes
-// call it together; lanes of idle groups / idle pairs pass zeros.
+// iou_pair_dev with the ring spread over the 8 lanes of a group: lane v holds vertex v, the ring
+// is mirrored in LDS (poly[0..n)) so that a lane reads its predecessor from there.  Every vertex
+// goes through the same operations in the same order as in the serial loop (dp of vertex i is dc
+// of vertex i-1: the same function of the same operands, evaluated again), and the output ring is
+// laid out in the serial order (crossing point before the kept vertex, vertices ascending): same
+// bits.  A group clips NP pairs side by side (NP = 1 is what ships, see kMaxNP).  (cx, cy): this
+// lane's anchor corner of pair u (v < 4); gk: that pair's ground-truth corners in LDS; area_g: its
+// area.  All 64 lanes call it together; lanes of idle groups / idle pairs pass zeros.
 template <int NP>
 __device__ __forceinline__ void clip_groups(double (&cx)[NP], double (&cy)[NP], const double2 *(&gk)[NP],
-                                            const double (&area_g)[NP], double2 *(&poly)[NP], int v, int gbase,
-                                            double (&iou)[NP], bool (&wrong)[NP]) {
+                                            const double (&area_g)[NP], double2 *(&poly)[NP], double *(&terms)[NP],
+                                            int v, int gbase, double (&iou)[NP], bool (&wrong)[NP]) {
   double area_a[NP];
   int n[NP];
 #pragma unroll
+  for (int u = 0; u < NP; ++u) poly[u][v] = make_double2(cx[u], cy[u]);  // the anchor quad (v < 4; zeros beyond)
+  iou_wave_sync();
+#pragma unroll
   for (int u = 0; u < NP; ++u) {
-    area_a[u] = group_shoelace<4>(cx[u], cy[u], 4, v, gbase);
+    area_a[u] = group_shoelace<4>(cx[u], cy[u], 4, v, poly[u], terms[u]);
     wrong[u] = (area_a[u] < 0.0 || area_g[u] < 0.0);
     n[u] = 4;
   }
@@ -325,19 +335,18 @@ __device__ __forceinline__ void clip_groups(double (&cx)[NP], double (&cy)[NP], 
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const double2 a = gk[u][ia], b = gk[u][ib];
+      const double2 p = poly[u][(v == 0) ? max(n[u] - 1, 0) : v - 1];  // the predecessor vertex
       ax[u] = a.x;
       ay[u] = a.y;
       ex[u] = b.x - a.x;
       ey[u] = b.y - a.y;
+      px[u] = p.x;
+      py[u] = p.y;
     }
 #pragma unroll
-    for (int u = 0; u < NP; ++u) dc[u] = ex[u] * (cy[u] - ay[u]) - ey[u] * (cx[u] - ax[u]);
-#pragma unroll
     for (int u = 0; u < NP; ++u) {
-      const int pred = gbase + ((v == 0) ? max(n[u] - 1, 0) : v - 1);
-      dp[u] = __shfl(dc[u], pred, 64);
-      px[u] = __shfl(cx[u], pred, 64);
-      py[u] = __shfl(cy[u], pred, 64);
+      dc[u] = ex[u] * (cy[u] - ay[u]) - ey[u] * (cx[u] - ax[u]);
+      dp[u] = ex[u] * (py[u] - ay[u]) - ey[u] * (px[u] - ax[u]);
     }
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
@@ -352,6 +361,7 @@ __device__ __forceinline__ void clip_groups(double (&cx)[NP], double (&cy)[NP], 
     // spare slot.  (A ninth vertex cannot come from two convex quads; it would land there too.)
 #pragma unroll
     for (int u = 0; u < NP; ++u) tt[u] = dp[u] / (dp[u] - dc[u]);
+    iou_wave_sync();  // every lane has its predecessor: the ring may be overwritten
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int pos = __popc(cb[u] & below) + __popc(kb[u] & below);
@@ -368,11 +378,10 @@ __device__ __forceinline__ void clip_groups(double (&cx)[NP], double (&cy)[NP], 
       cx[u] = (v < n[u]) ? c.x : cx[u];
       cy[u] = (v < n[u]) ? c.y : cy[u];
     }
-    iou_wave_sync();
   }
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
-    const double inter = group_shoelace(cx[u], cy[u], n[u], v, gbase);
+    const double inter = group_shoelace(cx[u], cy[u], n[u], v, poly[u], terms[u]);
     double r = inter / (area_a[u] + area_g[u] - inter);
     if (!(inter > 0.0)) r = 0.0;
     if (n[u] < 3) r = 0.0;
@@ -388,6 +397,7 @@ __device__ __forceinline__ void clip_round(const TargetArgs &t, TgtLds &S, int r
   double cx[NP], cy[NP], area_g[NP], iou[NP];
   const double2 *gk[NP];
   double2 *poly[NP];
+  double *terms[NP];
   bool wrong[NP];
   int q[NP];
 #pragma unroll
@@ -409,8 +419,9 @@ __device__ __forceinline__ void clip_round(const TargetArgs &t, TgtLds &S, int r
     gk[u] = S.gk[pg];
     area_g[u] = on ? S.garea[pg] : 0.0;
     poly[u] = S.poly[u][tid >> 3];
+    terms[u] = S.terms[u][tid >> 3];
   }
-  clip_groups<NP>(cx, cy, gk, area_g, poly, v, gbase, iou, wrong);
+  clip_groups<NP>(cx, cy, gk, area_g, poly, terms, v, gbase, iou, wrong);
 #pragma unroll
   for (int u = 0; u < NP; ++u)
     if (q[u] < wn && v == 0) {
