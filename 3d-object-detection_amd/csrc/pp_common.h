@@ -91,6 +91,26 @@ __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
 #undef PP_DPP_OR
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// minimum / maximum of a double over the wave's 64 lanes on the same DPP steps (a lane without a
+// source keeps its own value); the result is read from lane 63 and is wave-uniform
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax_f64(double v) {
+#define PP_DPP_MM(ctrl, rmask)                                                                         \
+  do {                                                                                                 \
+    const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, rmask, 0xF, false); \
+    const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, rmask, 0xF, false); \
+    const double o_ = __hiloint2double(hi_, lo_);                                                       \
+    v = MAX ? fmax(v, o_) : fmin(v, o_);                                                                \
+  } while (0)
+  PP_DPP_MM(0x111, 0xF);
+  PP_DPP_MM(0x112, 0xF);
+  PP_DPP_MM(0x114, 0xF);
+  PP_DPP_MM(0x118, 0xF);
+  PP_DPP_MM(0x142, 0xA);
+  PP_DPP_MM(0x143, 0xC);
+#undef PP_DPP_MM
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 #endif  // __HIPCC__
 
 }  // namespace pp

@@ -648,13 +648,10 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
     double mnx = live ? acx : INFINITY, mxx = live ? acx : -INFINITY;
     double mny = live ? acy : INFINITY, mxy = live ? acy : -INFINITY;
     const bool odd = live && !(acx == acx && acy == acy);  // a NaN centre passes every gate
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      mnx = fmin(mnx, __shfl_xor(mnx, d, 64));
-      mxx = fmax(mxx, __shfl_xor(mxx, d, 64));
-      mny = fmin(mny, __shfl_xor(mny, d, 64));
-      mxy = fmax(mxy, __shfl_xor(mxy, d, 64));
-    }
+    mnx = wave_minmax_f64<false>(mnx);
+    mxx = wave_minmax_f64<true>(mxx);
+    mny = wave_minmax_f64<false>(mny);
+    mxy = wave_minmax_f64<true>(mxy);
     if (lane == 0) {
       const bool any_odd = __ballot(odd) != 0ull;
       S.bbox[wv][0] = any_odd ? -INFINITY : mnx;
