@@ -1017,23 +1017,14 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
     sg.aligned = ((((int64_t)P * sg.N4) & 7) == 0) && (KW * sg.N4 / 8 + 2 <= 64);
     sg.late_lines = 0;
   }
-  if (lane < KW) {
-    L.slot[lane] = m.x;
-    L.start[lane] = m.y;
-    L.cnt[lane] = m.z;
-    L.live[lane] = min(m.z, N);
-    double cx = 0, cy = 0;
-    if (m.z > 0) pillar_canvas(m.x, a.g, cx, cy);
-    L.cx[lane] = cx;
-    L.cy[lane] = cy;
-  }
-  wave_sync();
-  PP_STAMP_E(2);
+  // The counts come straight from the lanes that hold the descriptors, and the bucket read is issued
+  // BEFORE the descriptors go to LDS (the hand-off's fence would otherwise hold the loads back):
+  // their latency covers the canvas arithmetic and the LDS writes below.
   int cnts[KW], segbeg[KW], segpad[KW];
   int T = 0, Tpad = 0;
 #pragma unroll
   for (int k = 0; k < KW; ++k) {
-    cnts[k] = __builtin_amdgcn_readfirstlane(L.cnt[k]);
+    cnts[k] = __builtin_amdgcn_readlane(m.z, k);  // lane k holds pillar k's descriptor: no LDS round trip
     segbeg[k] = T;       // position in the CSR range
     segpad[k] = Tpad;    // position in the sorted LDS arrays: 4-aligned bucket starts
     T += cnts[k];
@@ -1047,12 +1038,24 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   for (int it = 0; it < kPre; ++it) rec_r[it].x = rec_r[it].y = rec_r[it].z = rec_r[it].w = 0;
   if (pooled && T > 0) {
     // the first occupied pillar's start (empty rows only follow occupied ones)
-    const int start0 = __builtin_amdgcn_readfirstlane(L.start[0]);
+    const int start0 = __builtin_amdgcn_readlane(m.y, 0);
     const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + start0;
 #pragma unroll
     for (int it = 0; it < kPre; ++it)
       if (lane + it * kWave < T) rec_r[it] = srec[lane + it * kWave];
   }
+  if (lane < KW) {
+    L.slot[lane] = m.x;
+    L.start[lane] = m.y;
+    L.cnt[lane] = m.z;
+    L.live[lane] = min(m.z, N);
+    double cx = 0, cy = 0;
+    if (m.z > 0) pillar_canvas(m.x, a.g, cx, cy);
+    L.cx[lane] = cx;
+    L.cy[lane] = cy;
+  }
+  wave_sync();
+  PP_STAMP_E(2);
   // (3) scatter indices; dense modes: the zero padding that needs no point data
   float *outb = nullptr;
   if (MODE != kModeCompact) {
