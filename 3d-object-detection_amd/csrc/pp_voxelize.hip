@@ -634,17 +634,36 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
     }
     wave_sync();
     const int c = min(kWave, cnt - base);
-    for (int t = 0; t < c; ++t) {  // uniform: every lane carries the chain
-      if (base + t == 0) {
-        m0 = (double)L.px[0];
-        m1 = (double)L.py[0];
-        m2 = (double)L.pz[0];
-      } else {
-        const double4 o = L.u.cq[t];
-        m0 = m0 * o.x + o.y;
-        m1 = m1 * o.x + o.z;
-        m2 = m2 * o.x + o.w;
-      }
+    // uniform: every lane carries the chain.  The chain is serial in m, its operands are not: four
+    // points' operands are fetched ahead of the four dependent steps (one LDS round trip per point
+    // otherwise -- a 381-point cell of BASELINE config 1 is 381 of them).
+    int t = 0;
+    if (base == 0) {
+      m0 = (double)L.px[0];
+      m1 = (double)L.py[0];
+      m2 = (double)L.pz[0];
+      t = 1;
+    }
+    for (; t + 3 < c; t += 4) {
+      const double4 o0 = L.u.cq[t], o1 = L.u.cq[t + 1], o2 = L.u.cq[t + 2], o3 = L.u.cq[t + 3];
+      m0 = m0 * o0.x + o0.y;
+      m1 = m1 * o0.x + o0.z;
+      m2 = m2 * o0.x + o0.w;
+      m0 = m0 * o1.x + o1.y;
+      m1 = m1 * o1.x + o1.z;
+      m2 = m2 * o1.x + o1.w;
+      m0 = m0 * o2.x + o2.y;
+      m1 = m1 * o2.x + o2.z;
+      m2 = m2 * o2.x + o2.w;
+      m0 = m0 * o3.x + o3.y;
+      m1 = m1 * o3.x + o3.z;
+      m2 = m2 * o3.x + o3.w;
+    }
+    for (; t < c; ++t) {
+      const double4 o = L.u.cq[t];
+      m0 = m0 * o.x + o.y;
+      m1 = m1 * o.x + o.z;
+      m2 = m2 * o.x + o.w;
     }
     wave_sync();
   }

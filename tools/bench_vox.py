@@ -20,9 +20,10 @@ ap.add_argument("--N", type=int, default=100)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--order", type=int, default=1)
+ap.add_argument("--step", type=float, default=0.2)
 a = ap.parse_args()
 
-cfg = VoxelConfig.square(a.half, 0.2, a.P, a.N, order=a.order)
+cfg = VoxelConfig.square(a.half, a.step, a.P, a.N, order=a.order)
 vox = PillarVoxelizer(cfg)
 pts = torch.from_numpy(np.stack([synth.lidar_like(a.n, a.half, s) for s in range(a.batch)])).cuda()
 out = (torch.empty((a.batch, 9, a.P, a.N), dtype=torch.float32, device="cuda"),
