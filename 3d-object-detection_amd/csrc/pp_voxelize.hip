@@ -1490,7 +1490,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   const long long per_tile = ((long long)maxn + g.ntiles - 1) / g.ntiles;
   const int tw = ctx->force_tile_waves ? ctx->force_tile_waves
                : per_tile <= 96 ? 4
-               : (per_tile <= 640 || g.order != PP_ORDER_ROW_MAJOR) ? 8 : 16;
+               : per_tile <= (g.order == PP_ORDER_ROW_MAJOR ? 640 : 1024) ? 8 : 16;
   const int wi = tw == 4 ? 0 : tw == 8 ? 1 : 2;
   const size_t lds_split = split_lds_bytes(g.ntiles);
   const size_t lds_tile = tile_lds_bytes(1 << g.tile_shift, tw);
