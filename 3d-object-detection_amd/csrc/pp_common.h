@@ -60,7 +60,8 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g);
 #ifdef __HIPCC__
 // Inclusive prefix sum over the wave's 64 lanes on the DPP path (row shifts inside the rows of 16,
 // then the two row broadcasts of gfx9): 6 VALU adds with DPP operands instead of 6 ds_bpermute
-// round trips through the LDS pipeline.
+// round trips through the LDS pipeline.  ALL 64 lanes must be active at the call (a DPP read of an
+// inactive lane leaves the destination unchanged, which would cut the carry chain).
 __device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
 #define PP_DPP_ADD(ctrl, rmask)                                                              \
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false)
