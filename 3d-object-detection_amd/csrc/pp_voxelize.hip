@@ -269,7 +269,6 @@ constexpr int kWin = 256;    // chunks per window
 constexpr int kCapT = 2048;  // positions per tile whose {source, cell} stay cached in LDS for pass 2
 constexpr int kP1 = 4;       // pass 1: rounds whose gathers are in flight together
 constexpr int kP2 = 3;       // pass 2: rounds fetched ahead
-constexpr unsigned kDropped = 0xFFFFFFFFu;
 
 struct TileLds {
   unsigned *cur;          // [tile slots] population, then bucket cursor
