@@ -1136,7 +1136,19 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   // folds the live points [sb, sb+live) of pillar k (features in L.u.feat) into acc
   auto pfn_fold = [&](int k, int sb, int live) {
     float mx = -INFINITY, mn = INFINITY;
-    for (int j = sb; j < sb + live; ++j) {
+    int j = sb;
+    for (; j + 1 < sb + live; j += 2) {  // two points per trip: their LDS reads do not wait for each other
+      float xv[9], yv[9];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        xv[d] = L.u.feat[d][j];
+        yv[d] = L.u.feat[d][j + 1];
+      }
+      const float r0 = pfn_relu_conv(acc, xv), r1 = pfn_relu_conv(acc, yv);
+      mx = fmaxf(mx, fmaxf(r0, r1));
+      mn = fminf(mn, fminf(r0, r1));
+    }
+    for (; j < sb + live; ++j) {
       float xv[9];
 #pragma unroll
       for (int d = 0; d < 9; ++d) xv[d] = L.u.feat[d][j];
