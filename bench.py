@@ -167,6 +167,23 @@ def static_traffic(key):
         return None, None
 
 
+def self_launch(n_ranks):
+    """Start `n_ranks` rank processes of this script (one per GPU) under torch.distributed.run and
+    wait for them.  Called before anything in this process has touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +203,14 @@ def main():
                     help="nccl = RCCL over xGMI (the contract); gloo only to rehearse the multi-rank "
                          "code path on a box with fewer GPUs than ranks (all ranks share device 0)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has
+        # made no HIP call so far and makes none (no torch.cuda.*, no pp_ctx_create): the N ranks are
+        # FRESH child processes of torch.distributed.run (never an exec of this one), rank 0's JSON
+        # line goes straight through the inherited stdout, and the exit code is the launcher's
+        # (non-zero when any rank failed).
+        sys.exit(self_launch(a.gpus))
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
@@ -372,6 +397,10 @@ def main():
                        "pillar_order": "scrambled (default; stand-in for the reference's hash-map order)",
                        "voxelizer_arithmetic": "f64 binning/mean, f32 features",
                        "parallelism": f"1 sweep-shard per GPU x{ctx.world_size}, no data-path collective"},
+            "collectives": {"backend": ctx.backend if ctx.distributed else None,
+                            "world_size": torch.distributed.get_world_size() if ctx.distributed else 1,
+                            "in_timed_step": "none (sweeps shard; no data-path collective)" if a.mode == "fwd"
+                            else "positive-count, gradient and loss-scalar all-reduces"},
             "roofline": roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc),
             "voxelizer_only": {"sweeps_per_s": a.batch / vox_dt, "us_per_step": vox_dt * 1e6,
                                "pipeline_GBps": bytes_per_launch / vox_dt / 1e9,

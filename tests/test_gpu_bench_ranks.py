@@ -27,11 +27,18 @@ def _free_port():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["fwd", "train"])
 def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-           "--train-steps", "2", "--backend", "gloo", "--mode", mode, "--no-cpu-baseline", "--no-stress"]
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+            "--train-steps", "2", "--backend", "gloo", "--mode", mode, "--no-cpu-baseline", "--no-stress"]
+    if mode == "fwd":
+        # the way the driver starts it: plain `python bench.py --gpus N`, no launcher, no WORLD_SIZE --
+        # bench.py starts the N rank processes itself (before any GPU call in the parent)
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
     env = dict(os.environ, TMPDIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -44,6 +51,7 @@ def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
     assert out["config"]["global_batch"] == 2 * out["config"]["sweeps_per_gpu_per_step"]
     assert out["value"] > 0 and abs(out["value"] - 3 * out["config"]["global_batch"] /
                                     (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert out["collectives"]["world_size"] == 2 and out["collectives"]["backend"] == "gloo"
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1 and 0 < rf["pipeline_frac"] <= rf["frac"]
     assert set(rf["pipeline"]["kernels_us"]) == {"k_split", "k_tile", "k_emit"}

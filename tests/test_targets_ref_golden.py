@@ -1,0 +1,82 @@
+"""Reference-run vectors of create_target / make_target (tests/golden/targets_ref_golden.npz, made by
+tests/golden/make_targets_ref_golden.py by importing /root/reference/utils/box_utils.py:162-232, 70-109 in the
+build container and CALLING the reference's own functions).
+
+What these pin: all of create_target's post-IoU logic (strict threshold, first argmax, the np.nonzero filter that
+drops a best anchor 0, one-hot zero-and-reset of forced rows, duplicates, write order) and all of make_target's
+arithmetic.  What they do not pin: the IoU values (the generator binds ``data.pillars.make_ious`` to the oracle's --
+the Boost build is not obtainable here), ``Box.bottom_corners`` and ``Quaternion.yaw_pitch_roll`` (inputs there).
+
+CPU: the oracle's restatement must equal the reference's outputs (bit-exact; same numpy, same statements).
+GPU: the HIP target assignment (uploaded anchor arrays AND on-the-fly anchor grid) must equal them: classes,
+positive flags and orientation bits exact, regression values within 1e-6 (device log / sin vs glibc, f32)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "targets_ref_golden.npz")
+REG_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def cases():
+    g = dict(np.load(GOLD))
+    out = {}
+    for name in g["__cases__"]:
+        out[str(name)] = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(str(name) + "/")}
+    assert {"hotpath", "c3_small", "default_anchor_set", "best_anchor_is_0", "duplicate_forced",
+            "exactly_at_threshold", "just_below_threshold", "ties", "yaw_quadrants", "no_overlap"} <= set(out)
+    return out
+
+
+def _setup(c):
+    from pp_amd import boxes
+    fm = c["fm"]
+    acfg = boxes.AnchorConfig(int(fm[0]), int(fm[1]), float(fm[2]), tuple(tuple(d) for d in c["dims"]),
+                              tuple(c["yaws_deg"]), tuple(c["zs"]))
+    gt = {"centers": c["gt_centers"], "wlh": c["gt_wlh"], "yaw": c["gt_yaw"], "classes": c["gt_classes"]}
+    return acfg, boxes.make_anchors(acfg), gt, int(fm[3]), float(fm[4])
+
+
+def test_oracle_equals_the_reference_run(oracle, cases):
+    from pp_amd import boxes
+    for name, c in cases.items():
+        acfg, anchors, gt, H, thresh = _setup(c)
+        c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], H)
+        cls_t, reg_t, _ = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                               anchors["yaw"], gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], H,
+                                               pos_thresh=thresh)
+        assert cls_t.shape == c["cls"].shape and reg_t.shape == c["reg"].shape, name
+        assert np.array_equal(cls_t, c["cls"]), name
+        assert np.array_equal(reg_t, c["reg"]), name          # same statements under the same numpy: bit-equal
+
+
+def test_the_vectors_cover_the_quirks(cases):
+    """the fixture is only worth its name if the branches are in it"""
+    c = cases["duplicate_forced"]
+    assert (c["cls"].sum(1) == 2).sum() == 1                   # one anchor carries two classes
+    c = cases["best_anchor_is_0"]
+    assert not c["cls"][0].any() and c["reg"][:, 0].sum() == 1   # the box on anchor 0 left nothing behind
+    a, b = cases["exactly_at_threshold"], cases["just_below_threshold"]
+    assert a["reg"][:, 0].sum() + 1 == b["reg"][:, 0].sum()    # strict >: one anchor flips with one ulp
+    y = cases["yaw_quadrants"]["reg"]
+    assert {0.0, 1.0} == set(np.unique(y[y[:, 0] == 1][:, 8]))
+    assert not cases["no_overlap"]["cls"].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["arrays", "grid"])
+def test_hip_target_assignment_equals_the_reference_run(gpu, cases, source):
+    import torch
+    from pp_amd.targets import TargetAssigner
+    for name, c in cases.items():
+        acfg, anchors, gt, H, thresh = _setup(c)
+        ta = TargetAssigner(anchors if source == "arrays" else acfg, canvas_height=H, pos_thresh=thresh, device=gpu)
+        cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+        torch.cuda.synchronize()
+        cls_t, reg_t = cls_t.cpu().numpy(), reg_t.cpu().numpy()
+        ref_c, ref_r = c["cls"].astype(np.float32), c["reg"].astype(np.float32)
+        assert np.array_equal(cls_t, ref_c), name
+        assert np.array_equal(reg_t[:, 0], ref_r[:, 0]) and np.array_equal(reg_t[:, 8], ref_r[:, 8]), name
+        assert np.abs(reg_t - ref_r).max() <= REG_TOL, name
