@@ -55,7 +55,8 @@ struct GridGeom {
   unsigned long long barrett;         // floor(2^64 / ncells), for the device-side modulo
 };
 
-int make_grid(const pp_voxel_params_t *prm, GridGeom *g);
+// step_mode: tile sizes for k_step's 4-wave tile role (more, smaller tiles)
+int make_grid(const pp_voxel_params_t *prm, GridGeom *g, int step_mode = 0);
 
 #ifdef __HIPCC__
 // Inclusive prefix sum over the wave's 64 lanes on the DPP path (row shifts inside the rows of 16,
@@ -116,14 +117,26 @@ __device__ __forceinline__ double wave_minmax_f64(double v) {
 
 }  // namespace pp
 
+// A batch on its way through k_step's three roles (pp_voxelize_step_dev).
+struct pp_step_batch {
+  bool valid = false;
+  int slot = 0;      // workspace slot (1..3)
+  int batch = 0, maxn = 0;
+  int n_points[PP_MAX_BATCH] = {0};
+  int64_t points_stride = 0;
+  pp_voxel_params_t prm = {};
+};
+
 struct pp_ctx {
   int device = 0;
-  // voxelizer scratch, laid out by VoxWorkspace (pp_voxelize.hip)
-  pp::DevBuf vox_ws;
-  unsigned long long vox_layout_key[6] = {0, 0, 0, 0, 0, 0};
-  // dynamic-LDS attribute set so far, per kernel instance: k_tile [f64 input][4/8/16 waves], k_split [f64 input]
-  size_t tile_lds_armed[2][3] = {{0, 0, 0}, {0, 0, 0}};
-  size_t split_lds_armed[2] = {0, 0};
+  // voxelizer scratch, laid out by VoxLayout (pp_voxelize.hip).  Slot 0 serves the plain calls; the
+  // batches of the software-pipelined mode (pp_voxelize_step_dev: three of them are in flight, one
+  // per role of k_step) rotate through slots 1..3.
+  static constexpr int kVoxSlots = 4;
+  pp::DevBuf vox_ws[kVoxSlots];
+  unsigned long long vox_layout_key[kVoxSlots][6] = {};
+  pp_step_batch step_batch[2];   // [0]: split done, waits for its tile role; [1]: tiled, waits for its emit role
+  int step_next_slot = 1;
   bool sort_lds_armed = false;     // k_sort_runs' dynamic-LDS attribute set on this context's device
   int force_tile_waves = 0;  // development knob: PP_TILE_WAVES in the environment
   size_t dbg_stamps_off = 0, dbg_stamps_bytes = 0;  // PP_STAMPS builds (tools/lab)
@@ -140,4 +153,5 @@ struct pp_ctx {
   int ev_slots = 0;
   int ev_next = 0;
   int ev_count = 0;
+  int ev_columns = 7;    // bit k: column PP_KERNEL_k was recorded (k_step launches record the EMIT column only)
 };

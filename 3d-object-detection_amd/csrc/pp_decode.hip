@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void k_score(DecodeArgs d_) {
     // (30 significant bits of 0x3F800000 - bits(s), 20 bits of anchor id: unique 50-bit keys)
     const unsigned sb = (unsigned)__float_as_int(s);
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-    d.keys[base + __popcll(m & lt)] = ((u64)(0x3F800000u - sb) << 20) | (u64)a;
+    // (the counter is zero at the start of a call, so base + rank < A <= cap; the bound only matters
+    // if an earlier call died between k_score and k_nms and left the counter non-zero)
+    const int pos = base + __popcll(m & lt);
+    if (pos < d.cap) d.keys[pos] = ((u64)(0x3F800000u - sb) << 20) | (u64)a;
   }
 }
 
@@ -421,7 +424,13 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms(DecodeArgs d_) {
     NMS_STAMP(6);
     __syncthreads();
     NMS_STAMP(7);
-    if (s_done || !s_full) break;  // enough boxes, or the candidates ran out inside this chunk
+    // enough boxes, or the candidates ran out inside this chunk.  Both flags go to registers and a
+    // barrier follows: the next iteration's `s_full = valid` (thread 1023, before that iteration's
+    // first barrier when nothing is merged) must not reach a wave that has not read this one yet --
+    // it would leave the loop alone and the others would wait for it at the next barrier.
+    const bool stop = s_done || !s_full;
+    __syncthreads();
+    if (stop) break;
   }
   __syncthreads();
   if (t == 0) *d.count = s_nkept;
@@ -512,20 +521,27 @@ extern "C" int pp_decode_batch_dev(pp_ctx_t *ctx, void *stream_, int32_t batch, 
   d.count = count_out;
   d.boxes = boxes_out;
   const unsigned nb = (unsigned)batch;
+  // 128 KiB of dynamic LDS needs the attribute, once per device (a constant: the same value from
+  // every context) -- BEFORE the first launch, so that a failure here leaves the counters untouched
+  if (!ctx->sort_lds_armed) {
+    PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_runs),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kRun * 8));
+    ctx->sort_lds_armed = true;
+  }
   hipLaunchKernelGGL(k_score, dim3((unsigned)((A + 255) / 256), nb), dim3(256), 0, stream, d);
   d.run = (int)std::min<size_t>(kRun, cap);
-  {
-    // 128 KiB of dynamic LDS needs the attribute, once per device: kept with the context
-    if (!ctx->sort_lds_armed) {
-      PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_runs),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kRun * 8));
-      ctx->sort_lds_armed = true;
-    }
-  }
   const unsigned nrun_wgs = (unsigned)std::min<size_t>(kMaxRuns, cap / d.run);
   hipLaunchKernelGGL(k_sort_runs, dim3(nrun_wgs, nb), dim3(kSortThreads), (size_t)d.run * 8, stream, d, d.run);
   hipLaunchKernelGGL(k_nms, dim3(1, nb), dim3(kNmsThreads), 0, stream, d);  // + box decode
-  PP_HIP_TRY(hipGetLastError());
+  {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      // k_score may have run without the k_nms that zeroes the candidate counters again
+      (void)hipMemsetAsync(ws, 0, kCounterBytes, stream);
+      set_error("decode launch failed: %s", hipGetErrorString(e));
+      return PP_ERR_HIP;
+    }
+  }
   return PP_OK;
 }
 

@@ -125,7 +125,7 @@ extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
   int prev = -1;
   if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  ctx->vox_ws.release();
+  for (auto &w : ctx->vox_ws) w.release();
   ctx->stage_in.release();
   ctx->stage_out.release();
   ctx->stage_out2.release();
@@ -183,6 +183,10 @@ extern "C" int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int ca
     set_error("pp_ctx_read_kernel_ms: bad argument");
     return PP_ERR_VALUE;
   }
+  if (!((ctx->ev_columns >> which) & 1)) {  // k_step launches: one kernel, recorded in the EMIT column
+    *count = 0;
+    return PP_OK;
+  }
   const int n = ctx->ev_count < cap ? ctx->ev_count : cap;
   const int slots = ctx->ev_slots > 0 ? ctx->ev_slots : 1;
   int idx = (ctx->ev_next - ctx->ev_count + 2 * slots) % slots;  // oldest first
@@ -192,10 +196,7 @@ extern "C" int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int ca
     idx = (idx + 1) % slots;
   }
   *count = n;
-  if (which == PP_KERNEL_EMIT) {
-    ctx->ev_count = 0;
-    ctx->ev_next = 0;
-  }
+  if (which == PP_KERNEL_EMIT) ctx->ev_count = 0;   // read; the ring keeps turning
   return PP_OK;
 }
 

@@ -37,6 +37,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -154,7 +155,7 @@ __device__ __forceinline__ u64 wave_peers(unsigned key, int bits, bool valid) {
 #define PP_STAMP_AT(which, k)                                                        \
   do {                                                                               \
     if (PP_STAMPS == (which) && stamps && lane == 0)                                  \
-      stamps[(((size_t)blockIdx.y * stamp_nx + blockIdx.x) * 16 + w) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+      stamps[(((size_t)stamp_by * stamp_nx + stamp_bx) * 16 + w) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define PP_STAMP_AT(which, k) do {} while (0)
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
   const int chunk = blockIdx.x;
   if (chunk * kChunk >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  [[maybe_unused]] const int stamp_nx = gridDim.x;
+  [[maybe_unused]] const int stamp_nx = gridDim.x, stamp_bx = blockIdx.x, stamp_by = blockIdx.y;
   PP_STAMP_S(0);
   const int ntiles = g.ntiles;
   const int Tp = split_tp(ntiles);
@@ -255,6 +256,99 @@ __global__ __launch_bounds__(kSplitThreads) void k_split(
     kpts[dst] = rec;
   }
   PP_STAMP_S(7);
+}
+
+// k_split's work for a workgroup of PW < 16 physical waves (k_step's split role): the chunk is still
+// 1024 points = 16 "virtual waves" of 64 (the unit of the ballots and of the byte histogram's rows,
+// so `mat` and the grouped arrays come out exactly as k_split leaves them); physical wave w walks
+// the virtual waves [w*R, w*R + R), R = 16 / PW, one point per lane and virtual wave.
+template <typename T, int PW>
+__device__ __forceinline__ void split_body(
+    const T *__restrict__ pts, int64_t sweep_stride, int64_t s0, int64_t s1, int contig,
+    const NPoints &np, const GridGeom &g, int ncap, int nchunks_cap, int *__restrict__ kslot,
+    typename Rec4<T>::type *__restrict__ kpts, int2 *__restrict__ mat, unsigned char *split_smem,
+    int chunk, int b) {
+  using Rec = typename Rec4<T>::type;
+  constexpr int THREADS = PW * kWave;
+  constexpr int R = kSplitWaves / PW;
+  static_assert(kSplitWaves % PW == 0, "virtual waves per physical wave");
+  const int n = np.n[b];
+  if (chunk * kChunk >= n) return;  // the whole workgroup
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ntiles = g.ntiles;
+  const int Tp = split_tp(ntiles);
+  unsigned char *whist = split_smem;
+  unsigned short *binoff = reinterpret_cast<unsigned short *>(split_smem + kSplitWaves * Tp);
+  unsigned *wtot = reinterpret_cast<unsigned *>(split_smem + kSplitWaves * Tp + 2 * Tp);
+  for (int i = tid; i < kSplitWaves * Tp / 4; i += THREADS) reinterpret_cast<unsigned *>(whist)[i] = 0u;
+  Rec rec[R];
+  int slot[R], rank_w[R], cnt_w[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = chunk * kChunk + (w * R + r) * kWave + lane;
+    rec[r].x = rec[r].y = rec[r].z = rec[r].w = 0;
+    slot[r] = -1;
+    if (i < n) {
+      rec[r] = load_point<T>(pts + (int64_t)b * sweep_stride * 4, i, s0, s1, contig != 0);
+      const int cell = point_cell((double)rec[r].x, (double)rec[r].y, (double)rec[r].z, g);
+      if (cell >= 0) slot[r] = cell_to_slot(cell, g);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool valid = slot[r] >= 0;
+    const unsigned tile = valid ? (unsigned)slot[r] >> g.tile_shift : 0u;
+    const u64 peers = wave_peers(tile, g.tile_bits, valid);
+    rank_w[r] = __popcll(peers & lanes_below(lane));
+    cnt_w[r] = __popcll(peers);
+  }
+  __syncthreads();  // histogram zeroed
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (slot[r] >= 0 && rank_w[r] == 0)
+      whist[(w * R + r) * Tp + ((unsigned)slot[r] >> g.tile_shift)] = (unsigned char)cnt_w[r];  // <= 64
+  __syncthreads();
+  // bin totals over the 16 virtual waves, exclusive scan over the bins (consecutive bins per thread)
+  const int nb = (ntiles + THREADS - 1) / THREADS;
+  unsigned mine = 0;
+  for (int e = 0; e < nb; ++e) {
+    const int bin = tid * nb + e;
+    if (bin < ntiles) {
+#pragma unroll
+      for (int vv = 0; vv < kSplitWaves; ++vv) mine += whist[vv * Tp + bin];
+    }
+  }
+  const int inc = (int)wave_scan_u32(mine);
+  if (lane == kWave - 1) wtot[w] = (unsigned)inc;
+  __syncthreads();
+  unsigned base = (unsigned)inc - mine;
+#pragma unroll
+  for (int ww = 0; ww < PW; ++ww)
+    if (ww < w) base += wtot[ww];
+  int2 *mrow = mat + (int64_t)b * ntiles * nchunks_cap + chunk;
+  for (int e = 0; e < nb; ++e) {
+    const int bin = tid * nb + e;
+    if (bin < ntiles) {
+      unsigned t = 0;
+#pragma unroll
+      for (int vv = 0; vv < kSplitWaves; ++vv) t += whist[vv * Tp + bin];
+      binoff[bin] = (unsigned short)base;  // < 1024
+      mrow[(int64_t)bin * nchunks_cap] = make_int2((int)base, (int)t);
+      base += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (slot[r] >= 0) {
+      const unsigned tile = (unsigned)slot[r] >> g.tile_shift;
+      unsigned pos = binoff[tile] + (unsigned)rank_w[r];
+      for (int vv = 0; vv < w * R + r; ++vv) pos += whist[vv * Tp + tile];
+      const int64_t dst = (int64_t)b * ncap + (int64_t)chunk * kChunk + pos;
+      kslot[dst] = slot[r];
+      kpts[dst] = rec[r];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------- //
@@ -330,23 +424,21 @@ __device__ __forceinline__ unsigned byte_sum(unsigned v) { return __builtin_amdg
 //            consecutive positions, wave w takes positions [64w, 64w+64) of the round; a
 //            point's rank = cursor (earlier rounds) + points of its cell in earlier waves of
 //            the round (byte histogram column) + earlier lanes of its wave (ballots)
+// (the body of k_tile; k_step runs it as one of its roles with tile / b decoded from a flat block id)
 template <typename T, int WAVES>
-__global__ __launch_bounds__(WAVES * kWave) void k_tile(
-    NPoints np, GridGeom g, int ncap, int nchunks_cap, const int *__restrict__ kslot,
+__device__ __forceinline__ void tile_body(
+    const NPoints &np, const GridGeom &g, int ncap, int nchunks_cap, const int *__restrict__ kslot,
     const typename Rec4<T>::type *__restrict__ kpts, const int2 *__restrict__ mat,
     typename Rec4<T>::type *__restrict__ sorted_pts, int4 *__restrict__ tile_meta,
-    u64 *__restrict__ tile_agg, u64 *stamps) {
-  extern __shared__ __attribute__((aligned(16))) unsigned tile_smem[];
+    u64 *__restrict__ tile_agg, u64 *stamps, unsigned *tile_smem, int tile, int b) {
   using Rec = typename Rec4<T>::type;
   constexpr int THREADS = WAVES * kWave;
   constexpr int HW = WAVES / 4;  // dwords of a cell's per-wave byte counts
   __shared__ int s_G;
   __shared__ unsigned s_before;  // points of all earlier tiles
   __shared__ u64 s_wave[WAVES];
-  const int b = blockIdx.y;
-  const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  [[maybe_unused]] const int stamp_nx = g.ntiles;
+  [[maybe_unused]] const int stamp_nx = g.ntiles, stamp_bx = tile, stamp_by = b;
   PP_STAMP(0);
   const int TS = 1 << g.tile_shift;
   TileLds L;
@@ -523,6 +615,17 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     }
   }
   PP_STAMP(7);
+}
+
+template <typename T, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void k_tile(
+    NPoints np, GridGeom g, int ncap, int nchunks_cap, const int *__restrict__ kslot,
+    const typename Rec4<T>::type *__restrict__ kpts, const int2 *__restrict__ mat,
+    typename Rec4<T>::type *__restrict__ sorted_pts, int4 *__restrict__ tile_meta,
+    u64 *__restrict__ tile_agg, u64 *stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned tile_smem[];
+  tile_body<T, WAVES>(np, g, ncap, nchunks_cap, kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, stamps,
+                      tile_smem, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------- //
@@ -938,23 +1041,19 @@ __device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom
 }
 
 // AUX: cache policy of the dense tensor's 16-byte stores (kAuxPlain / kAuxSc1, see launch_pipeline)
-template <typename TIn, int MODE, int AUX = 0>
-#ifndef PP_EMIT_MINWAVES
-#define PP_EMIT_MINWAVES 4
-#endif
-__global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArgs a) {
-  __shared__ WaveLds<TIn> lds[kEmitWaves];
+// (the body of k_emit; k_step runs it as one of its roles: bx / b from a flat block id, nbx = blocks per sweep)
+template <typename TIn, int MODE, int AUX>
+__device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, int bx, int b, int nbx) {
   using Rec = typename Rec4<TIn>::type;
-  const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int N = a.N, P = a.P;
   WaveLds<TIn> &L = lds[w];
   // wave-uniform by construction; readfirstlane lets the compiler keep everything
   // derived from it (slab geometry, line masks, buffer offsets) in SGPRs
-  const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kEmitWaves + w) * KW);
+  const int p0 = __builtin_amdgcn_readfirstlane((bx * kEmitWaves + w) * KW);
   if (p0 >= P) return;
   [[maybe_unused]] u64 *stamps = a.stamps;
-  [[maybe_unused]] const int stamp_nx = gridDim.x;
+  [[maybe_unused]] const int stamp_nx = nbx, stamp_bx = bx, stamp_by = b;
   PP_STAMP_E(0);
   const int kw_eff = min(KW, P - p0);
   // (1) pillar descriptors.  The pillar index of a cell = occupied cells of all earlier
@@ -965,14 +1064,15 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const int nv = (ntiles + kWave - 1) / kWave;  // tiles per lane, <= 64
   const u64 *agg = a.tile_agg + (int64_t)b * ntiles;
   u64 mine = 0;
-  unsigned cv[4] = {0u, 0u, 0u, 0u};  // the lane's tiles' occupied-cell counts (all of them when nv <= 4)
+  constexpr int kCv = 8;
+  unsigned cv[kCv] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // the lane's tiles' occupied-cell counts (all of them when nv <= 8)
   for (int e = 0; e < nv; ++e) {
     const int t = lane * nv + e;
     if (t < ntiles) {
       const u64 v = agg[t];
       mine += v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < kCv; ++i)
         if (e == i) cv[i] = (unsigned)(v & 0xFFFFFFFFull);
     }
   }
@@ -980,7 +1080,7 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   const u64 tot = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(inc >> 32), kWave - 1) << 32) |
                   (unsigned)__builtin_amdgcn_readlane((int)(inc & 0xFFFFFFFFull), kWave - 1);
   const unsigned lane_excl = (unsigned)((inc - mine) & 0xFFFFFFFFull);  // occupied cells before my tiles
-  if (blockIdx.x == 0 && w == 0 && lane == 0)
+  if (bx == 0 && w == 0 && lane == 0)
     a.totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
   const int npil = min((int)(tot & 0xFFFFFFFFull), P);
   PP_STAMP_E(1);
@@ -999,9 +1099,9 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
       for (int e = 0; e < nv; ++e) {
         const int t = lane * nv + e;
         unsigned c = 0;
-        if (e < 4) {
+        if (e < kCv) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < kCv; ++i)
             if (e == i) c = cv[i];
         } else if (t < ntiles) {
           c = (unsigned)(agg[t] & 0xFFFFFFFFull);
@@ -1298,6 +1398,146 @@ __global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArg
   PP_STAMP_E(6);
 }
 
+#ifndef PP_EMIT_MINWAVES
+#define PP_EMIT_MINWAVES 4
+#endif
+template <typename TIn, int MODE, int AUX = 0>
+__global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArgs a) {
+  __shared__ WaveLds<TIn> lds[kEmitWaves];
+  emit_body<TIn, MODE, AUX>(a, lds, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------- //
+// k_step: the three stages of three CONSECUTIVE batches in one launch         //
+// ------------------------------------------------------------------------- //
+// Software pipelining across calls.  k_split / k_tile are latency chains that leave the memory system
+// idle, k_emit is the dense store; inside one call they depend on each other, but tile(batch i-1),
+// split(batch i) and emit(batch i-2) do not.  One launch runs all three as ROLES of one grid -- the
+// block id decides: first the tile role's workgroups, then the split role's, then the emit role's
+// (the few latency-bound ones are dispatched first and run beside the thousands that store) -- and
+// the launch boundary is the only synchronisation: the tile role reads what the previous launch's
+// split role wrote, the emit role what the previous launch's tile role wrote.  One launch per call
+// instead of three, one drain instead of three, and the binning chains hide behind the store.
+// All roles run 256-thread workgroups (emit: 4 waves x 4 pillars as in k_emit; tile: 4 waves; split:
+// 4 physical waves x 4 virtual waves) and share the dynamic LDS.
+struct SplitRole {
+  const void *pts;
+  int64_t sweep_stride;
+  NPoints np;
+  GridGeom g;
+  int ncap, nchunks_cap, nchunks;
+  int *kslot;
+  void *kpts;
+  int2 *mat;
+};
+struct TileRole {
+  NPoints np;
+  GridGeom g;
+  int ncap, nchunks_cap;
+  const int *kslot;
+  const void *kpts;
+  const int2 *mat;
+  void *sorted_pts;
+  int4 *tile_meta;
+  u64 *tile_agg;
+};
+// What the prefetch role streams through (k_step): the arrays the tile and emit roles read were written by the
+// PREVIOUS launch; when other work ran in between (the network's activations: a GiB per step) they are in HBM
+// again, and both roles are chains of dependent loads -- every hop would pay an HBM miss under a full store
+// load.  A few workgroups at the head of the grid read those arrays once, front to back, with many loads in
+// flight: the lines land in the memory-side Infinity Cache before most of the chains ask for them.
+struct PrefetchRole {
+  const void *ptr[6];
+  unsigned n16[6];       // 16-byte units
+  const u64 *tile_agg;   // [nlists] {points << 32 | occupied cells}: how much of each tile's list is in use
+  const int4 *tile_meta;
+  int nlists, list_stride;
+};
+struct StepArgs {
+  int n_pref_blocks;
+  PrefetchRole pf;
+  int n_tile_blocks, n_split_blocks, emit_nbx;
+  int mix, mix_groups;  // block order: mix_groups groups of {1 binning block, mix-1 emit blocks}, then the rest
+  TileRole t;
+  SplitRole s;
+  EmitArgs e;
+};
+constexpr int kStepWaves = 4;
+constexpr int kStepThreads = kStepWaves * kWave;
+static_assert(kStepWaves == kEmitWaves, "the emit role is k_emit's workgroup");
+
+template <int MODE, int AUX>
+__global__ __launch_bounds__(kStepThreads, PP_EMIT_MINWAVES) void k_step(StepArgs a) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char step_smem[];
+  int id = (int)blockIdx.x;
+  if (id < a.n_pref_blocks) {
+    // prefetch role: stream the previous launch's arrays into the cache hierarchy (values unused)
+    const unsigned worker = (unsigned)id * kStepThreads + threadIdx.x, nworkers = (unsigned)a.n_pref_blocks * kStepThreads;
+    unsigned acc = 0;
+    // the occupied heads of the tiles' descriptor lists: one wave per list
+    for (int t = (int)(worker >> 6); t < a.pf.nlists; t += (int)(nworkers >> 6)) {
+      const unsigned c = (unsigned)(a.pf.tile_agg[t] & 0xFFFFFFFFull);
+      const int4 *lst = a.pf.tile_meta + (int64_t)t * a.pf.list_stride;
+      for (unsigned e = threadIdx.x & 63; e < c; e += kWave) acc ^= (unsigned)lst[e].x;
+    }
+#pragma unroll 1
+    for (int r = 0; r < 6; ++r) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(a.pf.ptr[r]);
+      const unsigned n = a.pf.n16[r];
+      for (unsigned i = worker; i < n; i += 8u * nworkers) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned j = i + (unsigned)u * nworkers;
+          v[u] = j < n ? p[j] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x;
+      }
+    }
+    if (acc == 0x9E3779B9u && a.emit_nbx < 0) a.e.idx_out[0] = (long long)acc;  // never: keeps the loads alive
+    return;
+  }
+  id -= a.n_pref_blocks;
+  // Block order.  Workgroups are dispatched in id order.  The binning roles' (tile, split) are few and
+  // latency-bound, the emit role's many and store-bound: the grid starts with groups of one binning block
+  // and mix-1 emit blocks, so that the stores flow from the first microsecond AND every binning chain starts
+  // early (a chain that starts late is the launch's tail); what is left of either kind follows.
+  {
+    const int nbin = a.n_tile_blocks + a.n_split_blocks;
+    const int head = a.mix_groups * a.mix;
+    if (id < head) {
+      const int grp = id / a.mix, j = id - grp * a.mix;
+      id = j == 0 ? grp : nbin + grp * (a.mix - 1) + (j - 1);
+    } else {
+      const int r = id - head;                    // the rest: remaining binning blocks, then remaining emit blocks
+      const int bin_left = nbin - a.mix_groups;
+      id = r < bin_left ? a.mix_groups + r : nbin + a.mix_groups * (a.mix - 1) + (r - bin_left);
+    }
+  }
+  if (id < a.n_tile_blocks) {
+    const int nt = a.t.g.ntiles;
+    const int b = id / nt, tile = id - b * nt;
+    tile_body<float, kStepWaves>(a.t.np, a.t.g, a.t.ncap, a.t.nchunks_cap, a.t.kslot,
+                                 reinterpret_cast<const float4 *>(a.t.kpts), a.t.mat,
+                                 reinterpret_cast<float4 *>(a.t.sorted_pts), a.t.tile_meta, a.t.tile_agg,
+                                 nullptr, reinterpret_cast<unsigned *>(step_smem), tile, b);
+    return;
+  }
+  id -= a.n_tile_blocks;
+  if (id < a.n_split_blocks) {
+    const int nc = a.s.nchunks;
+    const int b = id / nc, chunk = id - b * nc;
+    split_body<float, kStepWaves>(reinterpret_cast<const float *>(a.s.pts), a.s.sweep_stride, 4, 1, 1, a.s.np,
+                                  a.s.g, a.s.ncap, a.s.nchunks_cap, a.s.kslot,
+                                  reinterpret_cast<float4 *>(a.s.kpts), a.s.mat, step_smem, chunk, b);
+    return;
+  }
+  id -= a.n_split_blocks;
+  const int b = id / a.emit_nbx, bx = id - b * a.emit_nbx;
+  emit_body<float, MODE, AUX>(a.e, reinterpret_cast<WaveLds<float> *>(step_smem), bx, b, a.emit_nbx);
+}
+
 // ------------------------------------------------------------------------- //
 // host side                                                                  //
 // ------------------------------------------------------------------------- //
@@ -1326,7 +1566,7 @@ static unsigned long long modinv(unsigned long long a, unsigned long long m) {
   return (unsigned long long)t;
 }
 
-int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
+int make_grid(const pp_voxel_params_t *prm, GridGeom *g, int step_mode) {
   if (!prm) {
     set_error("voxel params are NULL");
     return PP_ERR_VALUE;
@@ -1371,9 +1611,13 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g) {
   // row-major tiles are strips of the plane and lidar clouds are centre-heavy: finer tiles
   // (at most 2048 slots) bound the crowded ones; scrambled tiles are uniform and fewer, larger
   // ones cost less.  Beyond kMaxTiles of them the tiles grow to their LDS limit either way.
+  // k_step's tile role shares the launch's dynamic LDS with the emit role (27.5 KB per workgroup): tiles of
+  // at most 2048 slots (30.7 KB with 4 waves) keep the emit role at 5 workgroups per CU.  Fewer, fatter
+  // tile workgroups hold fewer of the chip's workgroup slots while they wait out their latency chains:
+  // 123 tiles of 2048 slots beat 245 of 1024 (C2: 13.1 / 33.6 us per step against 14.7 / 36.8, B = 1 / 4).
   const int target_tiles = forced_tiles ? forced_tiles
-                         : prm->order == PP_ORDER_ROW_MAJOR ? kTargetTiles : kTargetTiles / 2;
-  const int soft_cap = prm->order == PP_ORDER_ROW_MAJOR && !forced_tiles ? 2048 : kMaxTileSlots;
+                         : (prm->order == PP_ORDER_ROW_MAJOR && !step_mode) ? kTargetTiles : kTargetTiles / 2;
+  const int soft_cap = ((prm->order == PP_ORDER_ROW_MAJOR && !forced_tiles) || step_mode) ? 2048 : kMaxTileSlots;
   while ((nc + ts - 1) / ts > target_tiles && ts < soft_cap) ts *= 2;
   while ((nc + ts - 1) / ts > kMaxTiles && ts < kMaxTileSlots) ts *= 2;
   const long long nt = (nc + ts - 1) / ts;
@@ -1461,18 +1705,18 @@ struct DeviceGuard {
 // Makes the workspace fit (B, max_points, grid, P); zeroed whenever the layout changed
 // (nothing depends on it: every array is written before it is read within one call).
 int prepare_ws(pp_ctx *ctx, hipStream_t stream, int B, int64_t max_points,
-               const GridGeom &g, int P, int rec_bytes, VoxLayout *out) {
+               const GridGeom &g, int P, int rec_bytes, VoxLayout *out, int slot = 0) {
   VoxLayout l = vox_layout(B, max_points, g, P, rec_bytes);
   const unsigned long long key[6] = {(unsigned long long)B, (unsigned long long)l.ncap,
                                      ((unsigned long long)g.ntiles << 8) | (unsigned)g.tile_shift,
                                      (unsigned long long)P, (unsigned long long)l.bytes,
                                      (unsigned long long)rec_bytes};
   bool grew = false;
-  int rc = ctx->vox_ws.ensure(l.bytes, &grew);
+  int rc = ctx->vox_ws[slot].ensure(l.bytes, &grew);
   if (rc) return rc;
-  if (grew || std::memcmp(key, ctx->vox_layout_key, sizeof key) != 0) {
-    PP_HIP_TRY(hipMemsetAsync(ctx->vox_ws.ptr, 0, ctx->vox_ws.bytes, stream));
-    std::memcpy(ctx->vox_layout_key, key, sizeof key);
+  if (grew || std::memcmp(key, ctx->vox_layout_key[slot], sizeof key) != 0) {
+    PP_HIP_TRY(hipMemsetAsync(ctx->vox_ws[slot].ptr, 0, ctx->vox_ws[slot].bytes, stream));
+    std::memcpy(ctx->vox_layout_key[slot], key, sizeof key);
   }
   *out = l;
   return PP_OK;
@@ -1486,8 +1730,9 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr,
                     float *canvas = nullptr, int canvas_h = 0, int canvas_w = 0,
                     int canvas_nhwc = 0) {
+  constexpr int slot = 0;  // the plain calls' workspace (k_step's batches rotate through the others)
   using Rec = typename Rec4<TIn>::type;
-  char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+  char *ws = static_cast<char *>(ctx->vox_ws[slot].ptr);
   int *kslot = reinterpret_cast<int *>(ws + l.kslot);
   Rec *kpts = reinterpret_cast<Rec *>(ws + l.kpts);
   int2 *mat = reinterpret_cast<int2 *>(ws + l.mat);
@@ -1505,21 +1750,28 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   const int wi = tw == 4 ? 0 : tw == 8 ? 1 : 2;
   const size_t lds_split = split_lds_bytes(g.ntiles);
   const size_t lds_tile = tile_lds_bytes(1 << g.tile_shift, tw);
-  // dynamic LDS beyond 64 KiB needs the attribute; set once per kernel instance and size
+  // Dynamic LDS beyond 64 KiB needs the attribute.  hipFuncSetAttribute acts on the kernel function of
+  // the DEVICE, whatever context asks: every instance is set ONCE per process and device, to its worst
+  // case (the largest tile / the most split bins), so no context can ever lower another one's limit.
   {
-    size_t &armed = ctx->tile_lds_armed[sizeof(TIn) == 8][wi];
-    if (lds_tile > armed) {
+    static std::atomic<unsigned> armed_mask[64];   // per device: bit = [f64 input][k_tile 4/8/16 waves | k_split]
+    const int dev = ctx->device & 63;
+    const unsigned bit_tile = 1u << ((sizeof(TIn) == 8 ? 4 : 0) + wi);
+    const unsigned bit_split = 1u << ((sizeof(TIn) == 8 ? 4 : 0) + 3);
+    if (!(armed_mask[dev].load(std::memory_order_acquire) & bit_tile)) {
       const void *fn = tw == 4 ? reinterpret_cast<const void *>(&k_tile<TIn, 4>)
                      : tw == 8 ? reinterpret_cast<const void *>(&k_tile<TIn, 8>)
                                : reinterpret_cast<const void *>(&k_tile<TIn, 16>);
-      PP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
-      armed = lds_tile;
+      PP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)tile_lds_bytes(kMaxTileSlots, tw)));
+      armed_mask[dev].fetch_or(bit_tile, std::memory_order_release);
     }
-  }
-  if (lds_split > ctx->split_lds_armed[sizeof(TIn) == 8]) {
-    PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split<TIn>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
-    ctx->split_lds_armed[sizeof(TIn) == 8] = lds_split;
+    if (!(armed_mask[dev].load(std::memory_order_acquire) & bit_split)) {
+      PP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split<TIn>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)split_lds_bytes(kMaxTiles)));
+      armed_mask[dev].fetch_or(bit_split, std::memory_order_release);
+    }
   }
   const int nchunks = std::max(1, (maxn + kChunk - 1) / kChunk);
   u64 *stamps = nullptr;
@@ -1539,6 +1791,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
     }
     ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
     ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
+    ctx->ev_columns = 7;  // all three kernels recorded
   }
   hipExtLaunchKernelGGL((k_split<TIn>), dim3((unsigned)nchunks, (unsigned)B), dim3(kSplitThreads),
                         lds_split, stream, ev0[PP_KERNEL_SPLIT], ev1[PP_KERNEL_SPLIT], 0, pts,
@@ -1611,7 +1864,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       // the armed invariant (look-back words zero) can no longer be assumed
-      std::memset(ctx->vox_layout_key, 0, sizeof ctx->vox_layout_key);
+      std::memset(ctx->vox_layout_key[slot], 0, sizeof ctx->vox_layout_key[slot]);
       set_error("voxelizer launch failed: %s", hipGetErrorString(e));
       return PP_ERR_HIP;
     }
@@ -1628,7 +1881,7 @@ using namespace pp;
 // development builds only (tools/lab): k_tile's phase stamps of sweep 0, 8 per wave
 extern "C" int pp_debug_stamps(pp_ctx_t *ctx, unsigned long long *host, int cap) {
   const size_t n = std::min((size_t)cap * 8, ctx->dbg_stamps_bytes);
-  if (hipMemcpy(host, static_cast<char *>(ctx->vox_ws.ptr) + ctx->dbg_stamps_off, n,
+  if (hipMemcpy(host, static_cast<char *>(ctx->vox_ws[0].ptr) + ctx->dbg_stamps_off, n,
                 hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   return (int)(n / 8);
@@ -1645,6 +1898,7 @@ extern "C" int pp_voxelize_check(pp_ctx_t *ctx, void *stream_) {
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) {
     std::memset(ctx->vox_layout_key, 0, sizeof ctx->vox_layout_key);
+    for (auto &sb : ctx->step_batch) sb.valid = false;
     set_error("voxelizer: the stream reports %s", hipGetErrorString(e));
     return PP_ERR_HIP;
   }
@@ -1726,10 +1980,279 @@ extern "C" int pp_voxelize_dev(pp_ctx_t *ctx, void *stream_, const float *points
                               reinterpret_cast<long long *>(indices_dev), nullptr, true);
   if (rc) return rc;
   if (num_cells_dev) {
-    char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+    char *ws = static_cast<char *>(ctx->vox_ws[0].ptr);
     PP_HIP_TRY(hipMemcpyAsync(num_cells_dev, ws + l.totals, (size_t)batch * 8,
                               hipMemcpyDeviceToDevice, stream));
   }
+  return PP_OK;
+}
+
+static int check_dev_args(const char *what, int batch, const pp_voxel_params_t *prm, int64_t points_stride,
+                          const int32_t *n_points, NPoints *np, int *maxn) {
+  if (batch < 1 || batch > PP_MAX_BATCH) {
+    set_error("%s: batch must be in [1,%d], got %d", what, PP_MAX_BATCH, batch);
+    return PP_ERR_VALUE;
+  }
+  const int P = prm->max_pillars, N = prm->max_points_per_pillar;
+  if (P < 1 || N < 1 || N > 65536 || (long long)P * N > 100000000ll) {
+    set_error("%s: need 1 <= max_pillars, 1 <= max_points_per_pillar <= 65536 and P*N <= 1e8 "
+              "(got P=%d N=%d)", what, P, N);
+    return PP_ERR_VALUE;
+  }
+  if (points_stride < 0 || points_stride > INT_MAX / 2) {
+    set_error("%s: points_stride out of range", what);
+    return PP_ERR_VALUE;
+  }
+  std::memset(np, 0, sizeof *np);
+  *maxn = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (n_points[b] < 0 || n_points[b] > points_stride) {
+      set_error("%s: n_points[%d]=%d outside [0, points_stride=%lld]", what, b, n_points[b],
+                (long long)points_stride);
+      return PP_ERR_VALUE;
+    }
+    np->n[b] = n_points[b];
+    *maxn = std::max(*maxn, n_points[b]);
+  }
+  return PP_OK;
+}
+
+/* ---- software-pipelined mode: one k_step launch per call ---- */
+namespace {
+struct SlotArrays {
+  int *kslot;
+  float4 *kpts, *sorted_pts;
+  int2 *mat, *totals;
+  int4 *tile_meta;
+  u64 *tile_agg;
+};
+SlotArrays slot_arrays(pp_ctx *ctx, int slot, const VoxLayout &l) {
+  char *ws = static_cast<char *>(ctx->vox_ws[slot].ptr);
+  SlotArrays a;
+  a.kslot = reinterpret_cast<int *>(ws + l.kslot);
+  a.kpts = reinterpret_cast<float4 *>(ws + l.kpts);
+  a.mat = reinterpret_cast<int2 *>(ws + l.mat);
+  a.sorted_pts = reinterpret_cast<float4 *>(ws + l.sorted_pts);
+  a.tile_meta = reinterpret_cast<int4 *>(ws + l.tile_meta);
+  a.tile_agg = reinterpret_cast<u64 *>(ws + l.tile_agg);
+  a.totals = reinterpret_cast<int2 *>(ws + l.totals);
+  return a;
+}
+int step_geometry(const pp_step_batch &sb, GridGeom *g, VoxLayout *l) {
+  int rc = make_grid(&sb.prm, g, 1);
+  if (rc) return rc;
+  *l = vox_layout(sb.batch, std::max<int64_t>(sb.points_stride, 1), *g, sb.prm.max_pillars, 16);
+  return PP_OK;
+}
+}  // namespace
+
+extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                    int64_t points_stride, const int32_t *n_points, int batch,
+                                    const pp_voxel_params_t *prm, float *pillars_dev,
+                                    int64_t *indices_dev, int32_t *num_cells_dev, int *emitted) {
+  if (emitted) *emitted = 0;
+  if (!ctx) {
+    set_error("ctx is NULL");
+    return PP_ERR_VALUE;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(ctx->device);
+  pp_step_batch &sb_tile = ctx->step_batch[0], &sb_emit = ctx->step_batch[1];
+  if (sb_emit.valid) {
+    if (!pillars_dev || !indices_dev) {
+      set_error("pp_voxelize_step_dev: a batch is due, its output buffers are NULL");
+      return PP_ERR_VALUE;
+    }
+    if ((reinterpret_cast<uintptr_t>(pillars_dev) & 15) || (reinterpret_cast<uintptr_t>(indices_dev) & 7) ||
+        (reinterpret_cast<uintptr_t>(num_cells_dev) & 7)) {
+      set_error("device pointers must be 16-byte (pillars) / 8-byte (indices, num_cells) aligned");
+      return PP_ERR_VALUE;
+    }
+  }
+  StepArgs a;
+  std::memset(&a, 0, sizeof a);
+  size_t lds = 0;
+  int rc;
+  // split role: the new batch
+  pp_step_batch sb_new;
+  if (points_dev) {
+    if (!n_points || !prm) {
+      set_error("pp_voxelize_step_dev: NULL argument");
+      return PP_ERR_VALUE;
+    }
+    if (reinterpret_cast<uintptr_t>(points_dev) & 15) {
+      set_error("device pointers must be 16-byte aligned (points)");
+      return PP_ERR_VALUE;
+    }
+    NPoints np;
+    int maxn = 0;
+    rc = check_dev_args("pp_voxelize_step_dev", batch, prm, points_stride, n_points, &np, &maxn);
+    if (rc) return rc;
+    sb_new.valid = true;
+    sb_new.batch = batch;
+    sb_new.maxn = maxn;
+    std::memcpy(sb_new.n_points, np.n, sizeof sb_new.n_points);
+    sb_new.points_stride = points_stride;
+    sb_new.prm = *prm;
+    sb_new.slot = ctx->step_next_slot;
+    GridGeom g;
+    VoxLayout l;
+    rc = step_geometry(sb_new, &g, &l);
+    if (rc) return rc;
+    // the slot's last batch was emitted by the previous launch: resizing / clearing it is stream-ordered
+    VoxLayout l2;
+    rc = prepare_ws(ctx, stream, batch, std::max<int64_t>(points_stride, 1), g, prm->max_pillars, 16, &l2,
+                    sb_new.slot);
+    if (rc) return rc;
+    const SlotArrays w = slot_arrays(ctx, sb_new.slot, l);
+    a.s.pts = points_dev;
+    a.s.sweep_stride = points_stride;
+    a.s.np = np;
+    a.s.g = g;
+    a.s.ncap = l.ncap;
+    a.s.nchunks_cap = l.nchunks_cap;
+    a.s.nchunks = std::max(1, (maxn + kChunk - 1) / kChunk);
+    a.s.kslot = w.kslot;
+    a.s.kpts = w.kpts;
+    a.s.mat = w.mat;
+    a.n_split_blocks = a.s.nchunks * batch;
+    lds = std::max(lds, split_lds_bytes(g.ntiles));
+  }
+  if (sb_tile.valid) {
+    GridGeom g;
+    VoxLayout l;
+    rc = step_geometry(sb_tile, &g, &l);
+    if (rc) return rc;
+    const SlotArrays w = slot_arrays(ctx, sb_tile.slot, l);
+    std::memcpy(a.t.np.n, sb_tile.n_points, sizeof a.t.np.n);
+    a.t.g = g;
+    a.t.ncap = l.ncap;
+    a.t.nchunks_cap = l.nchunks_cap;
+    a.t.kslot = w.kslot;
+    a.t.kpts = w.kpts;
+    a.t.mat = w.mat;
+    a.t.sorted_pts = w.sorted_pts;
+    a.t.tile_meta = w.tile_meta;
+    a.t.tile_agg = w.tile_agg;
+    a.n_tile_blocks = g.ntiles * sb_tile.batch;
+    lds = std::max(lds, tile_lds_bytes(1 << g.tile_shift, kStepWaves));
+  }
+  int mode = kModeDenseVec4;
+  bool sc1 = false;
+  int n_emit_blocks = 0;
+  if (sb_emit.valid) {
+    GridGeom g;
+    VoxLayout l;
+    rc = step_geometry(sb_emit, &g, &l);
+    if (rc) return rc;
+    const SlotArrays w = slot_arrays(ctx, sb_emit.slot, l);
+    const int P = sb_emit.prm.max_pillars, N = sb_emit.prm.max_points_per_pillar;
+    a.e.g = g;
+    std::memcpy(a.e.np.n, sb_emit.n_points, sizeof a.e.np.n);
+    a.e.P = P;
+    a.e.N = N;
+    a.e.ncap = l.ncap;
+    a.e.tile_meta = w.tile_meta;
+    a.e.tile_agg = w.tile_agg;
+    a.e.totals = num_cells_dev ? reinterpret_cast<int2 *>(num_cells_dev) : w.totals;
+    a.e.sorted_pts = w.sorted_pts;
+    a.e.out = pillars_dev;
+    a.e.idx_out = reinterpret_cast<long long *>(indices_dev);
+    a.emit_nbx = (P + KW * kEmitWaves - 1) / (KW * kEmitWaves);
+    n_emit_blocks = a.emit_nbx * sb_emit.batch;
+    mode = (N % 4 == 0 && N <= 4096) ? kModeDenseVec4 : kModeDenseScalar;
+    static const int forced = [] {  // development knob: PP_EMIT_SC1=0/1
+      const char *e = getenv("PP_EMIT_SC1");
+      return e ? (atoi(e) ? 1 : 0) : -1;
+    }();
+    sc1 = forced >= 0 ? forced == 1 : (size_t)sb_emit.batch * 36u * (size_t)P * (size_t)N <= kSc1MaxBytes;
+    lds = std::max(lds, sizeof(WaveLds<float>) * kEmitWaves);
+  }
+  if (a.emit_nbx == 0) a.emit_nbx = 1;
+  {
+    static const int pref_blocks = [] {  // development knob: PP_STEP_PREFETCH=<workgroups> (0 = off)
+      const char *e = getenv("PP_STEP_PREFETCH");
+      return e ? std::max(0, atoi(e)) : 128;
+    }();
+    int r = 0;
+    auto add = [&](const void *ptr, size_t bytes) {
+      a.pf.ptr[r] = ptr;
+      a.pf.n16[r] = (unsigned)(bytes / 16);
+      ++r;
+    };
+    if (pref_blocks > 0 && sb_emit.valid) {   // what the emit role reads
+      add(a.e.sorted_pts, (size_t)sb_emit.batch * a.e.ncap * 16);
+      a.pf.tile_agg = a.e.tile_agg;
+      a.pf.tile_meta = a.e.tile_meta;
+      a.pf.nlists = sb_emit.batch * a.e.g.ntiles;
+      a.pf.list_stride = 1 << a.e.g.tile_shift;
+    }
+    if (pref_blocks > 0 && sb_tile.valid) {   // what the tile role reads
+      add(a.t.mat, (size_t)sb_tile.batch * a.t.g.ntiles * a.t.nchunks_cap * 8);
+      add(a.t.kslot, (size_t)sb_tile.batch * a.t.ncap * 4);
+      add(a.t.kpts, (size_t)sb_tile.batch * a.t.ncap * 16);
+    }
+    a.n_pref_blocks = r > 0 || a.pf.nlists > 0 ? pref_blocks : 0;
+  }
+  const long long nblocks = (long long)a.n_pref_blocks + a.n_tile_blocks + a.n_split_blocks + n_emit_blocks;
+  {
+    static const int mix_env = [] {  // development knob: PP_STEP_MIX=m (1 = binning blocks first)
+      const char *e = getenv("PP_STEP_MIX");
+      return e ? std::max(1, atoi(e)) : 0;
+    }();
+    const int nbin = a.n_tile_blocks + a.n_split_blocks;
+    a.mix = mix_env ? mix_env : 2;
+    a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit_blocks / (a.mix - 1)) : 0;
+    if (a.mix < 2) a.mix = 2, a.mix_groups = 0;
+  }
+  if (nblocks > 0) {
+    if (nblocks > INT_MAX) {
+      set_error("pp_voxelize_step_dev: grid too large");
+      return PP_ERR_VALUE;
+    }
+    const void *fn = mode == kModeDenseScalar ? reinterpret_cast<const void *>(&k_step<kModeDenseScalar, kAuxPlain>)
+                   : sc1 ? reinterpret_cast<const void *>(&k_step<kModeDenseVec4, kAuxSc1>)
+                         : reinterpret_cast<const void *>(&k_step<kModeDenseVec4, kAuxPlain>);
+    {
+      // dynamic LDS beyond 64 KiB (16.7 M-cell grids) needs the attribute: once per process, device and
+      // instance, at the worst case
+      static std::atomic<unsigned> armed[64];
+      const unsigned bit = mode == kModeDenseScalar ? 1u : sc1 ? 2u : 4u;
+      const int dev = ctx->device & 63;
+      if (!(armed[dev].load(std::memory_order_acquire) & bit)) {
+        const size_t worst = std::max(std::max(tile_lds_bytes(kMaxTileSlots, kStepWaves), split_lds_bytes(kMaxTiles)),
+                                      sizeof(WaveLds<float>) * kEmitWaves);
+        PP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)worst));
+        armed[dev].fetch_or(bit, std::memory_order_release);
+      }
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->ev_slots > 0) {
+      e0 = ctx->ev_start[PP_KERNEL_EMIT][ctx->ev_next];
+      e1 = ctx->ev_stop[PP_KERNEL_EMIT][ctx->ev_next];
+      ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
+      ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
+      ctx->ev_columns = 1 << PP_KERNEL_EMIT;
+    }
+    const dim3 grid((unsigned)nblocks), block(kStepThreads);
+    if (mode == kModeDenseScalar)
+      hipExtLaunchKernelGGL((k_step<kModeDenseScalar, kAuxPlain>), grid, block, lds, stream, e0, e1, 0, a);
+    else if (sc1)
+      hipExtLaunchKernelGGL((k_step<kModeDenseVec4, kAuxSc1>), grid, block, lds, stream, e0, e1, 0, a);
+    else
+      hipExtLaunchKernelGGL((k_step<kModeDenseVec4, kAuxPlain>), grid, block, lds, stream, e0, e1, 0, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      for (auto &sb : ctx->step_batch) sb.valid = false;
+      set_error("voxelizer launch failed: %s", hipGetErrorString(e));
+      return PP_ERR_HIP;
+    }
+  }
+  if (sb_emit.valid && emitted) *emitted = 1;
+  // the batches move on: tiled -> due at the next call, split -> to be tiled, new -> split
+  sb_emit = sb_tile;
+  sb_tile = sb_new;
+  if (sb_new.valid) ctx->step_next_slot = ctx->step_next_slot % 3 + 1;
   return PP_OK;
 }
 
@@ -1807,7 +2330,7 @@ static int voxelize_pfn_impl(pp_ctx_t *ctx, void *stream_, const float *points_d
                               channels_last ? 1 : 0);
   if (rc) return rc;
   if (num_cells_dev) {
-    char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+    char *ws = static_cast<char *>(ctx->vox_ws[0].ptr);
     PP_HIP_TRY(hipMemcpyAsync(num_cells_dev, ws + l.totals, (size_t)batch * 8,
                               hipMemcpyDeviceToDevice, stream));
   }
@@ -1900,7 +2423,7 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   // descriptors back: totals, pillar_meta[P] (pillar order, written by k_emit in compact mode)
   rc = ctx->pin_meta.ensure(256 + (size_t)P * 16);
   if (rc) return rc;
-  char *ws = static_cast<char *>(ctx->vox_ws.ptr);
+  char *ws = static_cast<char *>(ctx->vox_ws[0].ptr);
   char *pm = static_cast<char *>(ctx->pin_meta.ptr);
   PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.totals, 8, hipMemcpyDeviceToHost, stream));
   PP_HIP_TRY(hipMemcpyAsync(pm + 256, ws + l.meta, (size_t)P * 16, hipMemcpyDeviceToHost, stream));

@@ -63,6 +63,17 @@ class PillarPipeline:
         return self.model(pillars, indices)
 
     @torch.no_grad()
+    def forward_pipelined(self, points, n_points=None):
+        """The same forward as a software pipeline over consecutive batches (what the reference's
+        DataLoader prefetch amounts to, train.py:120-121): the voxelizer's ONE launch per call runs the
+        split stage of ``points``, the tile stage of the previous call's batch and the emit stage of the
+        batch before that (``PillarVoxelizer.submit``), and the network runs on that oldest batch.
+        Returns its ``(cls, reg)`` -- or ``None`` for the first two calls.  ``points=None`` drains."""
+        B = self.voxelizer._inflight[1] if getattr(self.voxelizer, "_inflight", None) else None
+        r = self.voxelizer.submit(points, n_points=n_points, out=self._buffers(B) if B else None)
+        return None if r is None else self.model(r[0], r[1])
+
+    @torch.no_grad()
     def forward_fused(self, points, n_points=None):
         """Inference with PPFeatureNet fused into the voxelizer:
         the dense [9,P,N] tensor and the [64,P,N] intermediate never exist.  Needs
@@ -95,10 +106,6 @@ class PillarPipeline:
             self._cbuf = torch.empty((B, 64, H, W), dtype=torch.float32, device=self.device,
                                      memory_format=torch.channels_last)
         return self._cbuf
-
-    def invalidate_fused_params(self):
-        """Kept for callers of the first release: the fused table now follows the weights'
-        versions by itself (PPFeatureNet.fused_table)."""
 
     def upload_ground_truth(self, g):
         """Host box arrays (centers / wlh / yaw / classes, canvas space) -> the device tuple

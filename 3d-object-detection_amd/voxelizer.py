@@ -204,6 +204,73 @@ class PillarVoxelizer:
             raise RuntimeError(f"{what}: the fused feature net skips the zero-padded slots, which a data_mean "
                                "makes non-zero; use the dense path (voxelizer(points) + PPFeatureNet)")
 
+    # -- software-pipelined mode ------------------------------------------------------------
+    def submit(self, points, n_points=None, out=None, return_counts=False):
+        """One step of the three-stage software pipeline (pp_voxelize_step_dev): ONE launch runs
+        the split stage of ``points``, the tile stage of the batch submitted one call ago and the
+        emit stage (the dense store) of the batch submitted TWO calls ago, side by side -- the way
+        the reference's DataLoader workers prepare the next batches while the model runs the
+        current one (train.py:120-121).
+
+        Returns the ``(pillars, indices[, counts])`` of the batch submitted two calls ago
+        (bit-identical to ``__call__`` on that batch), or ``None`` while the pipeline fills.
+        ``points=None`` drains (two such calls flush everything).  ``out`` buffers (optional)
+        receive that older batch.  Everything runs on the current stream."""
+        cfg = self.cfg
+        P, N = cfg.max_pillars, cfg.max_points_per_pillar
+        inflight = getattr(self, "_inflight", None)
+        if inflight is None:
+            inflight = self._inflight = [None, None]       # [split done, tiled]: batch sizes
+        due = inflight[1]
+        pillars = indices = counts = None
+        if due is not None:
+            if out is None:
+                pillars = torch.empty((due, _lib.NUM_FEATURES, P, N), dtype=torch.float32, device=self.device)
+                indices = torch.empty((due, P, 3), dtype=torch.int64, device=self.device)
+            else:
+                pillars, indices = out
+                if (pillars.shape != (due, _lib.NUM_FEATURES, P, N) or pillars.dtype != torch.float32
+                        or indices.shape != (due, P, 3) or indices.dtype != torch.int64
+                        or not pillars.is_contiguous() or not indices.is_contiguous()):
+                    raise ValueError("out buffers have the wrong shape/dtype/layout for the batch that is due")
+            if return_counts:
+                counts = torch.empty((due, 2), dtype=torch.int32, device=self.device)
+        nxt = self._prep(points, n_points) if points is not None else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        emitted = ctypes.c_int(0)
+        vp = ctypes.c_void_p
+        rc = _lib.lib().pp_voxelize_step_dev(
+            self._ctx.handle, vp(stream), vp(nxt[0].data_ptr()) if nxt else None,
+            nxt[2] if nxt else 0, nxt[3] if nxt else None, nxt[1] if nxt else 0, ctypes.byref(self._prm),
+            vp(pillars.data_ptr()) if pillars is not None else None,
+            vp(indices.data_ptr()) if indices is not None else None,
+            vp(counts.data_ptr()) if counts is not None else None, ctypes.byref(emitted))
+        if rc != _lib.PP_OK:
+            self._inflight = [None, None]
+        _lib.check(rc, "pp_voxelize_step_dev")
+        self._inflight = [nxt[1] if nxt else None, inflight[0]]
+        if due is None:
+            return None
+        assert emitted.value == 1
+        if self.data_mean is not None:       # dataset.py:102-105
+            rc = _lib.lib().pp_subtract_mean_dev(
+                self._ctx.handle, vp(stream), vp(pillars.data_ptr()), due,
+                _lib.NUM_FEATURES * P * N, vp(self.data_mean.data_ptr()))
+            _lib.check(rc, "pp_subtract_mean_dev")
+        return (pillars, indices, counts) if return_counts else (pillars, indices)
+
+    def stream(self, batches, n_points=None):
+        """Generator over an iterable of point tensors: yields ``(pillars, indices)`` per batch, in
+        order, from the software pipeline of ``submit``."""
+        for pts in batches:
+            r = self.submit(pts, n_points)
+            if r is not None:
+                yield r
+        for _ in range(2):
+            r = self.submit(None)
+            if r is not None:
+                yield r
+
     def __call__(self, points, n_points=None, out=None, return_counts=False):
         cfg = self.cfg
         points, B, ncap, n_arr = self._prep(points, n_points)

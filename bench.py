@@ -121,39 +121,95 @@ def cpu_baseline(seconds_budget=10.0, workers=4, worker_budget=5.0, c1_budget=5.
 
 
 def kernel_means_us(vox):
-    """mean duration (us) of the voxelizer's three kernels over the calls since set_timing"""
+    """mean duration (us) of the voxelizer's kernels over the calls since set_timing: the three kernels of the
+    plain calls, or k_step alone (recorded in the k_emit column) after pipelined calls"""
     ms = {k: vox.read_kernel_ms(w) for k, w in
           (("k_split", _lib.KERNEL_SPLIT), ("k_tile", _lib.KERNEL_TILE))}
-    ms["k_emit"] = vox.read_kernel_ms(_lib.KERNEL_EMIT)      # last: empties the ring
-    return {k: (float(np.mean(v)) * 1e3 if v else float("nan")) for k, v in ms.items()}, len(ms["k_emit"])
+    emit = vox.read_kernel_ms(_lib.KERNEL_EMIT)      # last: empties the ring
+    if not ms["k_split"]:
+        return {"k_step": float(np.mean(emit)) * 1e3 if emit else float("nan")}, len(emit)
+    ms["k_emit"] = emit
+    return {k: (float(np.mean(v)) * 1e3 if v else float("nan")) for k, v in ms.items()}, len(emit)
 
 
-def roofline_record(kern_us, launches, bytes_per_launch, traffic=None, traffic_source=None):
-    emit_s = kern_us["k_emit"] * 1e-6
+def three_launch_record(kern_us, bytes_per_launch):
     total_s = sum(kern_us.values()) * 1e-6
-    achieved = bytes_per_launch / emit_s / 1e9
-    return {"bound": "hbm", "kernel": "pp::k_emit<float,0>", "achieved": achieved,
-            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-            "traffic": traffic, "traffic_source": traffic_source,
-            "bytes_per_launch": bytes_per_launch, "avg_launch_us": kern_us["k_emit"],
-            "launches_timed": launches,
-            "pipeline": {"kernels_us": kern_us, "sum_us": total_s * 1e6,
-                         "achieved": bytes_per_launch / total_s / 1e9,
-                         "what": "the same algorithmic bytes over the SUM of the three kernels of one "
-                                 "voxelizer call (k_split, k_tile: binning, no output bytes; k_emit: the "
-                                 "dense store)"},
-            "pipeline_frac": bytes_per_launch / total_s / HBM_PEAK}
+    return {"kernels_us": kern_us, "sum_us": total_s * 1e6,
+            "pipeline_frac": bytes_per_launch / total_s / HBM_PEAK,
+            "k_emit_frac": bytes_per_launch / (kern_us["k_emit"] * 1e-6) / HBM_PEAK,
+            "what": "pp_voxelize_dev: k_split, k_tile, k_emit as three dependent launches of ONE batch; "
+                    "pipeline_frac = the same algorithmic bytes over the SUM of the three"}
 
 
-def voxelizer_wall(vox, points, out, iters=200, warm=20):
+def roofline_record(kern_us, launches, bytes_per_launch, traffic=None, traffic_source=None, three=None):
+    """the dominant hand-written kernel against the HBM roofline.  Pipelined calls: ONE kernel, k_step, does a
+    batch's worth of all three stages per launch, so its fraction IS the whole voxelizer's.  Plain calls:
+    k_emit (the dense store), with the sum of the three kernels beside it."""
+    if "k_step" in kern_us:
+        dur_us, name = kern_us["k_step"], ("pp::k_step<0,16> (one launch = the split stage of batch i, the tile "
+                                           "stage of batch i-1 and the emit stage of batch i-2: one batch's worth "
+                                           "of every voxelizer stage)")
+    else:
+        dur_us, name = kern_us["k_emit"], "pp::k_emit<float,0>"
+    achieved = bytes_per_launch / (dur_us * 1e-6) / 1e9
+    rec = {"bound": "hbm", "kernel": name, "achieved": achieved,
+           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+           "traffic": traffic, "traffic_source": traffic_source,
+           "bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_us, "launches_timed": launches}
+    if "k_step" in kern_us:
+        rec["pipeline_frac"] = rec["frac"]       # the kernel is the whole voxelizer
+        if three is not None:
+            rec["three_launch"] = three
+    else:
+        t = three_launch_record(kern_us, bytes_per_launch)
+        rec["pipeline"] = {"kernels_us": kern_us, "sum_us": t["sum_us"],
+                           "achieved": bytes_per_launch / (t["sum_us"] * 1e-6) / 1e9, "what": t["what"]}
+        rec["pipeline_frac"] = t["pipeline_frac"]
+    return rec
+
+
+def vox_measure(vox, points, out, pipelined, iters=200, warm=20, kernel_iters=64):
+    """(seconds per call, kernel means in us, launches timed): wall time with event timing OFF (the event pairs
+    cost launch time), the kernels' durations in a pass of their own"""
+    def call():
+        return vox.submit(points, out=out) if pipelined else vox(points, out=out)
+
+    def drain():
+        if pipelined:
+            vox.submit(None, out=out)
+            vox.submit(None, out=out)
     for _ in range(warm):
-        vox(points, out=out)
+        call()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(iters):
-        vox(points, out=out)
+        call()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t1) / iters
+    dt = (time.perf_counter() - t1) / iters
+    for _ in range(4):
+        call()
+    torch.cuda.synchronize()
+    vox.set_timing(kernel_iters)
+    for _ in range(kernel_iters):
+        call()
+    torch.cuda.synchronize()
+    kern_us, n = kernel_means_us(vox)
+    vox.set_timing(0)
+    drain()
+    torch.cuda.synchronize()
+    return dt, kern_us, n
+
+
+def vox_both(vox, points, out, bytes_per_launch, iters=200, kernel_iters=64):
+    """one voxelizer configuration both ways: software-pipelined (k_step) and as three launches"""
+    dt_p, k_p, _ = vox_measure(vox, points, out, True, iters=iters, kernel_iters=kernel_iters)
+    dt_3, k_3, _ = vox_measure(vox, points, out, False, iters=iters, kernel_iters=kernel_iters)
+    B = points.shape[0]
+    return {"sweeps_per_s": B / dt_p, "us_per_step": dt_p * 1e6,
+            "pipeline_GBps": bytes_per_launch / dt_p / 1e9, "wall_frac": bytes_per_launch / dt_p / HBM_PEAK,
+            "k_step_us": k_p["k_step"], "kernel_frac": bytes_per_launch / (k_p["k_step"] * 1e-6) / HBM_PEAK,
+            "three_launch": dict(three_launch_record(k_3, bytes_per_launch), sweeps_per_s=B / dt_3,
+                                 us_per_step=dt_3 * 1e6, wall_frac=bytes_per_launch / dt_3 / HBM_PEAK)}
 
 
 def static_traffic(key):
@@ -194,6 +250,9 @@ def main():
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
                     help="fwd: BASELINE metric (configs[1]); train: the headline itself becomes "
                          "configs[2] (HIP target assignment, loss forward/backward, all-reduces)")
+    ap.add_argument("--three-launch", action="store_true",
+                    help="fwd mode: time the headline with the voxelizer as three dependent launches per step "
+                         "(pp_voxelize_dev) instead of the software-pipelined k_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-feature-net side measurement")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the train_c3 sub-record")
@@ -248,42 +307,64 @@ def main():
         shard.allreduce_gradients(ctx, p_.model.parameters())     # DataParallel's gradient reduction
         return shard.reduce_loss_scalars(ctx, *losses, n_local=a.batch, device=dev)
 
+    pipelined = a.mode == "fwd" and not a.three_launch
+
     def step():
         if a.mode == "fwd":
-            return pipe.forward(points)
+            # software pipeline over consecutive steps (the reference's DataLoader prefetch, train.py:120-121):
+            # ONE voxelizer launch = split(batch i) | tile(batch i-1) | emit(batch i-2); the network runs on
+            # batch i-2.  Every step does one batch's worth of every stage.
+            return pipe.forward_pipelined(points) if pipelined else pipe.forward(points)
         return train_step(pipe, gts)
 
-    for _ in range(a.warmup):
+    def timed_loop(fn, steps):
+        torch.cuda.synchronize()
+        shard.barrier(ctx)
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        shard.barrier(ctx)
+        torch.cuda.synchronize()
+        return shard.max_over_ranks(ctx, time.perf_counter() - t_, device=dev)
+
+    for _ in range(max(a.warmup, 2 if pipelined else 0)):   # (the first two pipelined calls only fill the pipeline)
         step()
     pipe.voxelizer.set_timing(min(a.steps, 4096))
-    torch.cuda.synchronize()
-    shard.barrier(ctx)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    shard.barrier(ctx)
-    torch.cuda.synchronize()
-    elapsed = shard.max_over_ranks(ctx, time.perf_counter() - t0, device=dev)
+    elapsed = timed_loop(step, a.steps)
     kern_us, launches = kernel_means_us(pipe.voxelizer)
     pipe.voxelizer.set_timing(0)
+    bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
+    three_e2e = None
+    if pipelined:
+        pipe.forward_pipelined(None), pipe.forward_pipelined(None)      # drain
+        # the same forward with the voxelizer as three dependent launches per step, for comparison
+        for _ in range(3):
+            pipe.forward(points)
+        pipe.voxelizer.set_timing(min(a.steps, 4096))
+        el3 = timed_loop(lambda: pipe.forward(points), a.steps)
+        k3, _ = kernel_means_us(pipe.voxelizer)
+        pipe.voxelizer.set_timing(0)
+        three_e2e = dict(three_launch_record(k3, bytes_per_launch), ms_per_step=el3 / a.steps * 1e3,
+                         sweeps_per_s=a.steps * a.batch * ctx.world_size / el3)
 
-    # voxelizer alone (same resident inputs), for the per-stage picture: wall time per call,
-    # in the default order and in the row-major one
-    vox_dt = voxelizer_wall(pipe.voxelizer, points, pipe._buffers(a.batch))
+    # voxelizer alone (same resident inputs), for the per-stage picture: wall time per call (event timing off)
+    # and kernel durations, software-pipelined and as three launches; default order and the row-major one; ONE
+    # sweep per launch (BASELINE configs[3]'s per-GPU shape); BASELINE configs[0]'s 100x100 grid
+    vox_rec = vox_both(pipe.voxelizer, points, pipe._buffers(a.batch), bytes_per_launch)
     vox_rm = PillarVoxelizer(VoxelConfig.square(HALF, STEP, P, N, order=_lib.ORDER_ROW_MAJOR), device=dev)
-    vox_rm.set_timing(64)
-    vox_rm_dt = voxelizer_wall(vox_rm, points, pipe._buffers(a.batch), iters=64, warm=10)
-    rm_us, _ = kernel_means_us(vox_rm)
-    vox_rm.set_timing(0)
+    vox_rec["row_major_order"] = vox_both(vox_rm, points, pipe._buffers(a.batch), bytes_per_launch, iters=100)
     del vox_rm
-    # ... and at ONE sweep per launch: BASELINE configs[3]'s shape (one sweep per GPU), the short launch
-    vox1_dt = voxelizer_wall(pipe.voxelizer, points[:1], pipe._buffers(1), iters=200, warm=10)
-    pipe.voxelizer.set_timing(64)                    # the kernels, in a pass of their own
-    voxelizer_wall(pipe.voxelizer, points[:1], pipe._buffers(1), iters=64, warm=0)
-    one_us, _ = kernel_means_us(pipe.voxelizer)
-    pipe.voxelizer.set_timing(0)
+    vox_rec["one_sweep_per_launch"] = vox_both(pipe.voxelizer, points[:1], pipe._buffers(1),
+                                               bytes_per_launch // a.batch)
+    c1cfg = VoxelConfig.square(C1["half"], C1["step"], C1["P"], C1["N"])
+    vox_c1 = PillarVoxelizer(c1cfg, device=dev)
+    vox_rec["c1_shapes"] = dict(
+        vox_both(vox_c1, points, pipe._buffers(a.batch), c1cfg.algorithmic_bytes(C1["n"]) * a.batch, iters=100),
+        what="BASELINE configs[0]'s shapes on the GPU: the same clouds on the 100x100 grid (1 m cells, up to "
+             "~380 points in a cell: long sequential running-mean chains, pillars.cpp:311-328)")
+    del vox_c1
 
     # next row: the feature net fused into the voxelizer -- the dense
     # [9,P,N] tensor is never built.  Reported beside the headline, not as it.
@@ -304,6 +385,40 @@ def main():
                  "what": "same forward with PPFeatureNet (conv1x1+ReLU+BN(eval)+max) and PPScatter fused into "
                          "the HIP voxelizer (pp_voxelize_pfn_canvas_dev, channels-last canvas); outputs equal "
                          "the headline path's within 1e-4"}
+        # ... and the fused voxelizer call by itself against ITS bytes: points in, one 256-byte feature pixel
+        # per pillar, the indices, and the canvas clear (the dense [9,P,N] tensor does not exist here)
+        pfn_tab = pipe.model.feature_net.fused_table(dev)
+        H_, W_ = pipe.model.scatter.h, pipe.model.scatter.w
+        f_out = (pipe._canvas(a.batch, H_, W_), pipe._fbufs[1])
+
+        def fused_call():
+            pipe.voxelizer.pfn_canvas(points, pfn_tab, (H_, W_), out=f_out)
+        for _ in range(10):
+            fused_call()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(100):
+            fused_call()
+        torch.cuda.synchronize()
+        f_dt = (time.perf_counter() - t2) / 100
+        pipe.voxelizer.set_timing(64)
+        for _ in range(64):
+            fused_call()
+        torch.cuda.synchronize()
+        f_k, _ = kernel_means_us(pipe.voxelizer)
+        pipe.voxelizer.set_timing(0)
+        f_live = 16 * N_POINTS + 256 * P + 24 * P                      # per sweep, without the clear
+        f_clear = 64 * H_ * W_ * 4
+        fused["roofline"] = {
+            "bound": "hbm by its bytes; measured: latency-bound",
+            "kernel": "pp::k_emit<float,3,0> (+ k_split, k_tile, the canvas clear)",
+            "bytes_per_launch": (f_live + f_clear) * a.batch,
+            "bytes_what": "per sweep 16*n + 256*P (one channels-last feature pixel per pillar) + 24*P (indices) + "
+                          "the canvas clear 64*H*W*4",
+            "us_per_call": f_dt * 1e6, "kernels_us": f_k, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "achieved": (f_live + f_clear) * a.batch / f_dt / 1e9,
+            "frac": (f_live + f_clear) * a.batch / f_dt / HBM_PEAK,
+            "k_emit_frac_of_its_own_bytes": f_live * a.batch / (f_k["k_emit"] * 1e-6) / HBM_PEAK}
 
     # BASELINE configs[2] (and configs[3]'s collectives when N > 1): target assignment + loss
     # forward/backward + the gradient and loss-scalar all-reduces, every rank, timed like the headline
@@ -357,7 +472,8 @@ def main():
         del tp, tg
         torch.cuda.empty_cache()
 
-    # BASELINE configs[4] shapes (stress): voxelizer only, one GPU's share
+    # BASELINE configs[4] shapes (stress): voxelizer only, one GPU's share -- B sweeps per launch and the
+    # configs[4] per-GPU shape (ONE 200k-point sweep per launch), both ways
     stress = None
     if not a.no_stress and ctx.world_size == 1:
         c5 = VoxelConfig.square(C5["half"], C5["step"], C5["P"], C5["N"])
@@ -365,23 +481,62 @@ def main():
         pts5 = torch.from_numpy(np.stack([synth.lidar_like(C5["n"], C5["half"], s) for s in sweep_ids])).to(dev)
         out5 = (torch.empty((a.batch, 9, C5["P"], C5["N"]), dtype=torch.float32, device=dev),
                 torch.empty((a.batch, C5["P"], 3), dtype=torch.int64, device=dev))
-        v5.set_timing(100)
-        dt5 = voxelizer_wall(v5, pts5, out5, iters=100, warm=10)
-        k5, n5 = kernel_means_us(v5)
-        v5.set_timing(0)
         b5 = c5.algorithmic_bytes(C5["n"]) * a.batch
+        r5 = vox_both(v5, pts5, out5, b5, iters=100)
+        dt3, k3 = r5["three_launch"]["us_per_step"] * 1e-6, r5["three_launch"]["kernels_us"]
+        best = min(dt3, r5["us_per_step"] * 1e-6)
         stress = {"workload": f"configs[4] shapes on one GPU: {a.batch} x {C5['n']}-pt clouds, 1000x1000 grid, "
                               f"P={C5['P']} N={C5['N']}, voxelizer only",
-                  "sweeps_per_s": a.batch / dt5, "us_per_step": dt5 * 1e6,
-                  "wall_frac": b5 / dt5 / HBM_PEAK,
-                  "roofline": roofline_record(k5, n5, b5, *static_traffic(f"c5_batch{a.batch}"))}
+                  # beyond the Infinity Cache the three-launch path can be the faster one at this batch (the
+                  # binning stages are issue-bound at 800k points and k_step's roles share the workgroup slots)
+                  "sweeps_per_s": a.batch / best, "us_per_step": best * 1e6, "wall_frac": b5 / best / HBM_PEAK,
+                  "roofline": roofline_record(k3, 64, b5, *static_traffic(f"c5_batch{a.batch}")),
+                  "pipelined": {k: r5[k] for k in ("sweeps_per_s", "us_per_step", "wall_frac", "k_step_us",
+                                                   "kernel_frac")},
+                  "three_launch_us_per_step": dt3 * 1e6,
+                  "one_sweep_per_launch": vox_both(v5, pts5[:1], (out5[0][:1], out5[1][:1]), b5 // a.batch,
+                                                   iters=100)}
         del v5, pts5, out5
+        torch.cuda.empty_cache()
+
+    # the reference's SHIPPED configuration (config.py:46-61,109-123): 600x600 grid, P=24000, N=200 (every
+    # bucket cap above the 128-point LDS pool, 172.8 MB per sweep), 6 anchors per cell = 540 000 anchors
+    refdef = None
+    if not a.no_stress and ctx.world_size == 1:
+        from pp_amd import boxes
+        from pp_amd.targets import TargetAssigner
+        rc_ = VoxelConfig.reference_default()
+        vr = PillarVoxelizer(rc_, device=dev)
+        ptsr = torch.from_numpy(np.stack([synth.lidar_like(N_POINTS, 60.0, s) for s in sweep_ids])).to(dev)
+        outr = (torch.empty((a.batch, 9, rc_.max_pillars, rc_.max_points_per_pillar), dtype=torch.float32, device=dev),
+                torch.empty((a.batch, rc_.max_pillars, 3), dtype=torch.int64, device=dev))
+        br = rc_.algorithmic_bytes(N_POINTS) * a.batch
+        refdef = {"workload": f"config.py defaults: {a.batch} x {N_POINTS}-pt clouds, 600x600 grid, P=24000 N=200, "
+                              "voxelizer only; target assignment at 300x300x6 = 540000 anchors, G=40",
+                  "voxelizer": vox_both(vr, ptsr, outr, br, iters=60),
+                  "one_sweep_per_launch": vox_both(vr, ptsr[:1], (outr[0][:1], outr[1][:1]), br // a.batch, iters=100)}
+        del vr, ptsr, outr
+        torch.cuda.empty_cache()
+        ta = TargetAssigner(boxes.AnchorConfig.reference_default(), canvas_height=600, device=dev)
+        gr = synth.gt_boxes(40, 600, 0)
+        g_ = ta._gt_to_device(gr["centers"], gr["wlh"], gr["yaw"], gr["classes"])
+        for _ in range(10):
+            ta.assign_device(*g_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            ta.assign_device(*g_)
+        e1.record()
+        torch.cuda.synchronize()
+        t_us = e0.elapsed_time(e1) * 1e3 / 100
+        refdef["target_assign_us"] = t_us
+        refdef["target_assign_frac"] = 112 * ta.A / (t_us * 1e-6) / HBM_PEAK
+        del ta
         torch.cuda.empty_cache()
 
     if ctx.rank == 0:
         total_sweeps = a.steps * a.batch * ctx.world_size
-        bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
-        traffic, tsrc = static_traffic(f"batch{a.batch}")
+        traffic, tsrc = static_traffic(f"step_batch{a.batch}" if pipelined else f"batch{a.batch}")
         out = {
             "metric": METRIC, "value": total_sweeps / elapsed, "unit": "sweeps/s",
             "n_gpus": ctx.world_size, "steps": a.steps, "warmup": a.warmup,
@@ -401,27 +556,23 @@ def main():
                             "world_size": torch.distributed.get_world_size() if ctx.distributed else 1,
                             "in_timed_step": "none (sweeps shard; no data-path collective)" if a.mode == "fwd"
                             else "positive-count, gradient and loss-scalar all-reduces"},
-            "roofline": roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc),
-            "voxelizer_only": {"sweeps_per_s": a.batch / vox_dt, "us_per_step": vox_dt * 1e6,
-                               "pipeline_GBps": bytes_per_launch / vox_dt / 1e9,
-                               "wall_frac": bytes_per_launch / vox_dt / HBM_PEAK,
-                               "row_major_order": {"sweeps_per_s": a.batch / vox_rm_dt,
-                                                   "us_per_step": vox_rm_dt * 1e6,
-                                                   "wall_frac": bytes_per_launch / vox_rm_dt / HBM_PEAK,
-                                                   "kernels_us": rm_us},
-                               "one_sweep_per_launch": {"sweeps_per_s": 1.0 / vox1_dt, "us_per_step": vox1_dt * 1e6,
-                                                        "wall_frac": bytes_per_launch / a.batch / vox1_dt / HBM_PEAK,
-                                                        "kernels_us": one_us,
-                                                        "pipeline_frac": bytes_per_launch / a.batch
-                                                        / (sum(one_us.values()) * 1e-6) / HBM_PEAK
-                                                        if one_us else None}},
+            "roofline": roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc, three=three_e2e),
+            "voxelizer_only": vox_rec,
         }
+        out["config"]["voxelizer"] = (
+            "software-pipelined over consecutive steps: ONE launch per step (k_step) runs the split stage of "
+            "batch i, the tile stage of batch i-1 and the emit stage of batch i-2 side by side; the network "
+            "consumes batch i-2 (PillarPipeline.forward_pipelined).  Every step does one batch's worth of every "
+            "stage; `roofline.three_launch` is the same forward with three dependent launches per step"
+            if pipelined else "three dependent launches per step (pp_voxelize_dev: k_split, k_tile, k_emit)")
         if fused is not None:
             out["fused_feature_net"] = fused
         if train is not None:
             out["train_c3"] = train
         if stress is not None:
             out["stress_c5"] = stress
+        if refdef is not None:
+            out["reference_default"] = refdef
         if not a.no_cpu_baseline and ctx.world_size == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

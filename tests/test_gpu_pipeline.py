@@ -62,7 +62,8 @@ def test_train_step_runs_and_is_finite(gpu):
 
 def test_bench_contract_line(gpu):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-cpu-baseline", "--no-stress", "--no-train-leg"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
@@ -70,7 +71,18 @@ def test_bench_contract_line(gpu):
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 0 and j["vs_baseline"] is None
-    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1
+    # the headline's voxelizer is the software-pipelined one: ONE kernel (k_step) whose fraction is the whole
+    # voxelizer's; the three-launch path is measured beside it
+    assert rf["kernel"].startswith("pp::k_step") and rf["pipeline_frac"] == rf["frac"]
+    assert set(rf["three_launch"]["kernels_us"]) == {"k_split", "k_tile", "k_emit"}
+    assert 0 < rf["three_launch"]["pipeline_frac"] < rf["three_launch"]["k_emit_frac"] < 1
+    vo = j["voxelizer_only"]
+    for rec in (vo, vo["row_major_order"], vo["one_sweep_per_launch"], vo["c1_shapes"]):
+        assert 0 < rec["wall_frac"] < 1 and rec["k_step_us"] > 0 and 0 < rec["three_launch"]["wall_frac"] < 1
+    fr = j["fused_feature_net"]["roofline"]
+    assert fr["bytes_per_launch"] > 0 and 0 < fr["frac"] < 1 and set(fr["kernels_us"]) == {"k_split", "k_tile", "k_emit"}
 
 
 def test_fused_epilogue_equals_relu_batchnorm(gpu):

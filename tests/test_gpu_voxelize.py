@@ -393,3 +393,66 @@ def test_largest_grids(gpu, oracle, order):
     too_big = PillarVoxelizer(VoxelConfig.square(450.0, 0.2, 100, 4, order=order), device=gpu)   # 4501^2 > 2^24
     with pytest.raises(ValueError, match="too large"):
         too_big(torch.from_numpy(pts[:100]).to(gpu))
+
+
+def test_pipelined_mode_equals_plain_calls(gpu, oracle):
+    """PillarVoxelizer.submit / pp_voxelize_step_dev (ONE launch per call: the split stage of batch i, the
+    tile stage of batch i-1 and the emit stage of batch i-2 as roles of one grid): a sequence of DIFFERENT
+    batches -- changing batch size, ragged row counts, an empty sweep -- comes out in order and bit-identical
+    to plain calls on another context; the first batch also against the oracle.  Plain calls on the same
+    context in between do not disturb the batches in flight."""
+    import torch
+    from pp_amd import synth
+    half, step, P, N = 25.0, 0.25, 3000, 24
+    vp, vs = _vox(gpu, half, step, P, N, order=1), _vox(gpu, half, step, P, N, order=1)
+    seq = []
+    for i, (B, n) in enumerate([(2, 9000), (1, 20000), (4, 5000), (2, 9000), (3, 12000), (1, 300)]):
+        pts = np.stack([synth.lidar_like(n, half, 50 + 7 * i + s) for s in range(B)])
+        npts = [n - 37 * s for s in range(B)]
+        if i == 2:
+            npts[1] = 0
+        seq.append((torch.from_numpy(pts).to(gpu), npts))
+    plain = []
+    for t, npts in seq:
+        p, ix, c = vp(t, n_points=npts, return_counts=True)
+        plain.append((p.clone(), ix.clone(), c.clone()))
+    got = []
+    for rep in range(2):                      # twice: the slots are reused with stale contents
+        got = []
+        for k, (t, npts) in enumerate(seq):
+            r = vs.submit(t, n_points=npts, return_counts=True)
+            assert (r is None) == (k < 2)
+            if r is not None:
+                got.append(r)
+            if k == 3:                        # a plain call on the context with batches in flight
+                assert torch.equal(vs(seq[1][0], n_points=seq[1][1])[0], plain[1][0])
+        got.append(vs.submit(None, return_counts=True))
+        got.append(vs.submit(None, return_counts=True))
+        assert vs.submit(None) is None        # drained
+        torch.cuda.synchronize()
+        assert len(got) == len(seq)
+        for (p, ix, c), (q, jx, d) in zip(plain, got):
+            assert torch.equal(p, q) and torch.equal(ix, jx) and torch.equal(c, d)
+    ref_p, ref_i, m = oracle_stage(oracle, seq[0][0][0, :seq[0][1][0]].cpu().numpy(), P, N, half, step, order=1)
+    assert np.array_equal(got[0][0][0].cpu().numpy(), ref_p) and np.array_equal(got[0][1][0].cpu().numpy(), ref_i)
+    # the generator form
+    outs = list(vs.stream([t for t, _ in seq[:4]]))
+    torch.cuda.synchronize()
+    assert len(outs) == 4 and all(torch.equal(o[0], vp(t)[0]) for o, (t, _) in zip(outs, seq[:4]))
+
+
+@pytest.mark.parametrize("order", [0, 1], ids=["row_major", "scrambled"])
+@pytest.mark.parametrize("cfg", [C2, C5, C1], ids=["config2", "config5", "config1"])
+def test_pipelined_mode_full_size(gpu, cfg, order):
+    """k_step at BASELINE's sizes (and configs[0]'s crowded cells): bit-identical to the three-kernel path,
+    odd N (scalar store mode) included."""
+    import torch
+    from pp_amd import synth
+    for N in (cfg["N"], 37):
+        a, b = _vox(gpu, cfg["half"], cfg["step"], cfg["P"], N, order), _vox(gpu, cfg["half"], cfg["step"], cfg["P"], N, order)
+        ts = [torch.from_numpy(np.stack([synth.lidar_like(cfg["n"], cfg["half"], 10 * i + s) for s in range(2)])).to(gpu)
+              for i in range(3)]
+        outs = list(b.stream(ts))
+        for t, o in zip(ts, outs):
+            p, ix = a(t)
+            assert torch.equal(p, o[0]) and torch.equal(ix, o[1])
