@@ -1,9 +1,13 @@
 """GPU tests of the host drop-in module (the reference's pybind11 surface,
 data/pillars.cpp:429-435) through pp_create_pillars_f64 / pp_make_ious_f64."""
+import os
+
 import numpy as np
 import pytest
 
 from util import grid_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -186,3 +190,68 @@ def test_import_as_data_pillars_in_the_reference_layout(gpu, tmp_path):
     r = subprocess.run([sys.executable, "-c", _DATA_PILLARS_CHILD, str(tmp_path)], cwd=str(tmp_path),
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "data.pillars ok" in r.stdout, r.stderr[-2000:]
+
+
+_WORKER = r"""
+import sys, time
+import numpy as np
+root, repo, wid, iters = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+sys.path.insert(0, root)                       # the reference checkout's layout: data/pillars*.so
+import data.pillars as pillars                 # data/dataset.py:6 -- lazily creates THIS process's context
+assert pillars.__file__.startswith(root)
+sys.path.insert(1, repo)                       # the checker (CPU oracle) comes from the repo
+import pp_amd                                  # noqa: F401  (registers the package alias the oracle imports)
+from pp_amd import boxes, synth
+from oracle import oracle as O
+half, step, P, N = 30.0, 0.25, 9000, 40
+H = int(2 * half / step)
+anchors = boxes.make_anchors(boxes.AnchorConfig(30, 30))
+for it in range(iters):
+    seed = 1000 * wid + it
+    pts = synth.lidar_like(20000 + 500 * wid, half, seed).astype(np.float64)
+    T, I = np.zeros((P, N, 9)), np.zeros((P, 3))                                  # dataset.py:89-90
+    pillars.create_pillars(np.asfortranarray(pts), T, I, N, P, step, step, -half, -half, -10, half, half, 10, H)
+    rT, rI = np.zeros((P, N, 9)), np.zeros((P, 3))
+    O.create_pillars(pts, rT, rI, N, P, step, step, -half, -half, -10.0, half, half, 10.0, H, order=1)
+    assert np.array_equal(I, rI) and np.array_equal(T, rT), (wid, it)
+    gt = synth.gt_boxes(8, 60, seed, margin=8.0)
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 60)
+    ious, ref = np.zeros((len(anchors["corners"]), 8)), np.zeros((len(anchors["corners"]), 8))
+    pillars.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious)  # box_utils.py:182
+    O.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ref)
+    assert np.array_equal(ious, ref), (wid, it)
+print("worker", wid, "ok", iters)
+"""
+
+
+def test_concurrent_worker_processes_share_one_device(gpu, tmp_path):
+    """The reference calls the module from DataLoader(num_workers=4) worker processes (train.py:120-121,
+    data/dataset.py:92-97).  Here: three FRESH processes (spawned, never forked from a GPU-initialised one),
+    each importing ``data.pillars`` from the reference-layout scratch directory, creating its own lazy
+    context and looping create_pillars + make_ious on the SAME device at the same time; every result is
+    checked against the CPU oracle inside the worker.  A worker started without a visible device fails
+    loudly (no CPU fallback)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    import pp_amd
+    from oracle import oracle as O
+    assert hasattr(O, "create_pillars")
+    mod = pp_amd._lib.build_pybind_module()
+    data = tmp_path / "data"
+    data.mkdir()
+    (data / "__init__.py").write_text("")
+    shutil.copy(mod, data / os.path.basename(mod))
+    shutil.copy(pp_amd._lib.LIB_PATH, data / "libpp_hip.so")
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "PP_HIP_LIB", "LD_LIBRARY_PATH")}
+    procs = [subprocess.Popen([sys.executable, "-c", _WORKER, str(tmp_path), ROOT, str(w), "12"], cwd=str(tmp_path),
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(3)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for w, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"worker {w} ok 12" in so, se[-2000:]
+    # no device visible: the first call raises, naming the missing device and the absent fallback
+    env_nodev = dict(env, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-c", _WORKER, str(tmp_path), ROOT, "9", "1"], cwd=str(tmp_path),
+                       env=env_nodev, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr, r.stderr[-1500:]

@@ -68,6 +68,28 @@ def test_reference_default_anchor_set_sampled(gpu, oracle):
     _check(cls_t, reg_t, ref_c, ref_r)
 
 
+@pytest.mark.parametrize("source", ["arrays", "grid"])
+def test_reference_default_anchor_set_full_size(gpu, oracle, source):
+    """config.py:55-59,109-116 exactly: 300x300 feature map x 6 anchors = 540 000 anchors on the 600x600
+    canvas, G = 40 boxes of all three size groups; uploaded anchor arrays and the on-the-fly grid, against
+    the oracle's full [A,G] evaluation."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    cfg = boxes.AnchorConfig.reference_default()
+    anchors = boxes.make_anchors(cfg)
+    assert len(anchors["corners"]) == 540000
+    ta = TargetAssigner(anchors if source == "arrays" else cfg, canvas_height=600, device=gpu)
+    gt = synth.gt_boxes(40, 600, 3, margin=60.0)
+    gt["wlh"][::3, :2] = boxes.SMALL[:2] * 1.05          # small and large boxes too
+    gt["wlh"][1::3, :2] = boxes.LARGE[:2] * 0.95
+    cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+    torch.cuda.synchronize()
+    ref_c, ref_r, ious = _oracle_targets(oracle, anchors, gt, 600)
+    assert (ref_r[:, 0] == 1).sum() >= 40 and (ious > 0).sum() > 1000
+    _check(cls_t, reg_t, ref_c, ref_r)
+
+
 def test_quirks_anchor0_duplicates_ties_threshold(gpu, oracle):
     """a ground truth whose best anchor is index 0 is dropped; two
     ground truths sharing one best anchor set both classes, last regression row

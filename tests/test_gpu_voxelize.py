@@ -7,7 +7,7 @@ the oracle, one final f32 rounding), so most cases also assert bit equality.
 import numpy as np
 import pytest
 
-from util import C1, C2, C5, grid_args, oracle_stage, pillars_by_cell
+from util import C1, C2, C5, REFDEF, grid_args, oracle_stage, pillars_by_cell
 
 pytestmark = pytest.mark.gpu
 
@@ -175,11 +175,13 @@ def test_batch_ragged_and_rerun_identical(gpu, oracle):
 
 
 @pytest.mark.parametrize("order", [0, 1], ids=["row_major", "scrambled"])
-@pytest.mark.parametrize("cfg", [C2, C5], ids=["config2", "config5"])
+@pytest.mark.parametrize("cfg", [C2, C5, REFDEF], ids=["config2", "config5", "reference_default"])
 def test_full_size_configs(gpu, oracle, cfg, order):
-    """BASELINE configs 2 and 5 at full size, both pillar orders (scrambled is the default and
-    what bench.py runs): oracle comparison plus the size-independent properties (exactly
-    min(cells,P) rows, counts per cell, sortedness of the order, points conserved)."""
+    """BASELINE configs 2 and 5 and the reference's SHIPPED configuration (config.py:46-61,119-120: 600x600
+    grid, P = 24000, N = 200 -- every bucket cap above the 128-point LDS pool, 172.8 MB per sweep) at full
+    size, both pillar orders (scrambled is the default and what bench.py runs): oracle comparison plus the
+    size-independent properties (exactly min(cells,P) rows, counts per cell, sortedness of the order, points
+    conserved)."""
     from pp_amd import synth
     pts = synth.lidar_like(cfg["n"], cfg["half"], 0)
     P, N = cfg["P"], cfg["N"]
@@ -442,7 +444,7 @@ def test_pipelined_mode_equals_plain_calls(gpu, oracle):
 
 
 @pytest.mark.parametrize("order", [0, 1], ids=["row_major", "scrambled"])
-@pytest.mark.parametrize("cfg", [C2, C5, C1], ids=["config2", "config5", "config1"])
+@pytest.mark.parametrize("cfg", [C2, C5, C1, REFDEF], ids=["config2", "config5", "config1", "reference_default"])
 def test_pipelined_mode_full_size(gpu, cfg, order):
     """k_step at BASELINE's sizes (and configs[0]'s crowded cells): bit-identical to the three-kernel path,
     odd N (scalar store mode) included."""

@@ -4,6 +4,7 @@ import numpy as np
 C2 = dict(n=60000, half=50.0, step=0.2, P=12000, N=100)     # BASELINE config 2
 C5 = dict(n=200000, half=100.0, step=0.2, P=30000, N=100)   # BASELINE config 5
 C1 = dict(n=60000, half=50.0, step=1.0, P=12000, N=100)     # BASELINE config 1 (100x100)
+REFDEF = dict(n=60000, half=60.0, step=0.2, P=24000, N=200)  # the reference's shipped config.py:46-61,119-120
 
 
 def grid_args(half, step, z_min=-10.0, z_max=10.0):
