@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic sweeps that
@@ -11,19 +11,25 @@ configs[1]: 60k-point lidar-like clouds, 500x500 BEV grid, P=12000, N=100, D=9,
 random backbone weights.  Multi-GPU: one process per GPU, every rank owns its
 own sweeps (seed = global sweep id), no data-path collective ("weak" scaling).
 
+The voxelizer runs software-pipelined over consecutive steps (the reference's DataLoader prefetch,
+train.py:120-121): ONE launch per step (k_step) does the split stage of batch i, the tile stage of batch
+i-1 and the emit stage of batch i-2 side by side, and the network consumes batch i-2 -- every step does
+one batch's worth of every stage (`--three-launch`: three dependent launches per step instead).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant hand-written kernel (k_emit, the dense [9,P,N] store):
-                algorithmic bytes per launch / its mean duration, timed live with HIP
-                events bound to the dispatch packets during the timed steps; beside it
-                `pipeline`: the same bytes over the SUM of the voxelizer's three kernels
-                (k_split + k_tile + k_emit) -> pipeline_frac, and their mean durations
-  voxelizer_only   wall time of the voxelizer launches alone (default = scrambled order,
-                and the row-major order beside it)
-  fused_feature_net  SURVEY 8f rank 1 measured beside the headline
+  roofline      the dominant hand-written kernel: k_step (= the whole voxelizer), algorithmic bytes per
+                launch / its mean duration, timed live with HIP events bound to the dispatch packets during
+                the timed steps; `three_launch`: the same forward with k_split, k_tile, k_emit as three
+                launches per step (their durations, their sum's fraction, k_emit's own)
+  voxelizer_only   wall time per voxelizer call alone, pipelined and (`three_launch`) as three launches:
+                default (scrambled) order, `row_major_order`, `one_sweep_per_launch` (configs[3]'s per-GPU
+                shape), `c1_shapes` (configs[0]'s 100x100 grid on the GPU)
+  fused_feature_net  SURVEY 8f rank 1 measured beside the headline, with its own roofline record
   train_c3      BASELINE configs[2] (and the RCCL leg of configs[3] when N > 1): HIP target
                 assignment + loss forward/backward + gradient and loss-scalar all-reduces
   stress_c5     BASELINE configs[4] shapes on one GPU: 200k points, 1000x1000 grid, P=30000,
-                voxelizer only, with its own roofline / pipeline fractions
+                voxelizer only, both paths, B sweeps and one sweep per launch
+  reference_default  the reference's shipped config.py sizes (600x600, P=24000, N=200; 540 000 anchors)
   cpu_baseline  the CPU oracle's reference-style voxel stage (hash map of heap nodes + the
                 caller's np.zeros/transpose/.float() glue, data/dataset.py:89-106) timed on
                 this host, 1 core, at configs[1]'s grid and (`c1`) at configs[0]'s 100x100 grid
@@ -83,7 +89,7 @@ def _cpu_voxel_stage(n, half, step, p, nn, seconds_budget):
         t0 = time.perf_counter()
         O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
         times.append(time.perf_counter() - t0)
-    return float(np.median(times)), len(times)
+    return float(np.median(times)), len(times), float(np.min(times)), float(np.max(times))
 
 
 def cpu_baseline(seconds_budget=10.0, workers=4, worker_budget=5.0, c1_budget=5.0):
@@ -92,17 +98,20 @@ def cpu_baseline(seconds_budget=10.0, workers=4, worker_budget=5.0, c1_budget=5.
     import subprocess
     from oracle import oracle as O
     O.build()
-    med, calls = _cpu_voxel_stage(N_POINTS, HALF, STEP, P, N, seconds_budget)
+    med, calls, lo, hi = _cpu_voxel_stage(N_POINTS, HALF, STEP, P, N, seconds_budget)
     out = {"value": 1.0 / med, "unit": "sweeps/s", "cores": 1, "kind": "port",
            "sample": f"{calls} calls of the voxel stage only (np.zeros + create_pillars "
                      f"[reference-style hash map of heap nodes] + transpose + f32 cast, "
-                     f"dataset.py:89-106) on one {N_POINTS}-pt cloud, median {med * 1e3:.1f} ms; "
-                     f"host has {os.cpu_count()} cores; the backbone is not part of this leg"}
+                     f"dataset.py:89-106) on one {N_POINTS}-pt cloud, median {med * 1e3:.1f} ms "
+                     f"(min {lo * 1e3:.1f}, max {hi * 1e3:.1f}; the median moves by +-25 % between boxes of "
+                     f"this pool); host has {os.cpu_count()} cores; the backbone is not part of this leg",
+           "ms_min_median_max": [lo * 1e3, med * 1e3, hi * 1e3]}
     # BASELINE configs[0]: the same cloud on the 100x100 grid (1 m cells), CPU path only
-    med1, calls1 = _cpu_voxel_stage(C1["n"], C1["half"], C1["step"], C1["P"], C1["N"], c1_budget)
+    med1, calls1, lo1, hi1 = _cpu_voxel_stage(C1["n"], C1["half"], C1["step"], C1["P"], C1["N"], c1_budget)
     out["c1"] = {"value": 1.0 / med1, "unit": "sweeps/s", "cores": 1, "kind": "port",
                  "sample": f"configs[0]: {calls1} calls, one {C1['n']}-pt cloud, 100x100 grid "
-                           f"(step {C1['step']} m), P={C1['P']} N={C1['N']}, median {med1 * 1e3:.1f} ms"}
+                           f"(step {C1['step']} m), P={C1['P']} N={C1['N']}, median {med1 * 1e3:.1f} ms "
+                           f"(min {lo1 * 1e3:.1f}, max {hi1 * 1e3:.1f})"}
     # the reference's loader runs num_workers = 4 such processes (config.py:139): fresh child
     # processes (never a fork of this GPU-initialised one), CPU only
     try:

@@ -2,8 +2,13 @@
 CPU oracle (oracle/, the restatement of data/pillars.cpp and utils/box_utils.py) at the time of writing.
 
 The reference ships no fixtures for this path and cannot be built in this image (Boost headers absent,
-DESIGN.md), so these vectors pin the ORACLE -- against drift between rounds -- and give the GPU tests a
-comparison that does not run the oracle at all.  They are data: inputs and expected outputs.
+DESIGN.md), so these vectors are an ORACLE-DRIFT PIN ONLY: they hold the oracle (and the HIP path, in a
+comparison that does not run the oracle) to what the oracle produced when they were written.  They do NOT pin
+parity with the reference's pillars.cpp / box_utils.py -- what does, as far as this image allows:
+tests/golden/targets_ref_golden.npz (create_target / make_target run from the reference's own source),
+tests/golden/model_golden.npz (model.py / loss.py run from the reference's own source), and the
+hand-computed known answers of tests/test_oracle_*.py and tests/test_host_logic.py (SURVEY 5.9 / 8c probe
+values, analytic IoUs, hand-derived corner / anchor rows).  They are data: inputs and expected outputs.
 
 Run:  python tests/golden/make_hotpath_golden.py
 """

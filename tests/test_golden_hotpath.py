@@ -1,6 +1,7 @@
 """Committed vectors of the hot path (tests/golden/hotpath_golden.npz, made by make_hotpath_golden.py from
 the CPU oracle): the oracle must still reproduce them (CPU), and the HIP path must produce them without
-the oracle being involved at all (GPU)."""
+the oracle being involved at all (GPU).  An ORACLE-DRIFT pin, not a reference pin: the vectors are the
+oracle's own output (the reference-run vectors are targets_ref_golden.npz and model_golden.npz)."""
 import os
 
 import numpy as np

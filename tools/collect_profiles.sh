@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/collect_profiles.sh: the rocprofv3 evidence of one round (run on the GPU box through gpurun):
-# kernel stats of the driver's bench command and of the voxelizer-only loop at C2/C5, B=1/4, both
-# pillar orders; FETCH_SIZE / WRITE_SIZE in separate --pmc passes.  Output: gpurun_out/prof/
+# kernel stats of the driver's bench command and of the voxelizer-only loop at C2/C5, B=1/4, software-pipelined
+# (k_step) and as three launches; FETCH_SIZE / WRITE_SIZE in separate --pmc passes; SQ counters of the binning
+# kernels.  Output: gpurun_out/prof/
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
@@ -15,26 +16,42 @@ stats() { # name cmd...
   echo "== $name"; grep -h "us/step\|\"metric\"" $O/$name.log | cut -c1-200
   [ -n "$f" ] && grep "pp::" "$f" | cut -d, -f1-4 | head -8
 }
-pmc() { # name counter cmd...
+pmc() { # name "counters" cmd...
   name=$1; ctr=$2; shift 2
   rocprofv3 --pmc $ctr --kernel-trace -d /tmp/c_$name -o $name --output-format csv -- "$@" > $O/$name.log 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/c_$name $O/${name}_summary.csv
+  python3 $R/tools/pmc_summary.py /tmp/c_$name $O/${name}_summary.csv > /dev/null
+  echo "== $name"; cat $O/${name}_summary.csv
 }
 V="python3 $R/tools/bench_vox.py"
+C5="--n 200000 --half 100 --P 30000"
 stats bench python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline
-for o in 1 0; do
-  stats vox_c2_b1_o$o $V --batch 1 --order $o
-  stats vox_c2_b4_o$o $V --batch 4 --order $o
-  stats vox_c5_b1_o$o $V --batch 1 --n 200000 --half 100 --P 30000 --order $o
-  stats vox_c5_b4_o$o $V --batch 4 --n 200000 --half 100 --P 30000 --order $o
+for b in 1 4; do
+  stats vox_c2_b${b}_step $V --batch $b --pipelined
+  stats vox_c2_b${b}_three $V --batch $b
+  stats vox_c5_b${b}_step $V --batch $b $C5 --pipelined
+  stats vox_c5_b${b}_three $V --batch $b $C5
 done
-pmc pmc_c2_b4_fetch FETCH_SIZE $V --batch 4 --iters 50
-pmc pmc_c2_b4_write WRITE_SIZE $V --batch 4 --iters 50
-pmc pmc_c2_b1_fetch FETCH_SIZE $V --batch 1 --iters 50
-pmc pmc_c2_b1_write WRITE_SIZE $V --batch 1 --iters 50
-pmc pmc_c5_b4_fetch FETCH_SIZE $V --batch 4 --n 200000 --half 100 --P 30000 --iters 50
-pmc pmc_c5_b4_write WRITE_SIZE $V --batch 4 --n 200000 --half 100 --P 30000 --iters 50
+stats vox_c2_b4_rowmajor_step $V --batch 4 --order 0 --pipelined
+stats vox_c2_b4_rowmajor_three $V --batch 4 --order 0
+for b in 1 4; do
+  pmc pmc_c2_b${b}_step_fetch FETCH_SIZE $V --batch $b --iters 50 --pipelined
+  pmc pmc_c2_b${b}_step_write WRITE_SIZE $V --batch $b --iters 50 --pipelined
+  pmc pmc_c2_b${b}_three_fetch FETCH_SIZE $V --batch $b --iters 50
+  pmc pmc_c2_b${b}_three_write WRITE_SIZE $V --batch $b --iters 50
+done
+pmc pmc_c5_b4_three_fetch FETCH_SIZE $V --batch 4 $C5 --iters 50
+pmc pmc_c5_b4_three_write WRITE_SIZE $V --batch 4 $C5 --iters 50
+pmc pmc_c5_b1_step_fetch FETCH_SIZE $V --batch 1 $C5 --iters 50 --pipelined
+pmc pmc_c5_b1_step_write WRITE_SIZE $V --batch 1 $C5 --iters 50 --pipelined
+# where the binning kernels' time goes, by counter (SQ block: 8 per pass; quad-cycle units)
+SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE"
+SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
+for b in 1 4; do
+  pmc sq1_c2_b${b}_three "$SQ1" $V --batch $b --iters 50
+  pmc sq2_c2_b${b}_three "$SQ2" $V --batch $b --iters 50
+  pmc sq1_c2_b${b}_step "$SQ1" $V --batch $b --iters 50 --pipelined
+done
+pmc sq1_c5_b4_three "$SQ1" $V --batch 4 $C5 --iters 50
+pmc sq2_c5_b4_three "$SQ2" $V --batch 4 $C5 --iters 50
 T="python3 $R/tools/bench_targets.py"
 stats targets_c3 $T
-pmc pmc_targets_c3_fetch FETCH_SIZE $T
-pmc pmc_targets_c3_write WRITE_SIZE $T

@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
         rows.setdefault((name, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 with open(out, "w", newline="") as fo:
     w = csv.writer(fo)                       # kernel names contain commas
-    w.writerow(["kernel", "counter", "launches", "median_KB"])
+    w.writerow(["kernel", "counter", "launches", "median (FETCH_SIZE, WRITE_SIZE: KiB)"])
     for (k, c), v in sorted(rows.items()):
         w.writerow([k, c, len(v), statistics.median(v)])
 print(open(out).read())
