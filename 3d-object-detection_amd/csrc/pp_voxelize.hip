@@ -617,13 +617,57 @@ __device__ __forceinline__ void tile_body(
   PP_STAMP(7);
 }
 
+// The fused feature-net mode's canvas (PPScatter, model/model.py:53-62) must read zero wherever no pillar
+// lands.  A caller that hands the SAME canvas back call after call (PillarPipeline.forward_fused) does not
+// need the whole 64 MB per sweep cleared again: only the pixels the previous call wrote are non-zero, and
+// the previous call's indices say which.  Extra workgroups of the k_tile launch zero exactly those (a kernel
+// boundary before k_emit writes the new ones): 3 MB per sweep instead of 64 MB.
+struct UnscatterArgs {
+  const long long *prev_idx;  // [B][P][3] {flag, col, row} of the call that filled the canvas, or NULL
+  float *canvas;
+  int P, h, w, nhwc, nblocks;
+};
+constexpr int kPfnChannels = 64;  // one lane per output channel (model/model.py:28: 9 -> 64)
+constexpr int kUnscatterPixels = 256;  // pixels per extra workgroup
+
+__device__ __forceinline__ void unscatter_body(const UnscatterArgs &u, int blk, int b, int threads) {
+  const int tid = threadIdx.x;
+  const int64_t plane = (int64_t)u.h * u.w;
+  const int p_end = min(u.P, (blk + 1) * kUnscatterPixels);
+  if (u.nhwc) {
+    // a pixel = 64 channels = 256 contiguous bytes: 16 lanes x 16 bytes
+    const int sub = tid & 15;
+    for (int p = blk * kUnscatterPixels + (tid >> 4); p < p_end; p += threads >> 4) {
+      const long long *e = u.prev_idx + ((int64_t)b * u.P + p) * 3;
+      if (e[0] == 0) continue;
+      const long long col = e[1], row = e[2];
+      if (row < 0 || row >= u.h || col < 0 || col >= u.w) continue;
+      reinterpret_cast<float4 *>(u.canvas + (((int64_t)b * u.h + row) * u.w + col) * kPfnChannels)[sub] =
+          make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    const int c = tid & 63;
+    for (int p = blk * kUnscatterPixels + (tid >> 6); p < p_end; p += threads >> 6) {
+      const long long *e = u.prev_idx + ((int64_t)b * u.P + p) * 3;
+      if (e[0] == 0) continue;
+      const long long col = e[1], row = e[2];
+      if (row < 0 || row >= u.h || col < 0 || col >= u.w) continue;
+      u.canvas[((int64_t)b * kPfnChannels + c) * plane + row * u.w + col] = 0.0f;
+    }
+  }
+}
+
 template <typename T, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     NPoints np, GridGeom g, int ncap, int nchunks_cap, const int *__restrict__ kslot,
     const typename Rec4<T>::type *__restrict__ kpts, const int2 *__restrict__ mat,
     typename Rec4<T>::type *__restrict__ sorted_pts, int4 *__restrict__ tile_meta,
-    u64 *__restrict__ tile_agg, u64 *stamps) {
+    u64 *__restrict__ tile_agg, u64 *stamps, UnscatterArgs un) {
   extern __shared__ __attribute__((aligned(16))) unsigned tile_smem[];
+  if ((int)blockIdx.x >= g.ntiles) {  // (only launched when un.nblocks > 0)
+    unscatter_body(un, (int)blockIdx.x - g.ntiles, (int)blockIdx.y, WAVES * kWave);
+    return;
+  }
   tile_body<T, WAVES>(np, g, ncap, nchunks_cap, kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, stamps,
                       tile_smem, (int)blockIdx.x, (int)blockIdx.y);
 }
@@ -670,7 +714,6 @@ enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 
 constexpr int kAuxPlain = 0, kAuxSc1 = 16;           // buffer-store cache policy bits (gfx950: sc1 = 16)
 constexpr size_t kSc1MaxBytes = 128u << 20;          // write-through stores pay off up to about half the Infinity Cache
 
-constexpr int kPfnChannels = 64;  // one lane per output channel (model/model.py:28: 9 -> 64)
 
 // Fused PPFeatureNet (inference): y[c,p] = max_n BN_c(ReLU(b_c + sum_d W[c,d] x[d,p,n]))
 // over ALL N slots of the pillar, zero-padded ones included (model/model.py:31-40:
@@ -1729,7 +1772,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     int mode, float *out, long long *idx_out, double *feat_out,
                     bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr,
                     float *canvas = nullptr, int canvas_h = 0, int canvas_w = 0,
-                    int canvas_nhwc = 0) {
+                    int canvas_nhwc = 0, const long long *prev_idx = nullptr) {
   constexpr int slot = 0;  // the plain calls' workspace (k_step's batches rotate through the others)
   using Rec = typename Rec4<TIn>::type;
   char *ws = static_cast<char *>(ctx->vox_ws[slot].ptr);
@@ -1797,10 +1840,21 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                         lds_split, stream, ev0[PP_KERNEL_SPLIT], ev1[PP_KERNEL_SPLIT], 0, pts,
                         sweep_stride, s0, s1, contig, np, g, l.ncap, l.nchunks_cap, kslot, kpts, mat,
                         stamps);
+  UnscatterArgs un;
+  std::memset(&un, 0, sizeof un);
+  if (canvas && prev_idx) {
+    un.prev_idx = prev_idx;
+    un.canvas = canvas;
+    un.P = P;
+    un.h = canvas_h;
+    un.w = canvas_w;
+    un.nhwc = canvas_nhwc;
+    un.nblocks = (P + kUnscatterPixels - 1) / kUnscatterPixels;
+  }
   auto launch_tile = [&](auto kern) {
-    hipExtLaunchKernelGGL(kern, dim3((unsigned)g.ntiles, (unsigned)B), dim3(tw * kWave), lds_tile,
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)(g.ntiles + un.nblocks), (unsigned)B), dim3(tw * kWave), lds_tile,
                           stream, ev0[PP_KERNEL_TILE], ev1[PP_KERNEL_TILE], 0, np, g, l.ncap,
-                          l.nchunks_cap, kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, stamps);
+                          l.nchunks_cap, kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, stamps, un);
   };
   if (tw == 4) launch_tile(&k_tile<TIn, 4>);
   else if (tw == 8) launch_tile(&k_tile<TIn, 8>);
@@ -2261,7 +2315,7 @@ static int voxelize_pfn_impl(pp_ctx_t *ctx, void *stream_, const float *points_d
                              const pp_voxel_params_t *prm, const float *pfn_params_dev,
                              int channels, float *features_dev, int64_t *indices_dev,
                              int32_t *num_cells_dev, float *canvas_dev, int canvas_h, int canvas_w,
-                             int channels_last) {
+                             int channels_last, const int64_t *prev_indices_dev = nullptr) {
   if (!ctx || !points_dev || !n_points || !prm || !pfn_params_dev || !indices_dev ||
       (!features_dev && !canvas_dev)) {
     set_error("pp_voxelize_pfn*_dev: NULL argument");
@@ -2319,15 +2373,21 @@ static int voxelize_pfn_impl(pp_ctx_t *ctx, void *stream_, const float *points_d
                 "aligned)", canvas_h, canvas_w, g.canvas_height);
       return PP_ERR_VALUE;
     }
-    PP_HIP_TRY(hipMemsetAsync(canvas_dev, 0,
-                              (size_t)batch * kPfnChannels * canvas_h * canvas_w * sizeof(float),
-                              stream));
+    if (prev_indices_dev && (reinterpret_cast<uintptr_t>(prev_indices_dev) & 7)) {
+      set_error("prev_indices_dev must be 8-byte aligned");
+      return PP_ERR_VALUE;
+    }
+    if (!prev_indices_dev)   // an unknown canvas: all of it
+      PP_HIP_TRY(hipMemsetAsync(canvas_dev, 0,
+                                (size_t)batch * kPfnChannels * canvas_h * canvas_w * sizeof(float),
+                                stream));
   }
   rc = launch_pipeline<float>(ctx, stream, points_dev, points_stride, 4, 1, 1, np, batch, maxn,
                               g, P, N, l, kModePfn, nullptr,
                               reinterpret_cast<long long *>(indices_dev), nullptr, true,
                               pfn_params_dev, features_dev, canvas_dev, canvas_h, canvas_w,
-                              channels_last ? 1 : 0);
+                              channels_last ? 1 : 0,
+                              canvas_dev ? reinterpret_cast<const long long *>(prev_indices_dev) : nullptr);
   if (rc) return rc;
   if (num_cells_dev) {
     char *ws = static_cast<char *>(ctx->vox_ws[0].ptr);
@@ -2365,6 +2425,22 @@ extern "C" int pp_voxelize_pfn_canvas_dev(pp_ctx_t *ctx, void *stream_, const fl
   return voxelize_pfn_impl(ctx, stream_, points_dev, points_stride, n_points, batch, prm,
                            pfn_params_dev, channels, nullptr, indices_dev, num_cells_dev,
                            canvas_dev, canvas_h, canvas_w, channels_last);
+}
+
+extern "C" int pp_voxelize_pfn_canvas_reuse_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                                int64_t points_stride, const int32_t *n_points,
+                                                int batch, const pp_voxel_params_t *prm,
+                                                const float *pfn_params_dev, int channels,
+                                                float *canvas_dev, int canvas_h, int canvas_w,
+                                                int channels_last, int64_t *indices_dev,
+                                                int32_t *num_cells_dev, const int64_t *prev_indices_dev) {
+  if (!canvas_dev) {
+    set_error("pp_voxelize_pfn_canvas_reuse_dev: NULL argument");
+    return PP_ERR_VALUE;
+  }
+  return voxelize_pfn_impl(ctx, stream_, points_dev, points_stride, n_points, batch, prm,
+                           pfn_params_dev, channels, nullptr, indices_dev, num_cells_dev,
+                           canvas_dev, canvas_h, canvas_w, channels_last, prev_indices_dev);
 }
 
 extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,

@@ -95,8 +95,14 @@ class PillarPipeline:
             # ... and PPScatter too: the emit kernel writes each pillar's 64 features to its
             # channels-last canvas pixel
             H, W = self.model.scatter.h, self.model.scatter.w
+            cbuf = self._canvas(B, H, W)
+            # the canvas and index buffers are this pipeline's own and nothing else writes them: after the
+            # first call only the previous call's pixels are non-zero, and only those are cleared again
+            key = (cbuf.data_ptr(), self._fbufs[1].data_ptr(), B)
             canvas, _ = self.voxelizer.pfn_canvas(points, pfn_params, (H, W), n_points=n_points,
-                                                  out=(self._canvas(B, H, W), self._fbufs[1]))
+                                                  out=(cbuf, self._fbufs[1]),
+                                                  reuse=(getattr(self, "_canvas_key", None) == key))
+            self._canvas_key = key
             return self.model.forward_canvas(canvas)
         feats, indices = self.voxelizer.pfn(points, pfn_params, n_points=n_points, out=self._fbufs)
         return self.model.forward_features(feats, indices)

@@ -162,11 +162,16 @@ class PillarVoxelizer:
         return feats, indices
 
     def pfn_canvas(self, points, pfn_params, canvas_hw, n_points=None, channels_last=True,
-                   out=None, return_counts=False):
+                   out=None, return_counts=False, reuse=False):
         """Voxelizer + feature net + PPScatter (model/model.py:31-62) in one pass:
         returns ``(canvas[B,64,H,W] f32, indices[B,P,3] i64)``; with
         ``channels_last`` the canvas is a channels-last tensor (same logical shape,
-        memory [B,H,W,64]) that MIOpen's NHWC convolutions consume directly."""
+        memory [B,H,W,64]) that MIOpen's NHWC convolutions consume directly.
+
+        ``reuse=True`` (with ``out``): the caller promises that ``out`` is exactly what the previous
+        ``pfn_canvas`` call with these buffers returned (same batch, canvas untouched since) -- then only
+        the pixels that call wrote are zeroed instead of the whole canvas
+        (pp_voxelize_pfn_canvas_reuse_dev)."""
         points, B, ncap, n_arr = self._prep(points, n_points)
         P = self.cfg.max_pillars
         self._no_mean("pfn_canvas")
@@ -188,13 +193,14 @@ class PillarVoxelizer:
         counts = (torch.empty((B, 2), dtype=torch.int32, device=self.device)
                   if return_counts else None)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = _lib.lib().pp_voxelize_pfn_canvas_dev(
+        rc = _lib.lib().pp_voxelize_pfn_canvas_reuse_dev(
             self._ctx.handle, ctypes.c_void_p(stream), ctypes.c_void_p(points.data_ptr()),
             ncap, n_arr, B, ctypes.byref(self._prm), ctypes.c_void_p(pfn_params.data_ptr()), 64,
             ctypes.c_void_p(canvas.data_ptr()), H, W, 1 if channels_last else 0,
             ctypes.c_void_p(indices.data_ptr()),
-            ctypes.c_void_p(counts.data_ptr()) if counts is not None else None)
-        _lib.check(rc, "pp_voxelize_pfn_canvas_dev")
+            ctypes.c_void_p(counts.data_ptr()) if counts is not None else None,
+            ctypes.c_void_p(indices.data_ptr()) if (reuse and out is not None) else None)
+        _lib.check(rc, "pp_voxelize_pfn_canvas_reuse_dev")
         if return_counts:
             return canvas, indices, counts
         return canvas, indices

@@ -400,34 +400,40 @@ def main():
         H_, W_ = pipe.model.scatter.h, pipe.model.scatter.w
         f_out = (pipe._canvas(a.batch, H_, W_), pipe._fbufs[1])
 
-        def fused_call():
-            pipe.voxelizer.pfn_canvas(points, pfn_tab, (H_, W_), out=f_out)
-        for _ in range(10):
-            fused_call()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(100):
-            fused_call()
-        torch.cuda.synchronize()
-        f_dt = (time.perf_counter() - t2) / 100
+        def fused_wall(reuse):
+            for _ in range(10):
+                pipe.voxelizer.pfn_canvas(points, pfn_tab, (H_, W_), out=f_out, reuse=reuse)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(100):
+                pipe.voxelizer.pfn_canvas(points, pfn_tab, (H_, W_), out=f_out, reuse=reuse)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / 100
+        f_dt_full = fused_wall(False)            # unknown canvas: all 64 MB per sweep cleared
+        f_dt = fused_wall(True)                  # the canvas handed back: only the previous call's pixels cleared
         pipe.voxelizer.set_timing(64)
         for _ in range(64):
-            fused_call()
+            pipe.voxelizer.pfn_canvas(points, pfn_tab, (H_, W_), out=f_out, reuse=True)
         torch.cuda.synchronize()
         f_k, _ = kernel_means_us(pipe.voxelizer)
         pipe.voxelizer.set_timing(0)
-        f_live = 16 * N_POINTS + 256 * P + 24 * P                      # per sweep, without the clear
-        f_clear = 64 * H_ * W_ * 4
+        f_live = 16 * N_POINTS + 256 * P + 24 * P                      # per sweep: points in, pixels + indices out
+        f_sparse = 256 * P + 24 * P                                    # ... the previous call's pixels zeroed, its indices read
+        f_clear = 64 * H_ * W_ * 4                                     # ... or the whole canvas
         fused["roofline"] = {
-            "bound": "hbm by its bytes; measured: latency-bound",
-            "kernel": "pp::k_emit<float,3,0> (+ k_split, k_tile, the canvas clear)",
-            "bytes_per_launch": (f_live + f_clear) * a.batch,
+            "bound": "hbm by its bytes; measured: latency-bound (three dependent launches, 4 waves per SIMD)",
+            "kernel": "pp::k_emit<float,3,0> (+ k_split, k_tile with the sparse canvas clear in extra workgroups)",
+            "bytes_per_launch": (f_live + f_sparse) * a.batch,
             "bytes_what": "per sweep 16*n + 256*P (one channels-last feature pixel per pillar) + 24*P (indices) + "
-                          "the canvas clear 64*H*W*4",
+                          "256*P + 24*P (the previous call's pixels zeroed: pp_voxelize_pfn_canvas_reuse_dev)",
             "us_per_call": f_dt * 1e6, "kernels_us": f_k, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "achieved": (f_live + f_clear) * a.batch / f_dt / 1e9,
-            "frac": (f_live + f_clear) * a.batch / f_dt / HBM_PEAK,
-            "k_emit_frac_of_its_own_bytes": f_live * a.batch / (f_k["k_emit"] * 1e-6) / HBM_PEAK}
+            "achieved": (f_live + f_sparse) * a.batch / f_dt / 1e9,
+            "frac": (f_live + f_sparse) * a.batch / f_dt / HBM_PEAK,
+            "k_emit_frac_of_its_own_bytes": f_live * a.batch / (f_k["k_emit"] * 1e-6) / HBM_PEAK,
+            "full_clear": {"us_per_call": f_dt_full * 1e6, "bytes_per_launch": (f_live + f_clear) * a.batch,
+                           "frac": (f_live + f_clear) * a.batch / f_dt_full / HBM_PEAK,
+                           "what": "pp_voxelize_pfn_canvas_dev: an unknown canvas, all 64*H*W*4 bytes per sweep "
+                                   "cleared by a memset first"}}
 
     # BASELINE configs[2] (and configs[3]'s collectives when N > 1): target assignment + loss
     # forward/backward + the gradient and loss-scalar all-reduces, every rank, timed like the headline

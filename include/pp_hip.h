@@ -208,6 +208,22 @@ int pp_voxelize_pfn_canvas_dev(pp_ctx_t *ctx, void *stream, const float *points_
                                int channels_last, int64_t *indices_dev, int32_t *num_cells_dev);
 
 /*
+ * The same for a canvas that is handed back call after call (a persistent buffer, as PPScatter's
+ * output is per step, model/model.py:53-62): `prev_indices_dev` are the indices the PREVIOUS call of
+ * this function (or of pp_voxelize_pfn_canvas_dev) wrote for the SAME canvas_dev with the same batch and
+ * prm -- the only pixels of it that are non-zero.  Instead of clearing the whole canvas (64 MB per
+ * sweep at 500x500) only those pixels are zeroed (3 MB), by extra workgroups of the tile launch.
+ * prev_indices_dev may alias indices_dev (it is read before indices_dev is written); NULL = the
+ * canvas's contents are unknown: full clear, exactly pp_voxelize_pfn_canvas_dev.
+ */
+int pp_voxelize_pfn_canvas_reuse_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
+                                     int64_t points_stride, const int32_t *n_points, int batch,
+                                     const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                                     int channels, float *canvas_dev, int canvas_h, int canvas_w,
+                                     int channels_last, int64_t *indices_dev, int32_t *num_cells_dev,
+                                     const int64_t *prev_indices_dev);
+
+/*
  * Host drop-in for create_pillars (pillars.cpp:236-249, exported :433).
  * points [n,>=4], tensor [P',N',>=9], indices [P',>=3]: f64 host arrays with
  * arbitrary BYTE strides, mutated in place; nothing is zeroed (pillars.cpp never

@@ -132,6 +132,20 @@ def test_fused_scatter_canvas_equals_ppscatter(gpu):
     assert torch.equal(buf, want)
     with pytest.raises(Exception):
         vox.pfn_canvas(pts, fn.fused_params(), (H - 1, W), n_points=n_points)
+    # a canvas handed back call after call (pp_voxelize_pfn_canvas_reuse_dev): only the previous call's pixels
+    # are cleared -- DIFFERENT clouds through the same buffers, each result equal to a fresh full-clear call
+    for cl in (True, False):
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        cbuf = torch.full((3, 64, H, W), 5.0, device=gpu).contiguous(memory_format=fmt)
+        ibuf = torch.empty_like(idx)
+        for k, seeds in enumerate([(1, 2, 3), (7, 8, 9), (4, 4, 4), (1, 2, 3)]):
+            q = torch.from_numpy(np.stack([synth.lidar_like(20000, half, s_) for s_ in seeds])).to(gpu)
+            npts = [20000, 700 + 3000 * k, 0 if k % 2 == 0 else 20000]
+            fresh, fresh_idx = vox.pfn_canvas(q, fn.fused_params(), (H, W), n_points=npts, channels_last=cl)
+            vox.pfn_canvas(q, fn.fused_params(), (H, W), n_points=npts, channels_last=cl, out=(cbuf, ibuf),
+                           reuse=(k > 0))
+            torch.cuda.synchronize()
+            assert torch.equal(cbuf, fresh) and torch.equal(ibuf, fresh_idx), (cl, k)
     # PPScatter's own inference path (pp_scatter_canvas_dev) gives the same canvas, channels last
     sc2 = M.PPScatter(H, W).eval()
     with torch.no_grad():
