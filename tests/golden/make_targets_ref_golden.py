@@ -23,6 +23,9 @@ strict threshold / the np.nonzero filter that drops a best anchor 0 / class one-
 zero-and-reset of the forced rows / duplicate forced anchors / write order of the regression rows)
 and every arithmetic statement of make_target (diagonal, y flip, quotients, logs, yaw folding, sine,
 orientation bit) -- executed by the reference's own source text under this image's numpy.
+Also run from the reference's source: make_anchor_boxes (box_utils.py:111-159) on two small maps -- the anchor
+ORDER (y, x, d), the centre formula and the anchor_xy corner choice; the corner values come from this repo's
+bottom_corners_xy standing in for the absent SDK method (section 5 below).
 WHAT IT DOES NOT PIN: the IoU values themselves (they come from the oracle: Boost.Geometry stays
 unpinned), ``Box.bottom_corners`` (corner arrays are inputs here, made by the repo's boxes.py) and
 ``Quaternion.yaw_pitch_roll`` (the yaw is handed over as a number; the SDK would derive it from a
@@ -229,6 +232,44 @@ assert set(np.unique(reg_t[:, 8])) == {0.0, 1.0}
 # 4f. no box reaches any anchor
 _, cls_t, reg_t = add("no_overlap", q, gt_dict([at(60, 60, yaw=0.2)]), HQ)
 assert not cls_t.any() and not reg_t.any()
+
+# 5. make_anchor_boxes (box_utils.py:111-159) run from the reference's source: the loop order (y, x, d), the centre
+#    formula, the per-type size / yaw / z lookup and the anchor_xy corner choice (yaw > 0: corners 1,3, else 2,0).
+#    The lyft Box / pyquaternion Quaternion it constructs are FIELD HOLDERS here; Box.bottom_corners() -- the
+#    SDK's arithmetic, absent -- is answered by this repo's boxes.bottom_corners_xy (so the corner VALUES are
+#    not pinned by this, their assembly into the four arrays is).
+class _QuatFields:
+    def __init__(self, axis=None, degrees=None, radians=None):
+        assert list(axis) == [0, 0, 1] and radians is None
+        self.degrees = degrees
+        self.yaw_pitch_roll = (float(np.deg2rad(degrees)), 0.0, 0.0)     # what boxes.py uses (recalled, see DESIGN)
+
+
+class _AnchorBoxFields:
+    def __init__(self, center=None, size=None, orientation=None):
+        self.center, self.wlh, self.orientation = np.array(center, np.float64), np.array(size, np.float64), orientation
+
+    def bottom_corners(self):
+        xy = boxes.bottom_corners_xy(self.center, self.wlh, np.float64(self.orientation.yaw_pitch_roll[0]))
+        return np.vstack([xy.T, np.zeros((1, 4))])                       # [3,4] like the SDK; only xy is read
+
+
+ref.Quaternion, ref.Box = _QuatFields, _AnchorBoxFields
+for tag, acfg in (("anchors_c3_8x5", boxes.AnchorConfig(8, 5)),
+                  ("anchors_default_6x7", boxes.AnchorConfig(6, 7, 0.5, dflt.dims, dflt.yaws_deg, dflt.zs))):
+    cfg.DATA.FM_HEIGHT, cfg.DATA.FM_WIDTH, cfg.DATA.FM_SCALE = acfg.fm_height, acfg.fm_width, acfg.fm_scale
+    cfg.DATA.ANCHOR_DIMS = [np.array(d) for d in acfg.dims]
+    cfg.DATA.ANCHOR_YAWS, cfg.DATA.ANCHOR_ZS = list(acfg.yaws_deg), list(acfg.zs)
+    b_list, corners, centers, xy = ref.make_anchor_boxes()               # reference-run
+    mine = boxes.make_anchors(acfg)
+    assert np.array_equal(corners, mine["corners"]) and np.array_equal(centers, mine["centers"])
+    assert np.array_equal(xy, mine["xy"])
+    assert np.array_equal(np.stack([b.wlh for b in b_list]), mine["wlh"])
+    assert np.array_equal(np.array([b.orientation.yaw_pitch_roll[0] for b in b_list]), mine["yaw"])
+    cases[tag] = dict(fm=np.array([acfg.fm_height, acfg.fm_width, acfg.fm_scale, 0, 0], np.float64),
+                      dims=np.asarray(acfg.dims, np.float64), yaws_deg=np.asarray(acfg.yaws_deg, np.float64),
+                      zs=np.asarray(acfg.zs, np.float64), anchor_corners=corners, anchor_centers=centers, anchor_xy=xy)
+    print(f"{tag}: make_anchor_boxes from the reference's source == boxes.make_anchors ({len(corners)} anchors)")
 
 flat = {}
 for name, c in cases.items():
