@@ -130,12 +130,13 @@ struct pp_step_batch {
 struct pp_ctx {
   int device = 0;
   // voxelizer scratch, laid out by VoxLayout (pp_voxelize.hip).  Slot 0 serves the plain calls; the
-  // batches of the software-pipelined mode (pp_voxelize_step_dev: three of them are in flight, one
-  // per role of k_step) rotate through slots 1..3.
-  static constexpr int kVoxSlots = 4;
+  // batches of the software-pipelined mode (pp_voxelize_step_dev: four of them are in flight, one
+  // per stage role of k_step) rotate through slots 1..4.
+  static constexpr int kVoxSlots = 5;
   pp::DevBuf vox_ws[kVoxSlots];
   unsigned long long vox_layout_key[kVoxSlots][6] = {};
-  pp_step_batch step_batch[2];   // [0]: split done, waits for its tile role; [1]: tiled, waits for its emit role
+  pp_step_batch step_batch[3];   // [0]: split done, waits for its tile role; [1]: tiled, waits for the order role;
+                                 // [2]: descriptors in pillar order, waits for its emit role
   int step_next_slot = 1;
   bool sort_lds_armed = false;     // k_sort_runs' dynamic-LDS attribute set on this context's device
   int force_tile_waves = 0;  // development knob: PP_TILE_WAVES in the environment

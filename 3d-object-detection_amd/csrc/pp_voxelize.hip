@@ -694,6 +694,8 @@ struct EmitArgs {
   const int4 *tile_meta;    // [B][tiles][tile slots] {slot, start, count, -} of a tile's occupied cells
   const u64 *tile_agg;      // [B][tiles] {points << 32 | occupied cells}
   int4 *pillar_meta;        // [B][P] the same descriptors in pillar order (written in compact mode: host path)
+  const int4 *ordered_meta;     // k_step: [B][P] descriptors in pillar order, written by the ORDER role of the previous
+  const int2 *ordered_totals;   // launch, and [B] {cells, points}; NULL -> every wave takes the tile prefix itself
   int2 *totals;             // [B] {cells, points}, written here
   const void *sorted_pts;   // [B][ncap] point record (x,y,z,r), CSR order, input order per bucket
   // dense mode
@@ -1102,7 +1104,15 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
   // (1) pillar descriptors.  The pillar index of a cell = occupied cells of all earlier
   //     tiles + its place in its tile's list; k_tile left the former open, so every wave
   //     prefix-sums the tiles' totals itself (lane l owns nv consecutive tiles: no LDS, no
-  //     barrier) and finds the tiles of its KW pillars with ballots.
+  //     barrier) and finds the tiles of its KW pillars with ballots.  (k_step: the previous launch's
+  //     ORDER role already wrote the descriptors in pillar order -- one load instead of that chain.)
+  int4 m = make_int4(-1, 0, 0, 0);
+  if (a.ordered_meta) {
+    const int2 tt = a.ordered_totals[b];
+    if (bx == 0 && w == 0 && lane == 0) a.totals[b] = tt;
+    const int npil_o = min(tt.x, P);
+    if (lane < KW && p0 + lane < npil_o) m = a.ordered_meta[(int64_t)b * P + p0 + lane];
+  } else {
   const int ntiles = a.g.ntiles;
   const int nv = (ntiles + kWave - 1) / kWave;  // tiles per lane, <= 64
   const u64 *agg = a.tile_agg + (int64_t)b * ntiles;
@@ -1127,7 +1137,6 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
     a.totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
   const int npil = min((int)(tot & 0xFFFFFFFFull), P);
   PP_STAMP_E(1);
-  int4 m = make_int4(-1, 0, 0, 0);
 #pragma unroll
   for (int k = 0; k < KW; ++k) {
     const unsigned p = (unsigned)(p0 + k);
@@ -1165,6 +1174,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
       if (MODE == kModeCompact) a.pillar_meta[(int64_t)b * P + p] = m;
     }
   }
+  }  // tile-prefix path
   SlabGeom sg;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       (void *)(a.out + (int64_t)b * 9 * P * N), 0,
@@ -1496,8 +1506,52 @@ struct PrefetchRole {
   const int4 *tile_meta;
   int nlists, list_stride;
 };
+// ORDER role: one wave per (sweep, tile) copies the tile's descriptor list to its place in pillar order (the
+// exclusive prefix of the tiles' occupied-cell counts: the one thing that depends on other tiles, known now
+// that the previous launch's tile role has finished), capped at P; the last tile's wave leaves the totals.
+// The emit role of the NEXT launch then starts with one descriptor load instead of prefix + search + load.
+struct OrderRole {
+  GridGeom g;
+  int P, B;
+  const int4 *tile_meta;
+  const u64 *tile_agg;
+  int4 *ordered_meta;
+  int2 *ordered_totals;
+};
+__device__ __forceinline__ void order_body(const OrderRole &o, int blk) {
+  const int lane = threadIdx.x & 63, wid = blk * kEmitWaves + (threadIdx.x >> 6);
+  const int ntiles = o.g.ntiles;
+  if (wid >= o.B * ntiles) return;
+  const int b = wid / ntiles, t = wid - b * ntiles;
+  const u64 *agg = o.tile_agg + (int64_t)b * ntiles;
+  const int nv = (ntiles + kWave - 1) / kWave;
+  u64 before = 0, all = 0;
+  for (int e = 0; e < nv; ++e) {
+    const int tt = lane * nv + e;
+    if (tt < ntiles) {
+      const u64 v = agg[tt];
+      all += v;
+      if (tt < t) before += v & 0xFFFFFFFFull;
+    }
+  }
+  const unsigned before_t = (unsigned)__builtin_amdgcn_readlane((int)wave_scan_u32((unsigned)before), kWave - 1);
+  const unsigned cells_t = (unsigned)(agg[t] & 0xFFFFFFFFull);
+  const int4 *lst = o.tile_meta + ((int64_t)b * ntiles + t) * (1 << o.g.tile_shift);
+  int4 *dst = o.ordered_meta + (int64_t)b * o.P;
+  for (unsigned k = lane; k < cells_t; k += kWave) {
+    const unsigned p = before_t + k;
+    if (p < (unsigned)o.P) dst[p] = lst[k];
+  }
+  if (t == ntiles - 1) {
+    const u64 tot = wave_scan_2x32(all);
+    if (lane == kWave - 1) o.ordered_totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
+  }
+}
+
 struct StepArgs {
   int n_pref_blocks;
+  int n_order_blocks;
+  OrderRole o;
   PrefetchRole pf;
   int n_tile_blocks, n_split_blocks, emit_nbx;
   int mix, mix_groups;  // block order: mix_groups groups of {1 binning block, mix-1 emit blocks}, then the rest
@@ -1547,7 +1601,7 @@ __global__ __launch_bounds__(kStepThreads, PP_EMIT_MINWAVES) void k_step(StepArg
   // and mix-1 emit blocks, so that the stores flow from the first microsecond AND every binning chain starts
   // early (a chain that starts late is the launch's tail); what is left of either kind follows.
   {
-    const int nbin = a.n_tile_blocks + a.n_split_blocks;
+    const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
     const int head = a.mix_groups * a.mix;
     if (id < head) {
       const int grp = id / a.mix, j = id - grp * a.mix;
@@ -1568,6 +1622,11 @@ __global__ __launch_bounds__(kStepThreads, PP_EMIT_MINWAVES) void k_step(StepArg
     return;
   }
   id -= a.n_tile_blocks;
+  if (id < a.n_order_blocks) {
+    order_body(a.o, id);
+    return;
+  }
+  id -= a.n_order_blocks;
   if (id < a.n_split_blocks) {
     const int nc = a.s.nchunks;
     const int b = id / nc, chunk = id - b * nc;
@@ -1692,7 +1751,7 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g, int step_mode) {
 namespace {
 
 struct VoxLayout {
-  size_t kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, meta, totals, stamps, bytes;
+  size_t kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, meta, totals, otot, stamps, bytes;
   int ncap;         // point capacity per sweep, a multiple of the split chunk
   int nchunks_cap;  // split chunks per sweep at capacity
 };
@@ -1720,6 +1779,8 @@ VoxLayout vox_layout(int B, int64_t max_points, const GridGeom &g, int P, int re
   l.meta = off;       // compact mode only (host drop-in)
   off = align_up(off + (size_t)B * P * 16, 256);
   l.totals = off;
+  off = align_up(off + (size_t)B * 8, 256);
+  l.otot = off;       // k_step: {cells, points} per sweep, left by the order role for the emit role
   off = align_up(off + (size_t)B * 8, 256);
   l.stamps = off;
 #ifdef PP_STAMPS
@@ -1868,6 +1929,8 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.tile_meta = tile_meta;
   a.tile_agg = tile_agg;
   a.pillar_meta = meta;
+  a.ordered_meta = nullptr;
+  a.ordered_totals = nullptr;
   a.totals = totals;
   a.sorted_pts = sorted_pts;
   a.out = out;
@@ -2076,8 +2139,8 @@ namespace {
 struct SlotArrays {
   int *kslot;
   float4 *kpts, *sorted_pts;
-  int2 *mat, *totals;
-  int4 *tile_meta;
+  int2 *mat, *totals, *otot;
+  int4 *tile_meta, *meta;
   u64 *tile_agg;
 };
 SlotArrays slot_arrays(pp_ctx *ctx, int slot, const VoxLayout &l) {
@@ -2090,6 +2153,8 @@ SlotArrays slot_arrays(pp_ctx *ctx, int slot, const VoxLayout &l) {
   a.tile_meta = reinterpret_cast<int4 *>(ws + l.tile_meta);
   a.tile_agg = reinterpret_cast<u64 *>(ws + l.tile_agg);
   a.totals = reinterpret_cast<int2 *>(ws + l.totals);
+  a.otot = reinterpret_cast<int2 *>(ws + l.otot);
+  a.meta = reinterpret_cast<int4 *>(ws + l.meta);
   return a;
 }
 int step_geometry(const pp_step_batch &sb, GridGeom *g, VoxLayout *l) {
@@ -2111,7 +2176,7 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(ctx->device);
-  pp_step_batch &sb_tile = ctx->step_batch[0], &sb_emit = ctx->step_batch[1];
+  pp_step_batch &sb_tile = ctx->step_batch[0], &sb_order = ctx->step_batch[1], &sb_emit = ctx->step_batch[2];
   if (sb_emit.valid) {
     if (!pillars_dev || !indices_dev) {
       set_error("pp_voxelize_step_dev: a batch is due, its output buffers are NULL");
@@ -2191,6 +2256,21 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     a.n_tile_blocks = g.ntiles * sb_tile.batch;
     lds = std::max(lds, tile_lds_bytes(1 << g.tile_shift, kStepWaves));
   }
+  if (sb_order.valid) {
+    GridGeom g;
+    VoxLayout l;
+    rc = step_geometry(sb_order, &g, &l);
+    if (rc) return rc;
+    const SlotArrays w = slot_arrays(ctx, sb_order.slot, l);
+    a.o.g = g;
+    a.o.P = sb_order.prm.max_pillars;
+    a.o.B = sb_order.batch;
+    a.o.tile_meta = w.tile_meta;
+    a.o.tile_agg = w.tile_agg;
+    a.o.ordered_meta = w.meta;
+    a.o.ordered_totals = w.otot;
+    a.n_order_blocks = (g.ntiles * sb_order.batch + kEmitWaves - 1) / kEmitWaves;   // one wave per (sweep, tile)
+  }
   int mode = kModeDenseVec4;
   bool sc1 = false;
   int n_emit_blocks = 0;
@@ -2209,6 +2289,8 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     a.e.tile_meta = w.tile_meta;
     a.e.tile_agg = w.tile_agg;
     a.e.totals = num_cells_dev ? reinterpret_cast<int2 *>(num_cells_dev) : w.totals;
+    a.e.ordered_meta = w.meta;
+    a.e.ordered_totals = w.otot;
     a.e.sorted_pts = w.sorted_pts;
     a.e.out = pillars_dev;
     a.e.idx_out = reinterpret_cast<long long *>(indices_dev);
@@ -2235,11 +2317,14 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
       ++r;
     };
     if (pref_blocks > 0 && sb_emit.valid) {   // what the emit role reads
+      add(a.e.ordered_meta, (size_t)sb_emit.batch * a.e.P * 16);
       add(a.e.sorted_pts, (size_t)sb_emit.batch * a.e.ncap * 16);
-      a.pf.tile_agg = a.e.tile_agg;
-      a.pf.tile_meta = a.e.tile_meta;
-      a.pf.nlists = sb_emit.batch * a.e.g.ntiles;
-      a.pf.list_stride = 1 << a.e.g.tile_shift;
+    }
+    if (pref_blocks > 0 && sb_order.valid) {  // ... the order role: the occupied heads of the tiles' lists
+      a.pf.tile_agg = a.o.tile_agg;
+      a.pf.tile_meta = a.o.tile_meta;
+      a.pf.nlists = sb_order.batch * a.o.g.ntiles;
+      a.pf.list_stride = 1 << a.o.g.tile_shift;
     }
     if (pref_blocks > 0 && sb_tile.valid) {   // what the tile role reads
       add(a.t.mat, (size_t)sb_tile.batch * a.t.g.ntiles * a.t.nchunks_cap * 8);
@@ -2248,13 +2333,13 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     }
     a.n_pref_blocks = r > 0 || a.pf.nlists > 0 ? pref_blocks : 0;
   }
-  const long long nblocks = (long long)a.n_pref_blocks + a.n_tile_blocks + a.n_split_blocks + n_emit_blocks;
+  const long long nblocks = (long long)a.n_pref_blocks + a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks + n_emit_blocks;
   {
     static const int mix_env = [] {  // development knob: PP_STEP_MIX=m (1 = binning blocks first)
       const char *e = getenv("PP_STEP_MIX");
       return e ? std::max(1, atoi(e)) : 0;
     }();
-    const int nbin = a.n_tile_blocks + a.n_split_blocks;
+    const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
     a.mix = mix_env ? mix_env : 2;
     a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit_blocks / (a.mix - 1)) : 0;
     if (a.mix < 2) a.mix = 2, a.mix_groups = 0;
@@ -2303,10 +2388,11 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     }
   }
   if (sb_emit.valid && emitted) *emitted = 1;
-  // the batches move on: tiled -> due at the next call, split -> to be tiled, new -> split
-  sb_emit = sb_tile;
+  // the batches move on: ordered -> due at the next call, tiled -> to be ordered, split -> to be tiled, new -> split
+  sb_emit = sb_order;
+  sb_order = sb_tile;
   sb_tile = sb_new;
-  if (sb_new.valid) ctx->step_next_slot = ctx->step_next_slot % 3 + 1;
+  if (sb_new.valid) ctx->step_next_slot = ctx->step_next_slot % (pp_ctx::kVoxSlots - 1) + 1;
   return PP_OK;
 }
 

@@ -66,10 +66,10 @@ class PillarPipeline:
     def forward_pipelined(self, points, n_points=None):
         """The same forward as a software pipeline over consecutive batches (what the reference's
         DataLoader prefetch amounts to, train.py:120-121): the voxelizer's ONE launch per call runs the
-        split stage of ``points``, the tile stage of the previous call's batch and the emit stage of the
-        batch before that (``PillarVoxelizer.submit``), and the network runs on that oldest batch.
-        Returns its ``(cls, reg)`` -- or ``None`` for the first two calls.  ``points=None`` drains."""
-        B = self.voxelizer._inflight[1] if getattr(self.voxelizer, "_inflight", None) else None
+        split stage of ``points``, the tile and order stages of the two previous calls' batches and the emit
+        stage of the batch before those (``PillarVoxelizer.submit``), and the network runs on that oldest
+        batch.  Returns its ``(cls, reg)`` -- or ``None`` for the first ``PillarVoxelizer.LAG`` calls.  ``points=None`` drains."""
+        B = self.voxelizer._inflight[-1] if getattr(self.voxelizer, "_inflight", None) else None
         r = self.voxelizer.submit(points, n_points=n_points, out=self._buffers(B) if B else None)
         return None if r is None else self.model(r[0], r[1])
 

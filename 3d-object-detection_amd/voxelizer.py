@@ -211,23 +211,25 @@ class PillarVoxelizer:
                                "makes non-zero; use the dense path (voxelizer(points) + PPFeatureNet)")
 
     # -- software-pipelined mode ------------------------------------------------------------
-    def submit(self, points, n_points=None, out=None, return_counts=False):
-        """One step of the three-stage software pipeline (pp_voxelize_step_dev): ONE launch runs
-        the split stage of ``points``, the tile stage of the batch submitted one call ago and the
-        emit stage (the dense store) of the batch submitted TWO calls ago, side by side -- the way
-        the reference's DataLoader workers prepare the next batches while the model runs the
-        current one (train.py:120-121).
+    LAG = 3   # calls between handing a batch in and getting it back
 
-        Returns the ``(pillars, indices[, counts])`` of the batch submitted two calls ago
+    def submit(self, points, n_points=None, out=None, return_counts=False):
+        """One step of the software pipeline (pp_voxelize_step_dev): ONE launch runs the split stage
+        of ``points``, the tile stage of the batch submitted one call ago, the order stage of the one
+        before that and the emit stage (the dense store) of the batch submitted THREE calls ago, side
+        by side -- the way the reference's DataLoader workers prepare the next batches while the model
+        runs the current one (train.py:120-121).
+
+        Returns the ``(pillars, indices[, counts])`` of the batch submitted three calls ago
         (bit-identical to ``__call__`` on that batch), or ``None`` while the pipeline fills.
-        ``points=None`` drains (two such calls flush everything).  ``out`` buffers (optional)
+        ``points=None`` drains (``LAG`` such calls flush everything).  ``out`` buffers (optional)
         receive that older batch.  Everything runs on the current stream."""
         cfg = self.cfg
         P, N = cfg.max_pillars, cfg.max_points_per_pillar
         inflight = getattr(self, "_inflight", None)
         if inflight is None:
-            inflight = self._inflight = [None, None]       # [split done, tiled]: batch sizes
-        due = inflight[1]
+            inflight = self._inflight = [None, None, None]   # [split done, tiled, ordered]: batch sizes
+        due = inflight[2]
         pillars = indices = counts = None
         if due is not None:
             if out is None:
@@ -252,9 +254,9 @@ class PillarVoxelizer:
             vp(indices.data_ptr()) if indices is not None else None,
             vp(counts.data_ptr()) if counts is not None else None, ctypes.byref(emitted))
         if rc != _lib.PP_OK:
-            self._inflight = [None, None]
+            self._inflight = [None, None, None]
         _lib.check(rc, "pp_voxelize_step_dev")
-        self._inflight = [nxt[1] if nxt else None, inflight[0]]
+        self._inflight = [nxt[1] if nxt else None, inflight[0], inflight[1]]
         if due is None:
             return None
         assert emitted.value == 1
@@ -272,7 +274,7 @@ class PillarVoxelizer:
             r = self.submit(pts, n_points)
             if r is not None:
                 yield r
-        for _ in range(2):
+        for _ in range(self.LAG):
             r = self.submit(None)
             if r is not None:
                 yield r

@@ -13,8 +13,8 @@ own sweeps (seed = global sweep id), no data-path collective ("weak" scaling).
 
 The voxelizer runs software-pipelined over consecutive steps (the reference's DataLoader prefetch,
 train.py:120-121): ONE launch per step (k_step) does the split stage of batch i, the tile stage of batch
-i-1 and the emit stage of batch i-2 side by side, and the network consumes batch i-2 -- every step does
-one batch's worth of every stage (`--three-launch`: three dependent launches per step instead).
+i-1, the order stage of batch i-2 and the emit stage of batch i-3 side by side, and the network consumes
+batch i-3 -- every step does one batch's worth of every stage (`--three-launch`: three dependent launches per step instead).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant hand-written kernel: k_step (= the whole voxelizer), algorithmic bytes per
@@ -156,8 +156,8 @@ def roofline_record(kern_us, launches, bytes_per_launch, traffic=None, traffic_s
     k_emit (the dense store), with the sum of the three kernels beside it."""
     if "k_step" in kern_us:
         dur_us, name = kern_us["k_step"], ("pp::k_step<0,16> (one launch = the split stage of batch i, the tile "
-                                           "stage of batch i-1 and the emit stage of batch i-2: one batch's worth "
-                                           "of every voxelizer stage)")
+                                           "stage of batch i-1, the order stage of batch i-2 and the emit stage of "
+                                           "batch i-3: one batch's worth of every voxelizer stage)")
     else:
         dur_us, name = kern_us["k_emit"], "pp::k_emit<float,0>"
     achieved = bytes_per_launch / (dur_us * 1e-6) / 1e9
@@ -185,8 +185,8 @@ def vox_measure(vox, points, out, pipelined, iters=200, warm=20, kernel_iters=64
 
     def drain():
         if pipelined:
-            vox.submit(None, out=out)
-            vox.submit(None, out=out)
+            for _ in range(vox.LAG):
+                vox.submit(None, out=out)
     for _ in range(warm):
         call()
     torch.cuda.synchronize()
@@ -321,8 +321,8 @@ def main():
     def step():
         if a.mode == "fwd":
             # software pipeline over consecutive steps (the reference's DataLoader prefetch, train.py:120-121):
-            # ONE voxelizer launch = split(batch i) | tile(batch i-1) | emit(batch i-2); the network runs on
-            # batch i-2.  Every step does one batch's worth of every stage.
+            # ONE voxelizer launch = split(batch i) | tile(batch i-1) | order(batch i-2) | emit(batch i-3); the
+            # network runs on batch i-3.  Every step does one batch's worth of every stage.
             return pipe.forward_pipelined(points) if pipelined else pipe.forward(points)
         return train_step(pipe, gts)
 
@@ -338,7 +338,7 @@ def main():
         torch.cuda.synchronize()
         return shard.max_over_ranks(ctx, time.perf_counter() - t_, device=dev)
 
-    for _ in range(max(a.warmup, 2 if pipelined else 0)):   # (the first two pipelined calls only fill the pipeline)
+    for _ in range(max(a.warmup, PillarVoxelizer.LAG if pipelined else 0)):   # (the first LAG pipelined calls only fill the pipeline)
         step()
     pipe.voxelizer.set_timing(min(a.steps, 4096))
     elapsed = timed_loop(step, a.steps)
@@ -347,7 +347,8 @@ def main():
     bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
     three_e2e = None
     if pipelined:
-        pipe.forward_pipelined(None), pipe.forward_pipelined(None)      # drain
+        for _ in range(PillarVoxelizer.LAG):
+            pipe.forward_pipelined(None)                                # drain
         # the same forward with the voxelizer as three dependent launches per step, for comparison
         for _ in range(3):
             pipe.forward(points)
@@ -576,8 +577,8 @@ def main():
         }
         out["config"]["voxelizer"] = (
             "software-pipelined over consecutive steps: ONE launch per step (k_step) runs the split stage of "
-            "batch i, the tile stage of batch i-1 and the emit stage of batch i-2 side by side; the network "
-            "consumes batch i-2 (PillarPipeline.forward_pipelined).  Every step does one batch's worth of every "
+            "batch i, the tile stage of batch i-1, the order stage of batch i-2 and the emit stage of batch i-3 side "
+            "by side; the network consumes batch i-3 (PillarPipeline.forward_pipelined).  Every step does one batch's worth of every "
             "stage; `roofline.three_launch` is the same forward with three dependent launches per step"
             if pipelined else "three dependent launches per step (pp_voxelize_dev: k_split, k_tile, k_emit)")
         if fused is not None:

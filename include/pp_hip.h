@@ -88,22 +88,23 @@ int pp_voxelize_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
  * The same voxel stage, software-pipelined over consecutive batches -- what the reference gets from
  * DataLoader prefetching (train.py:120-121: the workers voxelize the next batches while the model
  * consumes the current one).  Inside one batch the three stages depend on each other (split ->
- * tile -> emit); across batches they do not.  One call = ONE launch (k_step) whose workgroups take
- * three roles side by side:
+ * tile -> order -> emit); across batches they do not.  One call = ONE launch (k_step) whose workgroups
+ * take roles side by side:
  *     the SPLIT stage of the batch handed in now            (points_dev),
  *     the TILE  stage of the batch handed in one call ago,
- *     the EMIT  stage (the dense store) of the batch handed in two calls ago -> pillars_dev ...
+ *     the ORDER stage (descriptors into pillar order) of the batch handed in two calls ago,
+ *     the EMIT  stage (the dense store) of the batch handed in THREE calls ago -> pillars_dev ...
  * The launch boundary is the only synchronisation; the latency-bound binning stages hide behind the
  * store.  Outputs are those of pp_voxelize_dev for the same input, bit for bit (the same code on the
  * same data; only the tile size differs, which the outputs do not depend on).
- *   points_dev    as pp_voxelize_dev's, or NULL (pipeline drain: two such calls flush it); read by
+ *   points_dev    as pp_voxelize_dev's, or NULL (pipeline drain: three such calls flush it); read by
  *                 THIS call's launch only
  *   n_points, batch, prm   describe points_dev (ignored when it is NULL)
- *   pillars_dev, indices_dev, num_cells_dev   receive the batch handed in TWO calls ago, with that
+ *   pillars_dev, indices_dev, num_cells_dev   receive the batch handed in THREE calls ago, with that
  *                 call's batch / prm shapes; may be NULL while no batch is due
  *   emitted       (may be NULL) 1 when this call wrote outputs, else 0
  * Everything runs on `stream`; plain calls on the same context are unaffected (own workspace).
- * Capturable in a HIP graph once the workspace exists (call it three times before the capture).
+ * Capturable in a HIP graph once the workspace exists (call it four times before the capture).
  */
 int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                          int64_t points_stride, const int32_t *n_points, int batch,

@@ -1,5 +1,5 @@
-"""k_step's roles timed one at a time (development aid): submit(points), submit(None), submit(None) makes three
-launches with ONE role each (split / tile / emit); their event pairs land in the timing ring in that order."""
+"""k_step's roles timed one at a time (development aid): submit(points) followed by LAG drain calls makes four
+launches with ONE stage role each (split / tile / order / emit); their event pairs land in the timing ring in that order."""
 import argparse
 import os
 import sys
@@ -27,14 +27,20 @@ vox = PillarVoxelizer(cfg)
 pts = torch.from_numpy(np.stack([synth.lidar_like(a.n, a.half, s) for s in range(a.batch)])).cuda()
 out = (torch.empty((a.batch, 9, a.P, a.N), dtype=torch.float32, device="cuda"),
        torch.empty((a.batch, a.P, 3), dtype=torch.int64, device="cuda"))
+def one():
+    vox.submit(pts)
+    for _ in range(vox.LAG):
+        vox.submit(None, out=out)
+
+
 for _ in range(5):
-    vox.submit(pts), vox.submit(None), vox.submit(None, out=out)
+    one()
 torch.cuda.synchronize()
-vox.set_timing(3 * a.iters)
+vox.set_timing(4 * a.iters)
 for _ in range(a.iters):
-    vox.submit(pts), vox.submit(None), vox.submit(None, out=out)
+    one()
 torch.cuda.synchronize()
-ms = np.array(vox.read_emit_ms(3 * a.iters)).reshape(-1, 3) * 1e3
+ms = np.array(vox.read_emit_ms(4 * a.iters)).reshape(-1, 4) * 1e3
 med = np.median(ms, axis=0)
 print(f"batch={a.batch} n={a.n} step={a.step} order={a.order}: k_step roles alone (median us): "
-      f"split {med[0]:.1f}  tile {med[1]:.1f}  emit {med[2]:.1f}")
+      f"split {med[0]:.1f}  tile {med[1]:.1f}  order {med[2]:.1f}  emit {med[3]:.1f}")
