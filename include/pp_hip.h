@@ -104,7 +104,9 @@ int pp_voxelize_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
  *                 call's batch / prm shapes; may be NULL while no batch is due
  *   emitted       (may be NULL) 1 when this call wrote outputs, else 0
  * Everything runs on `stream`; plain calls on the same context are unaffected (own workspace).
- * Capturable in a HIP graph once the workspace exists (call it four times before the capture).
+ * HIP graphs: a single call must NOT be captured and replayed -- the workspace slot of every stage
+ * rotates from call to call on the host, and a replay would repeat one call's slots.  (The plain
+ * pp_voxelize_dev is the capturable form.)
  */
 int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                          int64_t points_stride, const int32_t *n_points, int batch,
