@@ -262,6 +262,9 @@ def main():
     ap.add_argument("--three-launch", action="store_true",
                     help="fwd mode: time the headline with the voxelizer as three dependent launches per step "
                          "(pp_voxelize_dev) instead of the software-pipelined k_step")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline loop (no side legs): under rocprofv3 the kernel-stats average of "
+                         "k_step then covers exactly the launches `roofline` is computed from")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-feature-net side measurement")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the train_c3 sub-record")
@@ -271,6 +274,8 @@ def main():
                     help="nccl = RCCL over xGMI (the contract); gloo only to rehearse the multi-rank "
                          "code path on a box with fewer GPUs than ranks (all ranks share device 0)")
     a = ap.parse_args()
+    if a.headline_only:
+        a.no_cpu_baseline = a.no_fused = a.no_train_leg = a.no_stress = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has
@@ -346,7 +351,10 @@ def main():
     pipe.voxelizer.set_timing(0)
     bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
     three_e2e = None
-    if pipelined:
+    if pipelined and a.headline_only:
+        for _ in range(PillarVoxelizer.LAG):
+            pipe.forward_pipelined(None)                                # drain
+    elif pipelined:
         for _ in range(PillarVoxelizer.LAG):
             pipe.forward_pipelined(None)                                # drain
         # the same forward with the voxelizer as three dependent launches per step, for comparison
@@ -362,19 +370,21 @@ def main():
     # voxelizer alone (same resident inputs), for the per-stage picture: wall time per call (event timing off)
     # and kernel durations, software-pipelined and as three launches; default order and the row-major one; ONE
     # sweep per launch (BASELINE configs[3]'s per-GPU shape); BASELINE configs[0]'s 100x100 grid
-    vox_rec = vox_both(pipe.voxelizer, points, pipe._buffers(a.batch), bytes_per_launch)
-    vox_rm = PillarVoxelizer(VoxelConfig.square(HALF, STEP, P, N, order=_lib.ORDER_ROW_MAJOR), device=dev)
-    vox_rec["row_major_order"] = vox_both(vox_rm, points, pipe._buffers(a.batch), bytes_per_launch, iters=100)
-    del vox_rm
-    vox_rec["one_sweep_per_launch"] = vox_both(pipe.voxelizer, points[:1], pipe._buffers(1),
-                                               bytes_per_launch // a.batch)
-    c1cfg = VoxelConfig.square(C1["half"], C1["step"], C1["P"], C1["N"])
-    vox_c1 = PillarVoxelizer(c1cfg, device=dev)
-    vox_rec["c1_shapes"] = dict(
-        vox_both(vox_c1, points, pipe._buffers(a.batch), c1cfg.algorithmic_bytes(C1["n"]) * a.batch, iters=100),
-        what="BASELINE configs[0]'s shapes on the GPU: the same clouds on the 100x100 grid (1 m cells, up to "
-             "~380 points in a cell: long sequential running-mean chains, pillars.cpp:311-328)")
-    del vox_c1
+    vox_rec = None
+    if not a.headline_only:
+        vox_rec = vox_both(pipe.voxelizer, points, pipe._buffers(a.batch), bytes_per_launch)
+        vox_rm = PillarVoxelizer(VoxelConfig.square(HALF, STEP, P, N, order=_lib.ORDER_ROW_MAJOR), device=dev)
+        vox_rec["row_major_order"] = vox_both(vox_rm, points, pipe._buffers(a.batch), bytes_per_launch, iters=100)
+        del vox_rm
+        vox_rec["one_sweep_per_launch"] = vox_both(pipe.voxelizer, points[:1], pipe._buffers(1),
+                                                   bytes_per_launch // a.batch)
+        c1cfg = VoxelConfig.square(C1["half"], C1["step"], C1["P"], C1["N"])
+        vox_c1 = PillarVoxelizer(c1cfg, device=dev)
+        vox_rec["c1_shapes"] = dict(
+            vox_both(vox_c1, points, pipe._buffers(a.batch), c1cfg.algorithmic_bytes(C1["n"]) * a.batch, iters=100),
+            what="BASELINE configs[0]'s shapes on the GPU: the same clouds on the 100x100 grid (1 m cells, up to "
+                 "~380 points in a cell: long sequential running-mean chains, pillars.cpp:311-328)")
+        del vox_c1
 
     # next row: the feature net fused into the voxelizer -- the dense
     # [9,P,N] tensor is never built.  Reported beside the headline, not as it.
@@ -573,8 +583,9 @@ def main():
                             "in_timed_step": "none (sweeps shard; no data-path collective)" if a.mode == "fwd"
                             else "positive-count, gradient and loss-scalar all-reduces"},
             "roofline": roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc, three=three_e2e),
-            "voxelizer_only": vox_rec,
         }
+        if vox_rec is not None:
+            out["voxelizer_only"] = vox_rec
         out["config"]["voxelizer"] = (
             "software-pipelined over consecutive steps: ONE launch per step (k_step) runs the split stage of "
             "batch i, the tile stage of batch i-1, the order stage of batch i-2 and the emit stage of batch i-3 side "

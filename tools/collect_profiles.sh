@@ -25,6 +25,10 @@ pmc() { # name "counters" cmd...
 V="python3 $R/tools/bench_vox.py"
 C5="--n 200000 --half 100 --P 30000"
 stats bench python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline
+# the headline loop alone: k_step's average here covers exactly the launches bench.py's `roofline` times
+stats bench_headline python3 $R/bench.py --steps 50 --warmup 10 --headline-only
+pmc pmc_bench_headline_fetch FETCH_SIZE python3 $R/bench.py --steps 20 --warmup 5 --headline-only
+pmc pmc_bench_headline_write WRITE_SIZE python3 $R/bench.py --steps 20 --warmup 5 --headline-only
 for b in 1 4; do
   stats vox_c2_b${b}_step $V --batch $b --pipelined
   stats vox_c2_b${b}_three $V --batch $b

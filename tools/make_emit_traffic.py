@@ -44,8 +44,9 @@ out = {"source": f"profiles/{rnd}/pmc_*_summary.csv: rocprofv3 --pmc FETCH_SIZE 
        "note": "HBM bytes per launch = FETCH_SIZE + WRITE_SIZE medians (KiB * 1024) of the dominant kernel: k_step "
                "(software-pipelined calls: the whole voxelizer incl. its prefetch role) or k_emit (three-launch calls); "
                "their reads are narrow gathers / short rows, so the guide's x2 correction for wide streaming reads "
-               "is not applied"}
-for key, tag, prefix in (("step_batch4", "c2_b4_step", "pp::k_step"), ("step_batch1", "c2_b1_step", "pp::k_step"),
+               "is not applied; step_batch4 comes from the PMC passes over bench.py's own headline loop "
+               "(`bench.py --headline-only`), step_batch4_loop from the voxelizer-only loop"}
+for key, tag, prefix in (("step_batch4_loop", "c2_b4_step", "pp::k_step"), ("step_batch4", "bench_headline", "pp::k_step"), ("step_batch1", "c2_b1_step", "pp::k_step"),
                          ("batch4", "c2_b4_three", "pp::k_emit"), ("batch1", "c2_b1_three", "pp::k_emit"),
                          ("c5_batch4", "c5_b4_three", "pp::k_emit"), ("c5_step_batch1", "c5_b1_step", "pp::k_step")):
     tot, det = kernel_bytes(tag, prefix)
