@@ -458,3 +458,39 @@ def test_pipelined_mode_full_size(gpu, cfg, order):
         for t, o in zip(ts, outs):
             p, ix = a(t)
             assert torch.equal(p, o[0]) and torch.equal(ix, o[1])
+
+
+def test_pipelined_mode_edge_shapes(gpu):
+    """k_step at the edges: PP_MAX_BATCH = 32 ragged sweeps per call, the largest grids (3909 tiles of 4096
+    slots: the split role's 16 bins per thread, 47 KB of dynamic LDS), a batch with no point at all, a grid
+    beyond the limit refused -- every result bit-identical to the three-launch form."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    # 32 ragged sweeps
+    B = 32
+    clouds = torch.from_numpy(np.stack([synth.lidar_like(3000, 8.0, 100 + i) for i in range(B)])).to(gpu)
+    ns = [3000 - 37 * i for i in range(B)]
+    a, b = _vox(gpu, 8.0, 0.2, 700, 16, order=1), _vox(gpu, 8.0, 0.2, 700, 16, order=1)
+    want = a(clouds, n_points=ns, return_counts=True)
+    outs = [b.submit(clouds, n_points=ns, return_counts=True) for _ in range(2)] + \
+           [b.submit(None, return_counts=True) for _ in range(b.LAG)]
+    got = [o for o in outs if o is not None]
+    assert len(got) == 2 and all(torch.equal(x, y) for g in got for x, y in zip(g, want))
+    # largest grids, both orders, with a crowded spot; then nothing but out-of-range points
+    pts = synth.lidar_like(30000, 400.0, 9)
+    pts[:2000] = synth.lidar_like(2000, 3.0, 10)
+    t = torch.from_numpy(pts).to(gpu)[None]
+    far = torch.full((1, 500, 4), 1.0e6, device=gpu)
+    for order in (0, 1):
+        a, b = _vox(gpu, 400.0, 0.2, 20000, 8, order=order), _vox(gpu, 400.0, 0.2, 20000, 8, order=order)
+        seq = [t, far, t]
+        outs = list(b.stream(seq))
+        for x, o in zip(seq, outs):
+            p, ix = a(x)
+            assert torch.equal(p, o[0]) and torch.equal(ix, o[1])
+        assert not outs[1][0].any() and not outs[1][1].any()
+    too_big = PillarVoxelizer(VoxelConfig.square(450.0, 0.2, 100, 4), device=gpu)   # 4501^2 > 2^24 cells
+    with pytest.raises(ValueError, match="too large"):
+        too_big.submit(t)
+    assert too_big.submit(None) is None       # the refused batch left nothing in flight
