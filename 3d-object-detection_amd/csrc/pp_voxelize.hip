@@ -68,7 +68,6 @@ constexpr int KW = PP_KW;  // pillars per emit wave
 #define PP_CAPW (PP_KW >= 2 ? 32 * PP_KW : 64)
 #endif
 constexpr int CAPW = PP_CAPW;  // pooled bucket capacity (points, 4-padded per pillar) per emit wave
-constexpr int kPre = CAPW / 64;  // bucket entries prefetched per lane
 
 using u64 = unsigned long long;
 
@@ -675,12 +674,18 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
 // ------------------------------------------------------------------------- //
 // k_emit                                                                      //
 // ------------------------------------------------------------------------- //
-template <typename TIn>
+// CAP: the wave's pooled bucket capacity (points, 4-padded per pillar).  CAPW = 128 for the dense modes; the
+// fused feature-net mode takes 64: its waves write almost nothing, so its rate IS its occupancy, and the
+// smaller pool (14 KB per workgroup) with a tighter register bound gives it six waves per SIMD instead of
+// four (k_emit<pfn> 26.9 -> 23.3 us at C2 B=4; the dense modes lose with 64 on crowded waves -- C5 B=1
+// 20.7 -> 25.4 us, row-major 28.0 -> 30.7 us -- and keep 128).
+template <typename TIn, int CAP = CAPW>
 struct alignas(32) WaveLds {
-  TIn px[CAPW], py[CAPW], pz[CAPW], pr[CAPW];  // points, input order per pillar, 4-aligned buckets
+  static constexpr int kCap = CAP;
+  TIn px[CAP], py[CAP], pz[CAP], pr[CAP];  // points, input order per pillar, 4-aligned buckets
   union {
-    double4 cq[CAPW];  // chain operands of one point: {n/(n+1), x/(n+1), y/(n+1), z/(n+1)}
-    float feat[PP_NUM_FEATURES][CAPW];  // f32 features (dense / fused-net modes), aliases cq
+    double4 cq[CAP];  // chain operands of one point: {n/(n+1), x/(n+1), y/(n+1), z/(n+1)}
+    float feat[PP_NUM_FEATURES][CAP];  // f32 features (dense / fused-net modes), aliases cq
   } u;
   double mean[KW][3];
   double cx[KW], cy[KW];  // canvas_x / canvas_y (pillars.cpp:278-280), once per pillar
@@ -760,8 +765,8 @@ __device__ __forceinline__ void point_features(double x, double y, double z, dou
 
 // A pillar whose bucket does not fit the wave's LDS pool: its bucket is streamed
 // 64 points at a time, in input order (k_tile left it that way).
-template <typename TIn, int MODE>
-__device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k, int p,
+template <typename TIn, int MODE, int CAP>
+__device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, int k, int p,
                                 int lane, PfnAcc *acc = nullptr, float *rmax = nullptr,
                                 float *rmin = nullptr) {
   using Rec = typename Rec4<TIn>::type;
@@ -868,12 +873,13 @@ __device__ void emit_big_pillar(WaveLds<TIn> &L, const EmitArgs &a, int b, int k
 // straight from the CSR array, where every bucket already is in input order.
 // Leaves the f32 features of the live points in L.u.feat (dense vec4 mode) or
 // stores them (other modes).
-template <typename TIn, int MODE>
-__device__ __forceinline__ void emit_group(WaveLds<TIn> &L, const EmitArgs &a, int b, int p0,
+template <typename TIn, int MODE, int CAP>
+__device__ __forceinline__ void emit_group(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, int p0,
                                            int kbeg, int kend, int lane,
-                                           const typename Rec4<TIn>::type rec_r[kPre],
+                                           const typename Rec4<TIn>::type rec_r[CAP / 64],
                                            int segbeg[KW],
                                            int segpad[KW], int cntk[KW], int T) {
+  constexpr int kPre = CAP / 64;  // bucket entries prefetched per lane
   const int N = a.N;
   // LDS arrays use 4-aligned bucket starts (16-byte reads in the store pass)
 #pragma unroll
@@ -1031,7 +1037,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 enum { kPassEarly = 0, kPassLate = 1, kPassAll = 2 };
 
 template <int PASS, typename TIn, int AUX>
-__device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom &sg,
+__device__ __forceinline__ void store_slab(const WaveLds<TIn, CAPW> &L, const SlabGeom &sg,
                                            __amdgpu_buffer_rsrc_t rs, int lane,
                                            const int segbeg[KW]) {
   const v4i_t z4 = {0, 0, 0, 0};
@@ -1087,12 +1093,17 @@ __device__ __forceinline__ void store_slab(const WaveLds<TIn> &L, const SlabGeom
 
 // AUX: cache policy of the dense tensor's 16-byte stores (kAuxPlain / kAuxSc1, see launch_pipeline)
 // (the body of k_emit; k_step runs it as one of its roles: bx / b from a flat block id, nbx = blocks per sweep)
-template <typename TIn, int MODE, int AUX>
-__device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, int bx, int b, int nbx) {
+// ORDERED: the descriptors come in pillar order from the previous launch's order role (k_step) instead of
+// through the tile prefix (k_emit) -- a compile-time choice: the prefix path's registers (the lane's tile
+// counts, the scan) would otherwise cost every instance a wave per SIMD
+template <typename TIn, int MODE, int AUX, int CAP, bool ORDERED>
+__device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *lds, int bx, int b, int nbx) {
   using Rec = typename Rec4<TIn>::type;
+  constexpr int CAPW = CAP;        // (shadows the file-scope default inside this body)
+  constexpr int kPre = CAP / 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int N = a.N, P = a.P;
-  WaveLds<TIn> &L = lds[w];
+  WaveLds<TIn, CAP> &L = lds[w];
   // wave-uniform by construction; readfirstlane lets the compiler keep everything
   // derived from it (slab geometry, line masks, buffer offsets) in SGPRs
   const int p0 = __builtin_amdgcn_readfirstlane((bx * kEmitWaves + w) * KW);
@@ -1107,7 +1118,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
   //     barrier) and finds the tiles of its KW pillars with ballots.  (k_step: the previous launch's
   //     ORDER role already wrote the descriptors in pillar order -- one load instead of that chain.)
   int4 m = make_int4(-1, 0, 0, 0);
-  if (a.ordered_meta) {
+  if constexpr (ORDERED) {
     const int2 tt = a.ordered_totals[b];
     if (bx == 0 && w == 0 && lane == 0) a.totals[b] = tt;
     const int npil_o = min(tt.x, P);
@@ -1117,8 +1128,8 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
   const int nv = (ntiles + kWave - 1) / kWave;  // tiles per lane, <= 64
   const u64 *agg = a.tile_agg + (int64_t)b * ntiles;
   u64 mine = 0;
-  constexpr int kCv = 8;
-  unsigned cv[kCv] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // the lane's tiles' occupied-cell counts (all of them when nv <= 8)
+  constexpr int kCv = 4;
+  unsigned cv[kCv] = {0u, 0u, 0u, 0u};  // the lane's tiles' occupied-cell counts (all of them when nv <= 4)
   for (int e = 0; e < nv; ++e) {
     const int t = lane * nv + e;
     if (t < ntiles) {
@@ -1259,7 +1270,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
       // 4 sweeps per launch -- the second pass's issue slots, not its bytes.)
       if (!pooled || T == 0) {
         sg.late_lines = slab_late_lines(sg, sg.pooled);
-        store_slab<kPassEarly, TIn, AUX>(L, sg, rs, lane, segbeg);
+        if constexpr (MODE == kModeDenseVec4) store_slab<kPassEarly, TIn, AUX>(L, sg, rs, lane, segbeg);
       }
     } else {
       const int rowf = kw_eff * N;
@@ -1363,9 +1374,9 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
   }
   PP_STAMP_E(3);
   if (pooled) {
-    emit_group<TIn, MODE>(L, a, b, p0, 0, KW, lane, rec_r, segbeg, segpad, cnts, T);
+    emit_group<TIn, MODE, CAP>(L, a, b, p0, 0, KW, lane, rec_r, segbeg, segpad, cnts, T);
     PP_STAMP_E(4);
-    if (MODE == kModeDenseVec4) store_slab<kPassAll, TIn, AUX>(L, sg, rs, lane, segpad);
+    if constexpr (MODE == kModeDenseVec4) store_slab<kPassAll, TIn, AUX>(L, sg, rs, lane, segpad);
     if constexpr (MODE == kModePfn) {
 #pragma unroll
       for (int k = 0; k < KW; ++k) pfn_fold(k, segpad[k], min(cnts[k], N));
@@ -1383,7 +1394,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
       if (cnts[k] > CAPW) {
         if constexpr (MODE == kModePfn) {
           float mx = -INFINITY, mn = INFINITY;
-          emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane, &acc, &mx, &mn);
+          emit_big_pillar<TIn, MODE, CAP>(L, a, b, k, p0 + k, lane, &acc, &mx, &mn);
 #pragma unroll
           for (int kk = 0; kk < KW; ++kk)
             if (kk == k) {
@@ -1391,7 +1402,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
               acc.rmin[kk] = fminf(acc.rmin[kk], mn);
             }
         } else {
-          emit_big_pillar<TIn, MODE>(L, a, b, k, p0 + k, lane);
+          emit_big_pillar<TIn, MODE, CAP>(L, a, b, k, p0 + k, lane);
         }
         wave_sync();
         ++k;
@@ -1427,7 +1438,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
 #pragma unroll
       for (int it = 0; it < kPre; ++it)
         if (lane + it * kWave < graw) rec_r[it] = srec[lane + it * kWave];
-      emit_group<TIn, MODE>(L, a, b, p0, kb, k, lane, rec_r, sbg, spg, ckg, graw);
+      emit_group<TIn, MODE, CAP>(L, a, b, p0, kb, k, lane, rec_r, sbg, spg, ckg, graw);
       if constexpr (MODE == kModePfn) {
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk)
@@ -1441,7 +1452,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
         SlabGeom s1 = sg;
         s1.pooled = gmask;
         s1.late_lines = slab_late_lines(sg, gmask);
-        store_slab<kPassLate, TIn, AUX>(L, s1, rs, lane, spg);
+        if constexpr (MODE == kModeDenseVec4) store_slab<kPassLate, TIn, AUX>(L, s1, rs, lane, spg);
         wave_sync();
       }
     }
@@ -1454,10 +1465,12 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn> *lds, 
 #ifndef PP_EMIT_MINWAVES
 #define PP_EMIT_MINWAVES 4
 #endif
+constexpr int emit_cap(int mode) { return mode == kModePfn ? 64 : CAPW; }
+constexpr int emit_minwaves(int mode) { return mode == kModePfn ? 6 : PP_EMIT_MINWAVES; }
 template <typename TIn, int MODE, int AUX = 0>
-__global__ __launch_bounds__(kEmitThreads, PP_EMIT_MINWAVES) void k_emit(EmitArgs a) {
-  __shared__ WaveLds<TIn> lds[kEmitWaves];
-  emit_body<TIn, MODE, AUX>(a, lds, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+__global__ __launch_bounds__(kEmitThreads, emit_minwaves(MODE)) void k_emit(EmitArgs a) {
+  __shared__ WaveLds<TIn, emit_cap(MODE)> lds[kEmitWaves];
+  emit_body<TIn, MODE, AUX, emit_cap(MODE), false>(a, lds, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1637,7 +1650,7 @@ __global__ __launch_bounds__(kStepThreads, PP_EMIT_MINWAVES) void k_step(StepArg
   }
   id -= a.n_split_blocks;
   const int b = id / a.emit_nbx, bx = id - b * a.emit_nbx;
-  emit_body<float, MODE, AUX>(a.e, reinterpret_cast<WaveLds<float> *>(step_smem), bx, b, a.emit_nbx);
+  emit_body<float, MODE, AUX, CAPW, true>(a.e, reinterpret_cast<WaveLds<float, CAPW> *>(step_smem), bx, b, a.emit_nbx);
 }
 
 // ------------------------------------------------------------------------- //
