@@ -772,7 +772,10 @@ __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, 
   using Rec = typename Rec4<TIn>::type;
   const int cnt = L.cnt[k];
   const Rec *sp = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + L.start[k];
-  double m0 = 0, m1 = 0, m2 = 0;
+  // the chain of coordinate c = lane % 3 in every lane (lanes 0, 1, 2 are read back): two f64 operations per
+  // step instead of six for the three chains in sequence -- the wave pays per operation, not per lane
+  const int cc = lane % 3;
+  double m = 0;
   for (int base = 0; base < cnt; base += kWave) {
     const int i = base + lane;
     if (i < cnt) {
@@ -786,39 +789,30 @@ __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, 
     }
     wave_sync();
     const int c = min(kWave, cnt - base);
-    // uniform: every lane carries the chain.  The chain is serial in m, its operands are not: four
-    // points' operands are fetched ahead of the four dependent steps (one LDS round trip per point
-    // otherwise -- a 381-point cell of BASELINE config 1 is 381 of them).
+    // The chain is serial in m, its operands are not: four points' operands are fetched ahead of the four
+    // dependent steps (one LDS round trip per point otherwise -- a 381-point cell of BASELINE config 1 is
+    // 381 of them).
+    const double *op = reinterpret_cast<const double *>(&L.u.cq[0]);
     int t = 0;
     if (base == 0) {
-      m0 = (double)L.px[0];
-      m1 = (double)L.py[0];
-      m2 = (double)L.pz[0];
+      m = cc == 0 ? (double)L.px[0] : cc == 1 ? (double)L.py[0] : (double)L.pz[0];
       t = 1;
     }
     for (; t + 3 < c; t += 4) {
-      const double4 o0 = L.u.cq[t], o1 = L.u.cq[t + 1], o2 = L.u.cq[t + 2], o3 = L.u.cq[t + 3];
-      m0 = m0 * o0.x + o0.y;
-      m1 = m1 * o0.x + o0.z;
-      m2 = m2 * o0.x + o0.w;
-      m0 = m0 * o1.x + o1.y;
-      m1 = m1 * o1.x + o1.z;
-      m2 = m2 * o1.x + o1.w;
-      m0 = m0 * o2.x + o2.y;
-      m1 = m1 * o2.x + o2.z;
-      m2 = m2 * o2.x + o2.w;
-      m0 = m0 * o3.x + o3.y;
-      m1 = m1 * o3.x + o3.z;
-      m2 = m2 * o3.x + o3.w;
+      const double s0 = op[4 * t], v0 = op[4 * t + 1 + cc], s1 = op[4 * t + 4], v1 = op[4 * t + 5 + cc];
+      const double s2 = op[4 * t + 8], v2 = op[4 * t + 9 + cc], s3 = op[4 * t + 12], v3 = op[4 * t + 13 + cc];
+      m = m * s0 + v0;
+      m = m * s1 + v1;
+      m = m * s2 + v2;
+      m = m * s3 + v3;
     }
-    for (; t < c; ++t) {
-      const double4 o = L.u.cq[t];
-      m0 = m0 * o.x + o.y;
-      m1 = m1 * o.x + o.z;
-      m2 = m2 * o.x + o.w;
-    }
+    for (; t < c; ++t) m = m * op[4 * t] + op[4 * t + 1 + cc];
     wave_sync();
   }
+  const int mlo = __double2loint(m), mhi = __double2hiint(m);
+  const double m0 = __hiloint2double(__builtin_amdgcn_readlane(mhi, 0), __builtin_amdgcn_readlane(mlo, 0));
+  const double m1 = __hiloint2double(__builtin_amdgcn_readlane(mhi, 1), __builtin_amdgcn_readlane(mlo, 1));
+  const double m2 = __hiloint2double(__builtin_amdgcn_readlane(mhi, 2), __builtin_amdgcn_readlane(mlo, 2));
   const double mean[3] = {m0, m1, m2};
   const double cx = L.cx[k], cy = L.cy[k];
   const int N = a.N;
@@ -909,44 +903,34 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn, CAP> &L, const EmitArgs 
     }
   }
   wave_sync();
-  // sequential running mean per pillar, pillars.cpp:311-328 (one lane each)
-  if (lane < KW) {
+  // sequential running mean, pillars.cpp:311-328: m <- m * (n/(n+1)) + v/(n+1), one chain per pillar and
+  // coordinate.  A chain is serial, and an f64 operation occupies the pipe for the whole wave whatever the
+  // number of active lanes -- so the 3*KW chains run SIDE BY SIDE, one lane each (two f64 operations per
+  // step for all of them; one lane per pillar with its x, y, z chains in sequence cost six).
+  if (lane < 3 * KW) {
+    const int kq = lane / 3, cq_ = lane - 3 * kq;
     int sb = 0, sc = 0;
 #pragma unroll
     for (int kk = 0; kk < KW; ++kk) {
-      sb = (lane == kk) ? segpad[kk] : sb;
-      sc = (lane == kk) ? cntk[kk] : sc;
+      sb = (kq == kk) ? segpad[kk] : sb;
+      sc = (kq == kk) ? cntk[kk] : sc;
     }
     if (sc > 0) {
-      double m0 = (double)L.px[sb], m1 = (double)L.py[sb], m2 = (double)L.pz[sb];
-      // the chain is serial in m, but its operands are not: fetch four points' operands
-      // ahead of the four dependent mul+add steps that consume them
+      double m = cq_ == 0 ? (double)L.px[sb] : cq_ == 1 ? (double)L.py[sb] : (double)L.pz[sb];
+      // operands of point n: {scale, x', y', z'} = four doubles; the chain is serial in m, its operands are
+      // not: four points' operands are fetched ahead of the four dependent mul+add steps
+      const double *op = reinterpret_cast<const double *>(&L.u.cq[sb]);
       int n = 1;
       for (; n + 3 < sc; n += 4) {
-        const double4 o0 = L.u.cq[sb + n], o1 = L.u.cq[sb + n + 1], o2 = L.u.cq[sb + n + 2],
-                      o3 = L.u.cq[sb + n + 3];
-        m0 = m0 * o0.x + o0.y;
-        m1 = m1 * o0.x + o0.z;
-        m2 = m2 * o0.x + o0.w;
-        m0 = m0 * o1.x + o1.y;
-        m1 = m1 * o1.x + o1.z;
-        m2 = m2 * o1.x + o1.w;
-        m0 = m0 * o2.x + o2.y;
-        m1 = m1 * o2.x + o2.z;
-        m2 = m2 * o2.x + o2.w;
-        m0 = m0 * o3.x + o3.y;
-        m1 = m1 * o3.x + o3.z;
-        m2 = m2 * o3.x + o3.w;
+        const double s0 = op[4 * n], v0 = op[4 * n + 1 + cq_], s1 = op[4 * n + 4], v1 = op[4 * n + 5 + cq_];
+        const double s2 = op[4 * n + 8], v2 = op[4 * n + 9 + cq_], s3 = op[4 * n + 12], v3 = op[4 * n + 13 + cq_];
+        m = m * s0 + v0;
+        m = m * s1 + v1;
+        m = m * s2 + v2;
+        m = m * s3 + v3;
       }
-      for (; n < sc; ++n) {
-        const double4 o = L.u.cq[sb + n];
-        m0 = m0 * o.x + o.y;
-        m1 = m1 * o.x + o.z;
-        m2 = m2 * o.x + o.w;
-      }
-      L.mean[lane][0] = m0;
-      L.mean[lane][1] = m1;
-      L.mean[lane][2] = m2;
+      for (; n < sc; ++n) m = m * op[4 * n] + op[4 * n + 1 + cq_];
+      L.mean[kq][cq_] = m;
     }
   }
   wave_sync();
@@ -1577,7 +1561,7 @@ constexpr int kStepThreads = kStepWaves * kWave;
 static_assert(kStepWaves == kEmitWaves, "the emit role is k_emit's workgroup");
 
 template <int MODE, int AUX>
-__global__ __launch_bounds__(kStepThreads, PP_EMIT_MINWAVES) void k_step(StepArgs a) {
+__global__ __launch_bounds__(kStepThreads, 5) void k_step(StepArgs a) {   // five waves per SIMD: <= 96 VGPRs
   extern __shared__ __attribute__((aligned(32))) unsigned char step_smem[];
   int id = (int)blockIdx.x;
   if (id < a.n_pref_blocks) {
