@@ -776,10 +776,14 @@ __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, 
   // step instead of six for the three chains in sequence -- the wave pays per operation, not per lane
   const int cc = lane % 3;
   double m = 0;
+  Rec nxt;
+  nxt.x = nxt.y = nxt.z = nxt.w = 0;
+  if (lane < cnt) nxt = sp[lane];
   for (int base = 0; base < cnt; base += kWave) {
     const int i = base + lane;
+    const Rec rec = nxt;
+    if (i + kWave < cnt) nxt = sp[i + kWave];  // the next 64 records travel while this chunk's chain runs
     if (i < cnt) {
-      const Rec rec = sp[i];
       const double n = (double)i, den = n + 1;
       L.px[lane] = rec.x;
       L.py[lane] = rec.y;
