@@ -2397,6 +2397,15 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
   return PP_OK;
 }
 
+extern "C" int pp_voxelize_step_reset(pp_ctx_t *ctx) {
+  if (!ctx) {
+    set_error("ctx is NULL");
+    return PP_ERR_VALUE;
+  }
+  for (auto &sb : ctx->step_batch) sb.valid = false;   // nothing to undo on the device: every role reads only
+  return PP_OK;                                         // what an earlier launch of ITS batch wrote
+}
+
 static int voxelize_pfn_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev,
                              int64_t points_stride, const int32_t *n_points, int batch,
                              const pp_voxel_params_t *prm, const float *pfn_params_dev,

@@ -267,6 +267,11 @@ class PillarVoxelizer:
             _lib.check(rc, "pp_subtract_mean_dev")
         return (pillars, indices, counts) if return_counts else (pillars, indices)
 
+    def reset_stream(self):
+        """Forgets the batches in flight in ``submit``'s pipeline (their results are never returned)."""
+        _lib.check(_lib.lib().pp_voxelize_step_reset(self._ctx.handle), "pp_voxelize_step_reset")
+        self._inflight = [None, None, None]
+
     def stream(self, batches, n_points=None):
         """Generator over an iterable of point tensors: yields ``(pillars, indices)`` per batch, in
         order, from the software pipeline of ``submit``."""

@@ -113,6 +113,10 @@ int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                          const pp_voxel_params_t *prm, float *pillars_dev,
                          int64_t *indices_dev, int32_t *num_cells_dev, int *emitted);
 
+/* Forgets the batches in flight in pp_voxelize_step_dev's pipeline (end of an epoch, an abandoned
+ * stream): the next call starts an empty pipeline.  Nothing is launched. */
+int pp_voxelize_step_reset(pp_ctx_t *ctx);
+
 /*
  * The optional last step of the voxel stage (data/dataset.py:102-105): pillar -= data_mean,
  * the per-element dataset mean of the [9,P,N] tensor (pillar_means.pkl), f32 - f32 like the

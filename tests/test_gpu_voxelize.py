@@ -490,6 +490,11 @@ def test_pipelined_mode_edge_shapes(gpu):
             p, ix = a(x)
             assert torch.equal(p, o[0]) and torch.equal(ix, o[1])
         assert not outs[1][0].any() and not outs[1][1].any()
+    # an abandoned stream: reset, then the pipeline starts empty again
+    b.submit(t), b.submit(far)
+    b.reset_stream()
+    outs = list(b.stream([t]))
+    assert len(outs) == 1 and torch.equal(outs[0][0], a(t)[0])
     too_big = PillarVoxelizer(VoxelConfig.square(450.0, 0.2, 100, 4), device=gpu)   # 4501^2 > 2^24 cells
     with pytest.raises(ValueError, match="too large"):
         too_big.submit(t)
