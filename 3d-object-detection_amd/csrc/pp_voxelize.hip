@@ -27,6 +27,12 @@
 //            381-383), dense [9,P,N] f32 store incl. the zero padding, [P,3]
 //            int64 indices
 //
+//
+// Streaming form (pp_voxelize_step_dev): the same stages -- plus an ORDER stage that copies the
+// tiles' descriptor lists into pillar order one launch ahead -- of FOUR consecutive batches as
+// roles of ONE launch per call (k_step): split(batch i) | tile(i-1) | order(i-2) | emit(i-3),
+// the launch boundary being the only synchronisation.
+//
 // The path is HBM-bound: 97% of the bytes are the dense store of
 // k_emit.  Every 128-byte line of the output is written once, whole.
 // All arithmetic that decides a value is f64 with contraction disabled
