@@ -1,5 +1,5 @@
 """Host drop-in timing (PCIe-inclusive): pillars.create_pillars / make_ious on numpy arrays,
-next to the CPU oracle's reference-style implementation.  Development aid."""
+next to the CPU oracle's reference-style implementation.  Development aid; lives under tests/ because it times the CPU oracle beside the product (only tests/, smoke() and bench.py's cpu_baseline may touch oracle/)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
