@@ -499,3 +499,33 @@ def test_pipelined_mode_edge_shapes(gpu):
     with pytest.raises(ValueError, match="too large"):
         too_big.submit(t)
     assert too_big.submit(None) is None       # the refused batch left nothing in flight
+
+
+def test_pipelined_mode_soak(gpu):
+    """Three hundred back-to-back submits cycling through inputs of different sizes and batch shapes (so that the
+    four workspace slots are re-laid-out while older batches are still in flight), cache-flushing traffic every
+    few calls: every returned batch equals the plain call's result for ITS input."""
+    import torch
+    from pp_amd import synth
+    half, step, P, N = 30.0, 0.25, 5000, 32
+    plain, vs = _vox(gpu, half, step, P, N, order=1), _vox(gpu, half, step, P, N, order=1)
+    inputs = []
+    for i, (B, n) in enumerate([(1, 30000), (3, 8000), (2, 15000), (4, 4000), (1, 500)]):
+        inputs.append(torch.from_numpy(np.stack([synth.lidar_like(n, half, 900 + 10 * i + s) for s in range(B)])).to(gpu))
+    want = [tuple(x.clone() for x in plain(t)) for t in inputs]
+    junk = torch.empty(512 << 20, dtype=torch.uint8, device=gpu)
+    order, got = [], []
+    for k in range(300):                      # no host synchronisation inside: the launches queue up back to back
+        i = (k * 7 + k // 5) % len(inputs)
+        order.append(i)
+        r = vs.submit(inputs[i])
+        if k % 11 == 0:
+            junk.zero_()
+        if r is not None:
+            got.append(r)
+    got += [vs.submit(None) for _ in range(vs.LAG)]
+    torch.cuda.synchronize()
+    assert len(got) == 300
+    bad = [k for k, (r, i) in enumerate(zip(got, order))
+           if not (torch.equal(r[0], want[i][0]) and torch.equal(r[1], want[i][1]))]
+    assert not bad, bad[:10]
