@@ -1460,7 +1460,10 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
 #define PP_EMIT_MINWAVES 4
 #endif
 constexpr int emit_cap(int mode) { return mode == kModePfn ? 64 : CAPW; }
-constexpr int emit_minwaves(int mode) { return mode == kModePfn ? 6 : PP_EMIT_MINWAVES; }
+#ifndef PP_PFN_MINWAVES
+#define PP_PFN_MINWAVES 6
+#endif
+constexpr int emit_minwaves(int mode) { return mode == kModePfn ? PP_PFN_MINWAVES : PP_EMIT_MINWAVES; }
 template <typename TIn, int MODE, int AUX = 0>
 __global__ __launch_bounds__(kEmitThreads, emit_minwaves(MODE)) void k_emit(EmitArgs a) {
   __shared__ WaveLds<TIn, emit_cap(MODE)> lds[kEmitWaves];
