@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstring>
 
 namespace pp {
@@ -57,6 +58,8 @@ struct TargetArgs {
   // anchor i = (y*fm_w + x)*per_cell + d; centre ((x+.5)/fm_scale, (y+.5)/fm_scale, z_d)
   int grid, fm_w, per_cell;
   double fm_scale;
+  double inv_scale;     // 1 / fm_scale when fm_scale is a power of two (then c * inv_scale IS c / fm_scale, bit for
+                        // bit, and an f64 division costs a wave ~15 instructions), else 0: divide
   const double *types;  // [per_cell][kTypeCols]: corner offsets x0,y0..x3,y3, w, l, h, yaw, z
   int a_center_cols, g_center_cols;  // doubles per row of a_centers / g_centers_img (3; the dense-matrix API: >= 2)
   const double *g_corners, *g_centers_img, *g_centers, *g_wlh, *g_yaw;
@@ -72,7 +75,12 @@ struct TargetArgs {
   // column maximum}, the maximum's bits; at most G entries per workgroup
   ColEntry *cand;        // [workgroups * G]
   unsigned *cand_count;  // entries appended
-  unsigned *ticket;      // workgroups finished
+  unsigned *ticket;      // groups of workgroups finished (second level)
+  // First level: workgroup w bumps ticket1[(w >> ticket_shift) * kTicketPad]; the last of its group resets
+  // that word and bumps `ticket`.  (One word for all workgroups: atomics on one address are served one
+  // after the other, ~25 ns each -- 2110 workgroups of the reference's anchor set queued 50 us there.)
+  unsigned *ticket1;
+  int ticket_shift;
   // outputs
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
@@ -80,10 +88,47 @@ struct TargetArgs {
 
 constexpr int kTypeCols = 13;
 
+// A batch of samples in one launch (grid.y = sample; the reference prepares BATCH_SIZE samples per step,
+// config.py:135, each through create_target, data/dataset.py:113-118): the anchors are shared, sample b's
+// ground truths are rows [g_off[b], g_off[b+1]) of the concatenated g_* arrays, its outputs follow sample
+// b-1's, and every piece of scratch the samples' tails depend on (list, counter, ticket, column words) is
+// the sample's own -- a shared ticket would let one sample's tail read another one's unfinished list.
+struct TargetBatch {
+  int g_off[PP_MAX_BATCH + 1];
+};
+constexpr int kCounterStride = 32;  // unsigned words between two samples' counters (128 B: own cache lines)
+constexpr int kTicketPad = 16;      // unsigned words between two first-level tickets (64 B)
+
 struct AnchorId {
   int d;          // anchor type within the cell
   double cx, cy;  // centre
 };
+
+// the view of sample b: everything per-sample moved to its rows (all wave-uniform: SGPR arithmetic)
+__device__ __forceinline__ void sample_view(TargetArgs &t, const TargetBatch &bt, int b, unsigned nwg) {
+  const int o = bt.g_off[b];
+  t.G = bt.g_off[b + 1] - o;
+  t.g_corners += (int64_t)o * 8;
+  t.g_centers_img += (int64_t)o * t.g_center_cols;
+  t.g_centers += (int64_t)o * 3;
+  t.g_wlh += (int64_t)o * 3;
+  t.g_yaw += o;
+  t.g_class += o;
+  t.col_max += o;
+  t.col_win += o;
+  t.cand += (size_t)nwg * (size_t)o;  // sample b appends at most nwg * G_b entries
+  t.cand_count += b * kCounterStride;
+  t.ticket += b * kCounterStride;
+  t.ticket1 += (size_t)b * (((nwg - 1u) >> t.ticket_shift) + 1u) * kTicketPad;
+  t.cls_targets += (int64_t)b * t.A * t.num_classes;
+  t.reg_targets += (int64_t)b * t.A * 9;
+}
+
+// centre coordinate of feature-map cell x: (x + .5) / fm_scale (box_utils.py:137-138), same f64 result
+__device__ __forceinline__ double cell_centre(const TargetArgs &t, unsigned x) {
+  const double c = (double)x + 0.5;
+  return t.inv_scale != 0.0 ? c * t.inv_scale : c / t.fm_scale;
+}
 
 __device__ __forceinline__ AnchorId anchor_id(const TargetArgs &t, int64_t i) {
   AnchorId a;
@@ -91,8 +136,8 @@ __device__ __forceinline__ AnchorId anchor_id(const TargetArgs &t, int64_t i) {
     const unsigned iu = (unsigned)i, cell = iu / (unsigned)t.per_cell;
     a.d = (int)(iu - cell * (unsigned)t.per_cell);
     const unsigned y = cell / (unsigned)t.fm_w, x = cell - y * (unsigned)t.fm_w;
-    a.cx = ((double)x + 0.5) / t.fm_scale;  // box_utils.py:137-138, same f64 operations
-    a.cy = ((double)y + 0.5) / t.fm_scale;
+    a.cx = cell_centre(t, x);
+    a.cy = cell_centre(t, y);
   } else {
     a.d = 0;
     a.cx = t.a_centers[i * t.a_center_cols];
@@ -120,7 +165,7 @@ __device__ __forceinline__ void anchor_corners(const TargetArgs &t, int64_t i, d
 
 // utils/box_utils.py:70-109 on plain values: one whole row on one lane -- the tail's forced rows (its
 // only use: inlined there; as an out-of-line function its callee-saved registers went through scratch
-// memory).  The workgroups' positives use target_component, 8 lanes per row.
+// memory).  The workgroups' positives and the usual tail use target_quotient / _logratio / _angle, one kind per wave.
 struct Row9 {
   float v[9];
 };
@@ -184,27 +229,31 @@ __device__ __forceinline__ BoxVals gt_vals(const TargetArgs &t, int j) {
   return g;
 }
 
-// target_row spread over the 8 lanes of a group: lane v returns element v + 1 of the row (element 0
-// is the constant 1).  One row on one lane is a 2 us chain (a square root, six divisions, three
-// logs and a sine, one after the other); here the three quotients, the three logs and the sine
-// each run once for the whole group.  Same operations on the same operands: same bits.
-__device__ __forceinline__ float target_component(const BoxVals &a, const BoxVals &g, double canvas_height, int v) {
+// target_row's values sorted by what they cost, for callers that give each WAVE one kind (a wave
+// executes every branch its lanes take: with the kinds mixed inside a wave every row pays for a square
+// root, divisions, a logarithm AND a sine -- 2.6 us for the 40 forced rows of a tail).  Same
+// expressions on the same operands as target_row: same bits.  Operands come as
+// plain values (picking fields of a struct by a run-time index made the compiler spill it to scratch).
+__device__ __forceinline__ float target_quotient(double g_c, double a_c, double a_w, double a_l, double a_h,
+                                                 double canvas_height, int c) {
+  const double ad = sqrt(a_w * a_w + a_l * a_l);
+  const double gq = c == 1 ? (canvas_height - 1) - g_c : g_c;  // box_utils.py:83
+  const double den = c < 2 ? ad : a_h;
+  return (float)((gq - a_c) / den);  // dx, dy, dz
+}
+__device__ __forceinline__ float target_logratio(double g_s, double a_s) {
+  return (float)log(g_s / a_s);  // dw, dl, dh
+}
+__device__ __forceinline__ void target_angle(double g_yaw, double a_yaw, float *dt, float *ort) {
   const double pi = 3.141592653589793;  // np.pi
-  const double ad = sqrt(a.w * a.w + a.l * a.l);
-  const double gy = (canvas_height - 1) - g.y;  // box_utils.py:83
-  double gt = g.yaw;
+  double gt = g_yaw;
   if (gt <= pi && gt >= pi / 2)  // box_utils.py:92-95
     gt -= pi;
   else if (gt >= -pi && gt <= -pi / 2)
     gt += pi;
-  const double df = gt - a.yaw;
-  const double num = v == 0 ? g.x - a.x : v == 1 ? gy - a.y : v == 2 ? g.z - a.z : v == 3 ? g.w : v == 4 ? g.l : g.h;
-  const double den = v < 2 ? ad : v == 2 ? a.h : v == 3 ? a.w : v == 4 ? a.l : a.h;
-  double r = num / den;  // dx, dy, dz
-  if (v >= 3 && v <= 5) r = log(r);  // dw, dl, dh
-  if (v == 6) r = sin(df);
-  if (v == 7) r = ((df <= pi && df >= pi / 2) || (df >= -pi && df <= -pi / 2)) ? 1.0 : 0.0;  // :99-102
-  return (float)r;
+  const double df = gt - a_yaw;
+  *dt = (float)sin(df);
+  *ort = ((df <= pi && df >= pi / 2) || (df >= -pi && df <= -pi / 2)) ? 1.0f : 0.0f;  // :99-102
 }
 
 __device__ __forceinline__ Row9 make_target_dev(const TargetArgs &t, int64_t i, int j) {
@@ -238,8 +287,8 @@ constexpr int kGtChunk = 64;    // ground truths per gate pass: one mask bit eac
 constexpr int kPairCap = 512;   // pairs per window
 constexpr int kGroup = 8;       // lanes per pair: a quad clipped by a quad has at most 8 vertices
 constexpr int kPairsPerRound = kTgtThreads / kGroup;
-constexpr int kStageCols = 16;  // widest target row staged in LDS
-constexpr int kForcedLds = 2048;  // ground truths whose column results the tail keeps in LDS
+constexpr int kStageCols = 10;  // widest target row staged in LDS (the reference has 9 classes, config.py:97; wider rows take scalar stores)
+constexpr int kForcedLds = 1024;  // ground truths whose column results the tail keeps in LDS
 
 constexpr int kMaxNP = 1;        // pairs a group of 8 lanes clips side by side: 2 (and 3) measured no faster than
                                  // as many rounds of one -- a round is issue-bound -- and cost 30 VGPRs
@@ -251,11 +300,13 @@ struct TgtLds {
   double2 gk[kGtChunk][4];                // their corners
   double garea[kGtChunk];                 // their declared-orientation areas
   union {
-    double2 poly[kMaxNP][kPairsPerRound][kGroup + 1];  // hand-over of a clip pass's output rings (+ a spare slot)
-    float stage[kTgtThreads * kStageCols];         // target rows on their way out
+    struct {                              // the clip phase's ...
+      double2 poly[kMaxNP][kPairsPerRound][kGroup + 1];  // hand-over of a clip pass's output rings (+ a spare slot)
+      double terms[kMaxNP][kPairsPerRound][kGroup];      // shoelace terms on their way to the ordered sum
+      double iou[kPairCap];
+    };
+    float stage[kTgtThreads * kStageCols];  // ... and, after it, the target rows on their way out
   };
-  double terms[kMaxNP][kPairsPerRound][kGroup];  // shoelace terms on their way to the ordered sum
-  double iou[kPairCap];
   u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
   int carg[kGtChunk];                     // first anchor reaching it
   unsigned short pair_lane[kPairCap], pair_gt[kPairCap];
@@ -264,11 +315,14 @@ struct TgtLds {
   double types[kLdsTypes][kTypeCols];
   double bbox[kTgtWaves][4];
   int woff[kTgtWaves];
-  int is_last;
+  int is_last, contrib;
 };
+constexpr int kTailGt = 128;  // ground truths whose box values the tail stages in LDS for the forced rows
 struct TailLds {
   u64 colmax[kForcedLds];
   u64 colwin[kForcedLds];
+  double gtv[kTailGt][7];                 // x, y, z, w, l, h, yaw of the sample's ground truths
+  double types[kLdsTypes][kTypeCols];     // the anchor type table again (the workgroup's copy lies under colmax)
 };
 static_assert(sizeof(TailLds) <= sizeof(TgtLds), "the tail reuses the workgroup's LDS");
 constexpr size_t kTgtLdsBytes = sizeof(TgtLds) > sizeof(TailLds) ? sizeof(TgtLds) : sizeof(TailLds);
@@ -450,6 +504,15 @@ __device__ __forceinline__ void store_rows(float *dst, const float *stage, int t
   for (int k = (n4 << 2) + tid; k < total; k += kTgtThreads)
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stage[k]), rs, k * 4, 0, kAuxSc1);
 }
+// `total` zero floats to dst (16-byte aligned): the rows of a workgroup without a positive anchor
+// (most of them) go out straight from registers, no LDS stage, no barrier
+__device__ __forceinline__ void store_zero_rows(float *dst, int total, int tid) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, total * 4, 0x00020000);
+  const int n4 = total >> 2;
+  const v4u z = {0u, 0u, 0u, 0u};
+  for (int k = tid; k < n4; k += kTgtThreads) __builtin_amdgcn_raw_buffer_store_b128(z, rs, k * 16, 0, kAuxSc1);
+  for (int k = (n4 << 2) + tid; k < total; k += kTgtThreads) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, k * 4, 0, kAuxSc1);
+}
 __device__ __forceinline__ void store_f32_sc1(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -461,7 +524,7 @@ __device__ __forceinline__ void store_f32_sc1(float *p, float v) {
 // (0 / all ones), which only this workgroup touches: atomics and sc1 loads meet in its XCD's L2.
 #ifdef PP_IOU_STAMPS
 __device__ unsigned long long g_iou_stamps[16 * 4096];
-#define IOU_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_iou_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define IOU_STAMP(k) do { const unsigned wg_ = blockIdx.x * gridDim.y + blockIdx.y; if (threadIdx.x == 0 && wg_ < 4096) g_iou_stamps[wg_ * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define IOU_STAMP(k) do {} while (0)
 #endif
@@ -484,6 +547,21 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
       T.colwin[j] = ~0ull;
     }
   __syncthreads();
+  // The forced rows' operands come along with the list: the ground truths' box values and the type
+  // table are loaded now (in flight with the entries) and wait in LDS -- read when the rows are due, they
+  // were a second and third memory round trip at the very end of the launch.
+  const bool gt_staged = IN_LDS && G <= kTailGt;
+  const bool ty_staged = IN_LDS && t.grid && t.per_cell <= kLdsTypes;
+  double pre_g[4] = {0.0, 0.0, 0.0, 0.0}, pre_t = 0.0;
+  if (gt_staged) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // kTailGt * 7 <= 4 * kTgtThreads
+      const int k = r * kTgtThreads + tid, j = k / 7, c = k - j * 7;
+      if (k < G * 7) pre_g[r] = c < 3 ? t.g_centers[j * 3 + c] : c < 6 ? t.g_wlh[j * 3 + c - 3] : t.g_yaw[j];
+    }
+  }
+  static_assert(kTailGt * 7 <= 4 * kTgtThreads, "staging loop");
+  if (ty_staged && tid < t.per_cell * kTypeCols) pre_t = t.types[tid];
   // The first 2048 entries (all of them on real scenes) are fetched once, every load in flight
   // together.
   u64 e_key[kTailBatch], e_bits[kTailBatch];
@@ -497,6 +575,14 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
     }
   }
   IOU_STAMP(11);
+  if (gt_staged) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = r * kTgtThreads + tid;
+      if (k < G * 7) T.gtv[0][k] = pre_g[r];
+    }
+  }
+  if (ty_staged && tid < t.per_cell * kTypeCols) T.types[0][tid] = pre_t;
 #pragma unroll
   for (int k = 0; k < kTailBatch; ++k)
     if (e_bits[k]) atomicMax(cmax_at((int)(e_key[k] & 0xFFFFFFFFull)), e_bits[k]);
@@ -537,7 +623,89 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
 #pragma unroll
     for (int d = 0; d < 9; ++d) reg[d] = row.v[d];
   };
-  if (IN_LDS && t.num_classes <= 63) {
+  if (IN_LDS && t.num_classes <= 63 && G <= 64) {
+    // The usual case: one ground truth per lane (row j = lane), one KIND of work per wave.  A wave executes
+    // every branch its lanes take, and the f64 library functions are chains of ~1 us each: with the kinds mixed
+    // inside a wave every row paid for a square root, divisions, a logarithm AND a sine (one row on one lane was
+    // a 2.6 us chain; eight lanes per row, one component each, 2 x 1.3 us).  Here the four chains run side by side:
+    //   wave 0  the sine, the orientation bit         wave 1  two of the logarithms (independent: they interleave)
+    //   wave 2  the third logarithm, the quotients    wave 3  which rows are due at all, and the class rows
+    // and meet at one barrier.  Wave 3: the classes of ALL ground truths forcing row j's anchor (duplicates set
+    // several ones, box_utils.py:212-213; every duplicate writes the same full class row) and whether a later
+    // ground truth forces the same anchor (then ITS regression row wins, :223-228).
+    const int ln = tid & 63, wv = tid >> 6;
+    const u64 w = ln < G ? T.colwin[ln] : 0ull;
+    const int i = (int)(w >> 32);
+    auto gval = [&](int k) -> double {  // k: x, y, z, w, l, h, yaw
+      if (gt_staged) return T.gtv[ln][k];
+      return k < 3 ? t.g_centers[ln * 3 + k] : k < 6 ? t.g_wlh[ln * 3 + k - 3] : t.g_yaw[ln];
+    };
+    const AnchorId id = anchor_id(t, i);
+    const int id_d = id.d;
+    auto aval = [&](int k) -> double {  // k >= 2 for grid anchors (their centre is arithmetic: id)
+      if (t.grid) {
+        const int col = k == 2 ? 12 : k == 6 ? 11 : 5 + k;  // z | yaw | w, l, h
+        return ty_staged ? T.types[id_d][col] : t.types[id_d * kTypeCols + col];
+      }
+      return k < 3 ? t.a_centers[(int64_t)i * 3 + k] : k < 6 ? t.a_wlh[(int64_t)i * 3 + k - 3] : t.a_yaw[i];
+    };
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+    if (wv == 3) {
+      // lanes forcing the same anchor find each other bit by bit: one ballot per bit of the anchor index
+      // (a loop over the lanes with v_readlane was 70 ns per ground truth: VALU -> SGPR -> VALU round trips)
+      const int cbit = (int)(w & 63ull);
+      u64 same = G == 64 ? ~0ull : (1ull << G) - 1ull;
+      const int nbits = 32 - __clz((int)t.A);  // i < A
+      for (int b = 0; b < nbits; ++b) {
+        const bool bit = ((unsigned)i >> b) & 1u;
+        const u64 bal = __ballot(bit);
+        same &= bit ? bal : ~bal;
+      }
+      const bool later = ((same >> ln) >> 1) != 0ull;
+      u64 mask = 0ull, rest = same;
+      while (__ballot(rest != 0ull)) {  // as many turns as the largest group has members: one, as a rule
+        const int src = rest ? __ffsll((long long)rest) - 1 : ln;
+        const int c2 = __shfl(cbit, src);
+        mask |= rest ? (1ull << c2) : 0ull;
+        rest &= rest - 1ull;
+      }
+      if (ln < G) T.colmax[ln] = later ? 1ull : 0ull;  // the column maxima are not needed any more
+      if (i != 0) {
+        float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+        for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;
+      }
+    } else if (i != 0) {
+      if (wv == 0) {
+        target_angle(gval(6), aval(6), &r0, &r1);
+      } else if (wv == 1) {
+        r0 = target_logratio(gval(3), aval(3));
+        r1 = target_logratio(gval(4), aval(4));
+      } else {
+        const double aw = aval(3), al = aval(4), ah = aval(5);
+        r0 = target_logratio(gval(5), ah);
+        r1 = target_quotient(gval(0), t.grid ? id.cx : aval(0), aw, al, ah, t.canvas_height, 0);
+        r2 = target_quotient(gval(1), t.grid ? id.cy : aval(1), aw, al, ah, t.canvas_height, 1);
+        r3 = target_quotient(gval(2), aval(2), aw, al, ah, t.canvas_height, 2);
+      }
+    }
+    __syncthreads();
+    if (wv < 3 && i != 0 && T.colmax[ln] == 0ull) {
+      float *reg = t.reg_targets + (int64_t)i * 9;
+      if (wv == 0) {
+        reg[0] = 1.0f;
+        reg[7] = r0;
+        reg[8] = r1;
+      } else if (wv == 1) {
+        reg[4] = r0;
+        reg[5] = r1;
+      } else {
+        reg[6] = r0;
+        reg[1] = r1;
+        reg[2] = r2;
+        reg[3] = r3;
+      }
+    }
+  } else if (IN_LDS && t.num_classes <= 63) {
     // class row of a forced anchor i: ones at the classes of ALL ground truths forcing it (every
     // duplicate writes the same full row); regression row: the last ground truth wins.  The scan
     // over the ground truths for duplicates is split over the four waves (quarter q of the
@@ -569,8 +737,53 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
         const u64 m = T.colmax[j];
         float *cls = t.cls_targets + (int64_t)i * t.num_classes;
         for (int c = 0; c < t.num_classes; ++c) cls[c] = ((m >> c) & 1ull) ? 1.0f : 0.0f;
-        // (one lane per row: 8 lanes per row take two rounds of dependent loads for 40 rows -- slower)
-        if (!(m >> 63)) write_row(i, j);
+      }
+    }
+    // Regression rows, one kind of value per wave (see target_quotient).  colmax[j] bit 63: a later
+    // ground truth forces the same anchor and its row wins.
+    __syncthreads();
+    IOU_STAMP(15);
+    // wave 0: the three quotients of every row (lane = row * 3 + component), wave 1: the three
+    // logarithms, wave 2: the sine, the orientation bit and the leading 1
+    const int wv = tid >> 6, ln = tid & 63;
+    auto forced = [&](int j) -> int {  // the anchor whose regression row ground truth j writes, or 0
+      if ((T.colmax[j] >> 63) != 0ull) return 0;
+      return (int)(T.colwin[j] >> 32);
+    };
+    auto gval = [&](int j, int k) -> double {  // k: x, y, z, w, l, h, yaw
+      if (gt_staged) return T.gtv[j][k];
+      return k < 3 ? t.g_centers[j * 3 + k] : k < 6 ? t.g_wlh[j * 3 + k - 3] : t.g_yaw[j];
+    };
+    auto aval = [&](int i, int k) -> double {
+      if (t.grid) {
+        const AnchorId id = anchor_id(t, i);
+        if (k < 2) return k == 0 ? id.cx : id.cy;
+        const int col = k == 2 ? 12 : k == 6 ? 11 : 5 + k;  // z | yaw | w, l, h
+        return ty_staged ? T.types[id.d][col] : t.types[id.d * kTypeCols + col];
+      }
+      return k < 3 ? t.a_centers[(int64_t)i * 3 + k] : k < 6 ? t.a_wlh[(int64_t)i * 3 + k - 3] : t.a_yaw[i];
+    };
+    if (wv < 2) {
+      for (int it = ln; it < G * 3; it += 64) {
+        const int j = it / 3, c = it - j * 3;
+        const int i = forced(j);
+        if (i == 0) continue;
+        float *reg = t.reg_targets + (int64_t)i * 9;
+        if (wv == 0)
+          reg[1 + c] = target_quotient(gval(j, c), aval(i, c), aval(i, 3), aval(i, 4), aval(i, 5), t.canvas_height, c);
+        else
+          reg[4 + c] = target_logratio(gval(j, 3 + c), aval(i, 3 + c));
+      }
+    } else if (wv == 2) {
+      for (int j = ln; j < G; j += 64) {
+        const int i = forced(j);
+        if (i == 0) continue;
+        float *reg = t.reg_targets + (int64_t)i * 9;
+        float dt, ort;
+        target_angle(gval(j, 6), aval(i, 6), &dt, &ort);
+        reg[0] = 1.0f;
+        reg[7] = dt;
+        reg[8] = ort;
       }
     }
   } else {
@@ -613,23 +826,52 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
 
 // MATRIX: make_ious (data/pillars.cpp:400-427) on the same gate / queue / clip machinery -- the
 // pairs past the gate are written into the host-zeroed [A][G] matrix, nothing else is computed.
+#ifdef PP_TGT_WAVES  // development knob (tools/lab): waves per SIMD the register allocation is held to
+#define PP_TGT_OCC __attribute__((amdgpu_waves_per_eu(PP_TGT_WAVES, PP_TGT_WAVES)))
+#else
+#define PP_TGT_OCC
+#endif
 template <bool MATRIX>
-__global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
+__global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t, TargetBatch bt) {
+  // Batch launches are (sample, tile of 256 anchors): workgroups are dispatched x first, so the samples
+  // advance side by side -- with the samples one after the other the last one's workgroups all started
+  // late, its heavy ones last, and the launch ended ~10 us after everything else had drained.
+  const unsigned tile = MATRIX ? blockIdx.x : blockIdx.y, nwg = MATRIX ? gridDim.x : gridDim.y;
+  if constexpr (!MATRIX) sample_view(t, bt, (int)blockIdx.x, nwg);
   __shared__ __align__(16) unsigned char smem[kTgtLdsBytes];
   TgtLds &S = *reinterpret_cast<TgtLds *>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int v = lane & (kGroup - 1), gbase = lane & ~(kGroup - 1);
-  const int64_t i0 = (int64_t)blockIdx.x * kTgtThreads;
+  const int64_t i0 = (int64_t)tile * kTgtThreads;
   const int64_t i = i0 + tid;
   const bool live = i < t.A;
   IOU_STAMP(0);
+  // The first chunk's ground truths and the type table are on their way while the arithmetic below
+  // runs.  Every wave fetches the chunk's centres for itself (lane = ground truth): the "is any box
+  // near this workgroup" decision below then needs no LDS and no barrier.
+  double2 pre_c = make_double2(0.0, 0.0), pre_k = make_double2(0.0, 0.0);
+  auto load_chunk = [&](int j0, int gn) {
+    if (lane < gn) {
+      const double *gp = t.g_centers_img + (int64_t)(j0 + lane) * t.g_center_cols;
+      pre_c = make_double2(gp[0], gp[1]);
+    }
+    if (tid < gn * 4) {  // kGtChunk * 4 == kTgtThreads: one corner per thread
+      const double *gp = t.g_corners + ((int64_t)j0 * 4 + tid) * 2;
+      pre_k = make_double2(gp[0], gp[1]);
+    }
+  };
+  static_assert(kGtChunk * 4 <= kTgtThreads, "one corner per thread");
+  const int gn0 = min(kGtChunk, t.G);
+  load_chunk(0, gn0);
+  const bool single = t.G <= kGtChunk;
+  const bool lds_types = t.grid && t.per_cell <= kLdsTypes;
+  double pre_ty = 0.0;
+  static_assert(kLdsTypes * kTypeCols <= kTgtThreads, "one table entry per thread");
+  if (lds_types && tid < t.per_cell * kTypeCols) pre_ty = t.types[tid];
   double acx = 0, acy = 0;
-  if (live) {
-    const AnchorId id = anchor_id(t, i);
-    acx = id.cx;
-    acy = id.cy;
-    S.acen[tid] = make_double2(acx, acy);
-    S.atype[tid] = (unsigned short)id.d;
+  if (!t.grid && live) {
+    acx = t.a_centers[i * t.a_center_cols];
+    acy = t.a_centers[i * t.a_center_cols + 1];
   }
   // Bounding box of the workgroup's anchor centres: a ground truth further than the gate's 10
   // (+1: rounding of the gate's subtraction, whatever the magnitudes) from it is far from every
@@ -640,10 +882,10 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
     const unsigned c0 = (unsigned)i0 / pc, c1 = (unsigned)(min(i0 + kTgtThreads, t.A) - 1) / pc;
     const unsigned y0 = c0 / fw, y1 = c1 / fw;
     const unsigned x0 = (y0 == y1) ? c0 - y0 * fw : 0u, x1 = (y0 == y1) ? c1 - y1 * fw : fw - 1u;
-    bx0 = ((double)x0 + 0.5) / t.fm_scale;
-    bx1 = ((double)x1 + 0.5) / t.fm_scale;
-    by0 = ((double)y0 + 0.5) / t.fm_scale;
-    by1 = ((double)y1 + 0.5) / t.fm_scale;
+    bx0 = cell_centre(t, x0);
+    bx1 = cell_centre(t, x1);
+    by0 = cell_centre(t, y0);
+    by1 = cell_centre(t, y1);
   } else {
     double mnx = live ? acx : INFINITY, mxx = live ? acx : -INFINITY;
     double mny = live ? acy : INFINITY, mxy = live ? acy : -INFINITY;
@@ -670,22 +912,40 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
     }
   }
   const double fx0 = bx0 - 11.0, fx1 = bx1 + 11.0, fy0 = by0 - 11.0, fy1 = by1 + 11.0;
-  const bool lds_types = t.grid && t.per_cell <= kLdsTypes;
-  if (lds_types)
-    for (int k = tid; k < t.per_cell * kTypeCols; k += kTgtThreads) S.types[0][k] = t.types[k];
+  // No box of the sample near this workgroup (a third of them at BASELINE config 3; every wave works
+  // the same answer out from the same registers): nothing below concerns it -- zero rows, a ticket, done.
+  const bool near0 = lane < gn0 && !(pre_c.x < fx0 || pre_c.x > fx1 || pre_c.y < fy0 || pre_c.y > fy1);
+  const bool skip = single && __ballot(near0) == 0ull;
+  if (MATRIX && skip) return;
+  if (!skip) {
+    if (live) {
+      int d = 0;
+      if (t.grid) {
+        const AnchorId id = anchor_id(t, i);
+        acx = id.cx;
+        acy = id.cy;
+        d = id.d;
+      }
+      S.acen[tid] = make_double2(acx, acy);
+      S.atype[tid] = (unsigned short)d;
+    }
+    if (lds_types && tid < t.per_cell * kTypeCols) S.types[0][tid] = pre_ty;
+  }
   double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
   int best_j = 0;
   bool bad = false;
   // this workgroup's columns of a chunk -> the list (at most one entry per ground truth)
-  auto append_columns = [&](int j0, int gn) {
-    if (wv != 0) return;
+  // wave 0: reserve list slots for the chunk's touched columns (one counter bump), write them later
+  auto reserve_columns = [&](int gn, u64 &tb, unsigned &base) {
     const bool touched = lane < gn && S.cmax[lane] != 0ull;
-    const u64 tb = __ballot(touched);
+    tb = __ballot(touched);
+    base = 0u;
+    if (tb && lane == 0) base = atomicAdd(t.cand_count, (unsigned)__popcll(tb));
+  };
+  auto write_columns = [&](int j0, u64 tb, unsigned base) {
     if (!tb) return;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(t.cand_count, (unsigned)__popcll(tb));
     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (touched) {
+    if ((tb >> lane) & 1ull) {
       const unsigned pos = base + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
       ColEntry *ce = t.cand + pos;
       __hip_atomic_store(&ce->key, (u64)(unsigned)(j0 + lane) | ((u64)(unsigned)S.carg[lane] << 32), __ATOMIC_RELAXED,
@@ -693,21 +953,27 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       __hip_atomic_store(&ce->bits, S.cmax[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
+  auto append_columns = [&](int j0, int gn) -> bool {
+    if (wv != 0) return false;
+    u64 tb;
+    unsigned base;
+    reserve_columns(gn, tb, base);
+    write_columns(j0, tb, base);
+    return tb != 0ull;
+  };
   int last_j0 = 0, last_gn = 0;  // the last chunk's columns are appended behind the row stores
-  for (int j0 = 0; j0 < t.G; j0 += kGtChunk) {
+  bool touched_before = false;   // wave 0: an earlier chunk had a column with IoU > 0
+  for (int j0 = 0; j0 < (skip ? 0 : t.G); j0 += kGtChunk) {
     const int gn = min(kGtChunk, t.G - j0);
+    if (j0 > 0) load_chunk(j0, gn);
     __syncthreads();
-    if (tid < gn) {
-      S.gc[tid] = make_double2(t.g_centers_img[(int64_t)(j0 + tid) * t.g_center_cols],
-                               t.g_centers_img[(int64_t)(j0 + tid) * t.g_center_cols + 1]);
+    if (tid < gn) {  // wave 0's copy
+      S.gc[tid] = pre_c;
       S.cmax[tid] = 0ull;
       S.cseen[tid] = 0ull;
       S.carg[tid] = INT_MAX;
     }
-    for (int k = tid; k < gn * 4; k += kTgtThreads) {
-      const double *gp = t.g_corners + ((int64_t)j0 * 4 + k) * 2;
-      S.gk[k >> 2][k & 3] = make_double2(gp[0], gp[1]);
-    }
+    if (tid < gn * 4) S.gk[tid >> 2][tid & 3] = pre_k;
     __syncthreads();
     IOU_STAMP(1);
     // the chunk's ground truths near this workgroup (every wave works out the same mask)
@@ -767,12 +1033,11 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
       __syncthreads();
       IOU_STAMP(3);
       // clip: 32 groups of 8 lanes, one pair each per round
-      for (int r0 = 0; r0 < wn; r0 += kMaxNP * kPairsPerRound) {
-        if (wn - r0 <= kPairsPerRound)
-          clip_round<1>(t, S, r0, wn, i0, tid, v, gbase, lds_types, bad);
-        else
-          clip_round<kMaxNP>(t, S, r0, wn, i0, tid, v, gbase, lds_types, bad);
-      }
+      // (a wave whose eight groups have no pair in this round sits it out: a round is ~500 instructions,
+      // and a third of the wave-rounds were empty)
+      static_assert(kMaxNP == 1, "one pair per group and round");
+      for (int r0 = 0; r0 < wn; r0 += kPairsPerRound)
+        if (r0 + wv * (64 / kGroup) < wn) clip_round<1>(t, S, r0, wn, i0, tid, v, gbase, lds_types, bad);
       __syncthreads();
       IOU_STAMP(4);
       if constexpr (MATRIX) {
@@ -813,7 +1078,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
     }
     if constexpr (MATRIX) continue;
     if (j0 + kGtChunk < t.G) {
-      append_columns(j0, gn);
+      touched_before = append_columns(j0, gn) || touched_before;
     } else {
       last_j0 = j0;
       last_gn = gn;
@@ -828,71 +1093,132 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
   const bool pos = live && best > t.pos_thresh;  // box_utils.py:195 (strict >)
   const int cj = pos ? t.g_class[best_j] : -1;
   float *cls_dst = t.cls_targets + i0 * nc, *reg_dst = t.reg_targets + i0 * 9;
-  // the positives, lined up for the groups of 8 lanes that work their regression rows out
-  const u64 pb = __ballot(pos);
-  if (lane == 0) S.woff[wv] = __popcll(pb);
-  __syncthreads();
-  int pbase = 0, npos = 0;
-#pragma unroll
-  for (int w = 0; w < kTgtWaves; ++w) {
-    if (w < wv) pbase += S.woff[w];
-    npos += S.woff[w];
-  }
-  if (pos) {
-    const int k = pbase + __popcll(pb & ((1ull << lane) - 1ull));
-    S.pair_lane[k] = (unsigned short)tid;
-    S.pair_gt[k] = (unsigned short)best_j;
-  }
-  const bool cls_staged = nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0;
-  if (cls_staged) {
-    if (live)
-      for (int c = 0; c < nc; ++c) S.stage[tid * nc + c] = (c == cj) ? 1.0f : 0.0f;
+  // Does the tail depend on this workgroup at all?  It reads the list entries and overwrites forced
+  // rows, and a forced anchor has IoU > 0 with its ground truth: only a workgroup with a touched
+  // column appends anything or owns a row the tail may write.
+  bool contrib = false;
+  u64 pb = 0ull, last_tb = 0ull;
+  unsigned last_base = 0u;
+  if (!skip) {
+    if (wv == 0) {
+      // the last chunk's list slots: the counter's round trip runs under the row phase
+      reserve_columns(last_gn, last_tb, last_base);
+      if (lane == 0) S.contrib = (touched_before || last_tb != 0ull) ? 1 : 0;
+    }
+    // the positives, lined up for the groups of 8 lanes that work their regression rows out
+    pb = __ballot(pos);
+    if (lane == 0) S.woff[wv] = __popcll(pb);
     __syncthreads();
-    store_rows(cls_dst, S.stage, nrows * nc, tid);
-  } else if (live) {
-    for (int c = 0; c < nc; ++c) store_f32_sc1(&cls_dst[(int64_t)tid * nc + c], (c == cj) ? 1.0f : 0.0f);
+    contrib = S.contrib != 0;
   }
-  __syncthreads();
-  if (live) {
+  // Every other workgroup (half of them at BASELINE config 3) takes its ticket NOW -- no store of
+  // its own to order, so no drain -- and the counter's round trip runs under its row stores.
+  unsigned tk = 0u;
+  unsigned *my_ticket1 = t.ticket1 + (size_t)(tile >> t.ticket_shift) * kTicketPad;
+  if (!contrib && t.G != 0 && tid == 0) tk = atomicAdd(my_ticket1, 1u);
+  int pbase = 0, npos = 0;
+  if (!skip) {
 #pragma unroll
-    for (int d = 0; d < 9; ++d) S.stage[tid * 9 + d] = 0.0f;
-  }
-  __syncthreads();
-  for (int k0 = 0; k0 < npos; k0 += kPairsPerRound) {
-    const int k = k0 + (tid >> 3);
-    if (k < npos) {
-      const int pl = S.pair_lane[k];
-      BoxVals a;
-      if (lds_types) {  // centre and type row are in LDS already
-        const double *ty = S.types[S.atype[pl]];
-        a.x = S.acen[pl].x, a.y = S.acen[pl].y, a.z = ty[12];
-        a.w = ty[8], a.l = ty[9], a.h = ty[10], a.yaw = ty[11];
-      } else {
-        a = anchor_vals(t, i0 + pl);
-      }
-      const float val = target_component(a, gt_vals(t, S.pair_gt[k]), t.canvas_height, v);
-      S.stage[pl * 9 + 1 + v] = val;
-      if (v == 0) S.stage[pl * 9] = 1.0f;
+    for (int w = 0; w < kTgtWaves; ++w) {
+      if (w < wv) pbase += S.woff[w];
+      npos += S.woff[w];
     }
   }
-  __syncthreads();
-  if (((uintptr_t)t.reg_targets & 15) == 0) {
-    store_rows(reg_dst, S.stage, nrows * 9, tid);
-  } else if (live) {
+  const bool aligned = (((uintptr_t)t.cls_targets | (uintptr_t)t.reg_targets) & 15) == 0;
+  if (npos == 0 && aligned) {
+    // no positive anchor here (nine workgroups in ten): zero rows straight from registers
+    store_zero_rows(cls_dst, nrows * nc, tid);
+    store_zero_rows(reg_dst, nrows * 9, tid);
+  } else {
+    if (pos) {
+      const int k = pbase + __popcll(pb & ((1ull << lane) - 1ull));
+      S.pair_lane[k] = (unsigned short)tid;
+      S.pair_gt[k] = (unsigned short)best_j;
+    }
+    const bool cls_staged = nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0;
+    if (cls_staged) {
+      if (live)
+        for (int c = 0; c < nc; ++c) S.stage[tid * nc + c] = (c == cj) ? 1.0f : 0.0f;
+      __syncthreads();
+      store_rows(cls_dst, S.stage, nrows * nc, tid);
+    } else if (live) {
+      for (int c = 0; c < nc; ++c) store_f32_sc1(&cls_dst[(int64_t)tid * nc + c], (c == cj) ? 1.0f : 0.0f);
+    }
+    __syncthreads();
+    if (live) {
 #pragma unroll
-    for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], S.stage[tid * 9 + d]);
+      for (int d = 0; d < 9; ++d) S.stage[tid * 9 + d] = 0.0f;
+    }
+    __syncthreads();
+    // The positives' regression rows, one KIND of value per wave (a wave executes every branch its lanes take:
+    // eight lanes per row, one value each, made every wave pay for a square root, divisions, a logarithm and
+    // a sine per 32 rows): wave 0 the sine and the orientation bit, wave 1 two logarithms (independent chains:
+    // they interleave), wave 2 the third and the quotients; lane = positive.
+    if (wv < 3) {
+      for (int k = lane; k < npos; k += 64) {
+        const int pl = S.pair_lane[k], pj = S.pair_gt[k];
+        double ax, ay, az, aw, al, ah, ayaw;
+        if (lds_types) {  // centre and type row are in LDS already
+          const double *ty = S.types[S.atype[pl]];
+          ax = S.acen[pl].x, ay = S.acen[pl].y, az = ty[12];
+          aw = ty[8], al = ty[9], ah = ty[10], ayaw = ty[11];
+        } else {
+          const BoxVals a = anchor_vals(t, i0 + pl);
+          ax = a.x, ay = a.y, az = a.z, aw = a.w, al = a.l, ah = a.h, ayaw = a.yaw;
+        }
+        float *row = S.stage + pl * 9;
+        auto gval = [&](int k) -> double {  // k: x, y, z, w, l, h, yaw
+          return k < 3 ? t.g_centers[pj * 3 + k] : k < 6 ? t.g_wlh[pj * 3 + k - 3] : t.g_yaw[pj];
+        };
+        if (wv == 0) {
+          float dt, ort;
+          target_angle(gval(6), ayaw, &dt, &ort);
+          row[0] = 1.0f;
+          row[7] = dt;
+          row[8] = ort;
+        } else if (wv == 1) {
+          row[4] = target_logratio(gval(3), aw);
+          row[5] = target_logratio(gval(4), al);
+        } else {
+          row[6] = target_logratio(gval(5), ah);
+          row[1] = target_quotient(gval(0), ax, aw, al, ah, t.canvas_height, 0);
+          row[2] = target_quotient(gval(1), ay, aw, al, ah, t.canvas_height, 1);
+          row[3] = target_quotient(gval(2), az, aw, al, ah, t.canvas_height, 2);
+        }
+      }
+    }
+    __syncthreads();
+    if (((uintptr_t)t.reg_targets & 15) == 0) {
+      store_rows(reg_dst, S.stage, nrows * 9, tid);
+    } else if (live) {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], S.stage[tid * 9 + d]);
+    }
   }
   IOU_STAMP(6);
   if (t.G == 0) return;
-  append_columns(last_j0, last_gn);  // its counter round trip overlaps the drain of the row stores
-  // The last workgroup to get here finishes the job.  Every store above that the tail depends on
-  // is write-through; drained per wave, then one agent-scope add per workgroup: the workgroup
-  // whose add comes last reads the others' entries with sc1 loads and may overwrite their rows.
-  IOU_STAMP(7);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  IOU_STAMP(8);
-  if (tid == 0) S.is_last = (atomicAdd(t.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+  if (contrib) {
+    if (wv == 0) write_columns(last_j0, last_tb, last_base);
+    // The last workgroup to get here finishes the job.  Every store above that the tail depends on
+    // is write-through; drained per wave, then one agent-scope add per workgroup: the workgroup
+    // whose add comes last reads the others' entries with sc1 loads and may overwrite their rows.
+    IOU_STAMP(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    IOU_STAMP(8);
+    if (tid == 0) tk = atomicAdd(my_ticket1, 1u);
+  }
+  if (tid == 0) {
+    // the last workgroup of its group of 1 << ticket_shift carries the group's ticket on
+    const unsigned grp = tile >> t.ticket_shift, ngrp = ((nwg - 1u) >> t.ticket_shift) + 1u;
+    const unsigned gsize = min(1u << t.ticket_shift, nwg - (grp << t.ticket_shift));
+    int last = 0;
+    if (tk == gsize - 1u) {
+      __hip_atomic_store(my_ticket1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next call
+      last = (atomicAdd(t.ticket, 1u) == ngrp - 1u) ? 1 : 0;
+    }
+    S.is_last = last;
+  }
   __syncthreads();
   IOU_STAMP(9);
   if (!S.is_last) return;
@@ -904,17 +1230,18 @@ __global__ __launch_bounds__(kTgtThreads) void k_targets(TargetArgs t) {
 }
 
 __global__ void k_targets_init(u64 *col_max, u64 *col_win, int G, int *errflag,
-                               unsigned *cand_count, unsigned *ticket) {
+                               unsigned *cand_count, unsigned *ticket, unsigned *ticket1, int n_ticket1) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_ticket1) ticket1[j] = 0u;
   if (j < G) {
     col_max[j] = 0ull;
     col_win[j] = ~0ull;
   }
-  if (j == 0) {
-    *errflag = 0;
-    *cand_count = 0u;
-    *ticket = 0u;
+  if (j < PP_MAX_BATCH) {  // every sample's counter and ticket
+    cand_count[j * kCounterStride] = 0u;
+    ticket[j * kCounterStride] = 0u;
   }
+  if (j == 0) *errflag = 0;
 }
 
 namespace {
@@ -978,7 +1305,9 @@ extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_co
   t.ious = ious_dev;
   t.errflag = errflag;
   const unsigned nwg = (unsigned)((A + kTgtThreads - 1) / kTgtThreads);
-  hipLaunchKernelGGL(k_targets<true>, dim3(nwg), dim3(kTgtThreads), 0, stream, t);
+  TargetBatch bt{};
+  bt.g_off[1] = (int)G;
+  hipLaunchKernelGGL(k_targets<true>, dim3(nwg), dim3(kTgtThreads), 0, stream, t, bt);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -1076,41 +1405,61 @@ struct AnchorSource {
   const double *types = nullptr;
 };
 
-static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const AnchorSource &an,
-                               int64_t G, const double *g_corners, const double *g_centers_img,
-                               const double *g_centers, const double *g_wlh, const double *g_yaw,
-                               const int32_t *g_class, const pp_target_params_t *prm,
+static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const int32_t *g_counts,
+                               int64_t A, const AnchorSource &an, const double *g_corners,
+                               const double *g_centers_img, const double *g_centers, const double *g_wlh,
+                               const double *g_yaw, const int32_t *g_class, const pp_target_params_t *prm,
                                float *cls_targets, float *reg_targets) {
-  if (!ctx || !prm) {
+  if (!ctx || !prm || !g_counts) {
     set_error("pp_assign_targets*_dev: NULL argument");
     return PP_ERR_VALUE;
   }
-  if (A < 1 || A > INT_MAX / 2 || G < 0 || G > 65535 || prm->num_classes < 1 ||
-      prm->num_classes > 1024) {
-    set_error("pp_assign_targets*_dev: bad sizes (A=%lld G=%lld classes=%d)", (long long)A,
-              (long long)G, prm->num_classes);
+  if (batch < 1 || batch > PP_MAX_BATCH) {
+    set_error("pp_assign_targets*_dev: batch %d outside 1..%d", batch, PP_MAX_BATCH);
+    return PP_ERR_VALUE;
+  }
+  TargetBatch bt{};
+  int64_t g_total = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (g_counts[b] < 0 || g_counts[b] > 65535) {
+      set_error("pp_assign_targets*_dev: sample %d has %d ground truths (0..65535)", b, (int)g_counts[b]);
+      return PP_ERR_VALUE;
+    }
+    g_total += g_counts[b];
+    bt.g_off[b + 1] = (int)g_total;
+  }
+  if (A < 1 || A > 65535ll * kTgtThreads || prm->num_classes < 1 || prm->num_classes > 1024) {  // grid.y = tiles of 256
+    set_error("pp_assign_targets*_dev: bad sizes (A=%lld classes=%d)", (long long)A, prm->num_classes);
     return PP_ERR_VALUE;
   }
   if (!cls_targets || !reg_targets ||
-      (G > 0 && (!g_corners || !g_centers_img || !g_centers || !g_wlh || !g_yaw || !g_class))) {
+      (g_total > 0 && (!g_corners || !g_centers_img || !g_centers || !g_wlh || !g_yaw || !g_class))) {
     set_error("pp_assign_targets*_dev: NULL array");
     return PP_ERR_VALUE;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard2 guard(ctx->device);
-  // scratch: [0,4096) flags/counters | col_max[Gcap] | col_win[Gcap] | cand[workgroups * Gcap]
-  const size_t gcap = (size_t)std::max<int64_t>(G, 1);
+  // scratch: [0,8192) error flag + every sample's {counter, ticket} | col_max[Gcap] | col_win[Gcap] |
+  // cand[workgroups * Gcap]; sample b owns the rows [g_off[b], g_off[b+1]) of each (Gcap = all samples' G)
+  const size_t gcap = (size_t)std::max<int64_t>(g_total, 1);
   const size_t nwg = (size_t)((A + kTgtThreads - 1) / kTgtThreads);
-  const size_t off_cmax = 4096, off_cwin = off_cmax + gcap * 8;
-  const size_t off_cand = (off_cwin + gcap * 8 + 255) / 256 * 256;
+  const size_t off_cmax = 8192, off_cwin = off_cmax + gcap * 8;
+  // first-level tickets: groups of ~sqrt(workgroups) (a power of two), one 64-byte line per group and sample
+  int ticket_shift = 0;
+  while (((size_t)1 << (2 * ticket_shift)) < nwg) ++ticket_shift;
+  const size_t ngrp = ((nwg - 1) >> ticket_shift) + 1;
+  const size_t n_ticket1 = (size_t)PP_MAX_BATCH * ngrp * kTicketPad;
+  const size_t off_tk1 = (off_cwin + gcap * 8 + 255) / 256 * 256;
+  const size_t off_cand = (off_tk1 + n_ticket1 * 4 + 255) / 256 * 256;
   const size_t need = off_cand + nwg * gcap * sizeof(ColEntry);
+  static_assert(256 + PP_MAX_BATCH * kCounterStride * 4 <= 8192, "counter block");
   bool grew = false;
   int rc = ctx->iou_ws.ensure(need, &grew);
   if (rc) return rc;
   char *ws = static_cast<char *>(ctx->iou_ws.ptr);
   TargetArgs t;
   t.A = A;
-  t.G = (int)G;
+  t.G = 0;  // per sample: sample_view
   t.a_corners = an.corners;
   t.a_centers = an.centers;
   t.a_wlh = an.wlh;
@@ -1122,6 +1471,10 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   t.fm_w = an.fm_w;
   t.per_cell = an.per_cell;
   t.fm_scale = an.fm_scale;
+  {
+    int e2 = 0;
+    t.inv_scale = (an.grid && std::frexp(an.fm_scale, &e2) == 0.5) ? 1.0 / an.fm_scale : 0.0;
+  }
   t.types = an.types;
   t.g_corners = g_corners;
   t.g_centers_img = g_centers_img;
@@ -1133,24 +1486,59 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int64_t A, const An
   t.canvas_height = prm->canvas_height;
   t.num_classes = prm->num_classes;
   t.errflag = reinterpret_cast<int *>(ws);
-  t.cand_count = reinterpret_cast<unsigned *>(ws + 64);
-  t.ticket = reinterpret_cast<unsigned *>(ws + 128);
+  t.cand_count = reinterpret_cast<unsigned *>(ws + 256);
+  t.ticket = reinterpret_cast<unsigned *>(ws + 256 + 64);
   t.col_max = reinterpret_cast<u64 *>(ws + off_cmax);
   t.col_win = reinterpret_cast<u64 *>(ws + off_cwin);
   t.cand = reinterpret_cast<ColEntry *>(ws + off_cand);
+  t.ticket1 = reinterpret_cast<unsigned *>(ws + off_tk1);
+  t.ticket_shift = ticket_shift;
   t.cls_targets = cls_targets;
   t.reg_targets = reg_targets;
-  // The scratch words are re-armed by the kernel's tail at the end of every call; only a
+  // The scratch words are re-armed by every sample's tail at the end of every call; only a
   // fresh / regrown / re-shaped workspace needs the init.
-  const unsigned long long key = ((unsigned long long)A << 20) ^ (unsigned long long)gcap;
+  const unsigned long long key = ((unsigned long long)A << 24) ^ (unsigned long long)gcap;
   if (grew || ctx->tgt_key != key) {
-    const unsigned gb = (unsigned)((gcap + 255) / 256);
+    const unsigned gb = (unsigned)((std::max<size_t>(std::max<size_t>(gcap, PP_MAX_BATCH), n_ticket1) + 255) / 256);
     hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_win,
-                       (int)G, t.errflag, t.cand_count, t.ticket);
+                       (int)gcap, t.errflag, t.cand_count, t.ticket, t.ticket1, (int)n_ticket1);
     ctx->tgt_key = key;
   }
-  hipLaunchKernelGGL(k_targets<false>, dim3((unsigned)nwg), dim3(kTgtThreads), 0, stream, t);
-  PP_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_targets<false>, dim3((unsigned)batch, (unsigned)nwg), dim3(kTgtThreads), 0, stream, t, bt);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+    ctx->tgt_key = 0;  // counters in an unknown state: re-arm on the next call
+    set_error("k_targets launch failed: %s", hipGetErrorString(e));
+    return PP_ERR_HIP;
+  }
+  return PP_OK;
+}
+
+static int check_anchor_arrays(const double *a_corners, const double *a_centers, const double *a_wlh,
+                               const double *a_yaw, AnchorSource *an) {
+  if (!a_corners || !a_centers || !a_wlh || !a_yaw) {
+    set_error("pp_assign_targets*_dev: NULL anchor array");
+    return PP_ERR_VALUE;
+  }
+  an->corners = a_corners;
+  an->centers = a_centers;
+  an->wlh = a_wlh;
+  an->yaw = a_yaw;
+  return PP_OK;
+}
+
+static int check_anchor_grid(int fm_height, int fm_width, double fm_scale, int per_cell,
+                             const double *anchor_types_dev, AnchorSource *an) {
+  if (fm_height < 1 || fm_width < 1 || per_cell < 1 || per_cell > 1024 || !(fm_scale > 0.0) ||
+      !anchor_types_dev || (int64_t)fm_height * fm_width * per_cell > 65535ll * kTgtThreads) {
+    set_error("pp_assign_targets_grid*_dev: bad anchor grid (%dx%d, %d per cell, scale %g)",
+              fm_height, fm_width, per_cell, fm_scale);
+    return PP_ERR_VALUE;
+  }
+  an->grid = 1;
+  an->fm_w = fm_width;
+  an->per_cell = per_cell;
+  an->fm_scale = fm_scale;
+  an->types = anchor_types_dev;
   return PP_OK;
 }
 
@@ -1162,17 +1550,29 @@ extern "C" int pp_assign_targets_dev(pp_ctx_t *ctx, void *stream_, int64_t A,
                                      const double *g_yaw, const int32_t *g_class,
                                      const pp_target_params_t *prm, float *cls_targets,
                                      float *reg_targets) {
-  if (!a_corners || !a_centers || !a_wlh || !a_yaw) {
-    set_error("pp_assign_targets_dev: NULL anchor array");
+  AnchorSource an;
+  if (int rc = check_anchor_arrays(a_corners, a_centers, a_wlh, a_yaw, &an)) return rc;
+  if (G < 0 || G > 65535) {
+    set_error("pp_assign_targets_dev: bad sizes (G=%lld)", (long long)G);
     return PP_ERR_VALUE;
   }
-  AnchorSource an;
-  an.corners = a_corners;
-  an.centers = a_centers;
-  an.wlh = a_wlh;
-  an.yaw = a_yaw;
-  return assign_targets_impl(ctx, stream_, A, an, G, g_corners, g_centers_img, g_centers, g_wlh,
+  const int32_t g1 = (int32_t)G;
+  return assign_targets_impl(ctx, stream_, 1, &g1, A, an, g_corners, g_centers_img, g_centers, g_wlh,
                              g_yaw, g_class, prm, cls_targets, reg_targets);
+}
+
+extern "C" int pp_assign_targets_batch_dev(pp_ctx_t *ctx, void *stream_, int32_t batch,
+                                           const int32_t *g_counts, int64_t A, const double *a_corners,
+                                           const double *a_centers, const double *a_wlh,
+                                           const double *a_yaw, const double *g_corners,
+                                           const double *g_centers_img, const double *g_centers,
+                                           const double *g_wlh, const double *g_yaw,
+                                           const int32_t *g_class, const pp_target_params_t *prm,
+                                           float *cls_targets, float *reg_targets) {
+  AnchorSource an;
+  if (int rc = check_anchor_arrays(a_corners, a_centers, a_wlh, a_yaw, &an)) return rc;
+  return assign_targets_impl(ctx, stream_, batch, g_counts, A, an, g_corners, g_centers_img, g_centers,
+                             g_wlh, g_yaw, g_class, prm, cls_targets, reg_targets);
 }
 
 extern "C" int pp_assign_targets_grid_dev(pp_ctx_t *ctx, void *stream_, int fm_height, int fm_width,
@@ -1183,21 +1583,31 @@ extern "C" int pp_assign_targets_grid_dev(pp_ctx_t *ctx, void *stream_, int fm_h
                                           const double *g_yaw, const int32_t *g_class,
                                           const pp_target_params_t *prm, float *cls_targets,
                                           float *reg_targets) {
-  if (fm_height < 1 || fm_width < 1 || per_cell < 1 || per_cell > 1024 || !(fm_scale > 0.0) ||
-      !anchor_types_dev || (int64_t)fm_height * fm_width * per_cell > INT_MAX / 2) {
-    set_error("pp_assign_targets_grid_dev: bad anchor grid (%dx%d, %d per cell, scale %g)",
-              fm_height, fm_width, per_cell, fm_scale);
+  AnchorSource an;
+  if (int rc = check_anchor_grid(fm_height, fm_width, fm_scale, per_cell, anchor_types_dev, &an)) return rc;
+  if (G < 0 || G > 65535) {
+    set_error("pp_assign_targets_grid_dev: bad sizes (G=%lld)", (long long)G);
     return PP_ERR_VALUE;
   }
-  AnchorSource an;
-  an.grid = 1;
-  an.fm_w = fm_width;
-  an.per_cell = per_cell;
-  an.fm_scale = fm_scale;
-  an.types = anchor_types_dev;
-  return assign_targets_impl(ctx, stream_, (int64_t)fm_height * fm_width * per_cell, an, G, g_corners,
+  const int32_t g1 = (int32_t)G;
+  return assign_targets_impl(ctx, stream_, 1, &g1, (int64_t)fm_height * fm_width * per_cell, an, g_corners,
                              g_centers_img, g_centers, g_wlh, g_yaw, g_class, prm, cls_targets,
                              reg_targets);
+}
+
+extern "C" int pp_assign_targets_grid_batch_dev(pp_ctx_t *ctx, void *stream_, int32_t batch,
+                                                const int32_t *g_counts, int fm_height, int fm_width,
+                                                double fm_scale, int per_cell,
+                                                const double *anchor_types_dev, const double *g_corners,
+                                                const double *g_centers_img, const double *g_centers,
+                                                const double *g_wlh, const double *g_yaw,
+                                                const int32_t *g_class, const pp_target_params_t *prm,
+                                                float *cls_targets, float *reg_targets) {
+  AnchorSource an;
+  if (int rc = check_anchor_grid(fm_height, fm_width, fm_scale, per_cell, anchor_types_dev, &an)) return rc;
+  return assign_targets_impl(ctx, stream_, batch, g_counts, (int64_t)fm_height * fm_width * per_cell, an,
+                             g_corners, g_centers_img, g_centers, g_wlh, g_yaw, g_class, prm,
+                             cls_targets, reg_targets);
 }
 
 #ifdef PP_IOU_STAMPS

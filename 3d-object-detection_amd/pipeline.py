@@ -119,6 +119,12 @@ class PillarPipeline:
         utils/box_utils.py:19-32)."""
         return self.assigner._gt_to_device(g["centers"], g["wlh"], g["yaw"], g["classes"])
 
+    def upload_ground_truth_batch(self, gts):
+        """The boxes of ALL samples of a step in one device buffer (one host-to-device copy):
+        ``(g_counts, packed)``, what ``TargetAssigner.assign_batch_device`` and
+        ``train_forward_backward`` consume."""
+        return self.assigner.upload_batch(gts)
+
     def train_forward_backward(self, points, gts, n_points=None, shard_ctx=None):
         """train.py:139-147 without the optimizer: voxel stage, target stage, forward,
         loss, backward.  ``gts`` is a list (one per sweep) of dicts with
@@ -127,12 +133,16 @@ class PillarPipeline:
         the reference computes over the gathered batch); the returned scalars stay the local
         PPLoss values."""
         pillars, indices = self.voxelize(points, n_points)
-        # a ground-truth entry is either the dict of host arrays or the device tuple of
-        # upload_ground_truth() (what a prefetching loader hands over: no H2D copy, no sync)
-        targets = [self.assigner.assign_device(*g) if isinstance(g, tuple)
-                   else self.assigner.assign(g["centers"], g["wlh"], g["yaw"], g["classes"]) for g in gts]
-        cls_t = torch.stack([t[0] for t in targets])
-        reg_t = torch.stack([t[1] for t in targets])
+        if isinstance(gts, tuple) and len(gts) == 2 and torch.is_tensor(gts[1]):
+            cls_t, reg_t = self.assigner.assign_batch_device(*gts)
+        elif all(isinstance(g, dict) for g in gts):
+            cls_t, reg_t = self.assigner.assign_batch(gts)
+        else:
+            # per-sample device tuples of upload_ground_truth(): one launch per sample
+            targets = [self.assigner.assign_device(*g) if isinstance(g, tuple)
+                       else self.assigner.assign(g["centers"], g["wlh"], g["yaw"], g["classes"]) for g in gts]
+            cls_t = torch.stack([t[0] for t in targets])
+            reg_t = torch.stack([t[1] for t in targets])
         cls, reg = self.model(pillars, indices)
         p, cls_loss, reg_loss, ort_loss, total = self.loss(cls, reg, cls_t, reg_t)
         if shard_ctx is not None and shard_ctx.distributed:

@@ -97,6 +97,68 @@ class TargetAssigner:
             _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_dev")
         return cls_t, reg_t
 
+    # ------------------------------------------------------------------ a batch of samples per launch
+    def upload_batch(self, gts):
+        """``gts``: one dict per sample (centers / wlh / yaw / classes, canvas space).  Returns the
+        device hand-over ``assign_batch_device`` consumes: ``(g_counts, packed)`` -- the samples' boxes
+        concatenated in sample order in ONE f64 device buffer (one host-to-device copy per step instead
+        of six per sample), laid out [corners 8 | centers_img 3 | centers 3 | wlh 3 | yaw 1] per array,
+        then the int32 classes."""
+        counts = [int(np.asarray(g["yaw"]).reshape(-1).shape[0]) for g in gts]
+        if not 1 <= len(counts) <= _lib.MAX_BATCH:
+            raise ValueError(f"a batch is 1..{_lib.MAX_BATCH} samples, got {len(counts)}")
+        T = sum(counts)
+        host = np.zeros(max(T, 1) * 19, np.float64)   # 18 f64 columns + the classes' int32 (padded to 8 B)
+        corners, cimg = host[:T * 8].reshape(T, 4, 2), host[T * 8:T * 11].reshape(T, 3)
+        cen, wlh = host[T * 11:T * 14].reshape(T, 3), host[T * 14:T * 17].reshape(T, 3)
+        yaw, cls = host[T * 17:T * 18], host[T * 18:].view(np.int32)[:T]
+        o = 0
+        for g, n in zip(gts, counts):
+            if n:
+                c = np.asarray(g["centers"], np.float64).reshape(n, 3)
+                w = np.asarray(g["wlh"], np.float64).reshape(n, 3)
+                y = np.asarray(g["yaw"], np.float64).reshape(n)
+                ci, ki = boxes.boxes_to_image_space(c, w, y, self.canvas_height)
+                corners[o:o + n], cimg[o:o + n], cen[o:o + n], wlh[o:o + n], yaw[o:o + n] = ki, ci, c, w, y
+                cls[o:o + n] = np.asarray(g["classes"], np.int32).reshape(n)
+            o += n
+        return counts, torch.from_numpy(host).to(self.device, non_blocking=False)
+
+    def assign_batch(self, gts, check=False):
+        """``create_target`` for every sample of a step in ONE launch (data/dataset.py:113-118 runs it per
+        sample; config.py:135: four samples per step).  Returns ``(cls_targets[B,A,C], reg_targets[B,A,9])``."""
+        return self.assign_batch_device(*self.upload_batch(gts), check=check)
+
+    def assign_batch_device(self, g_counts, packed, check=False, out=None):
+        B, T = len(g_counts), int(sum(g_counts))
+        if packed.dtype != torch.float64 or packed.numel() < max(T, 1) * 19 or packed.device != self.device:
+            raise ValueError("packed ground truths: the f64 device buffer of upload_batch()")
+        if out is None:
+            out = (torch.empty((B, self.A, self.num_classes), dtype=torch.float32, device=self.device),
+                   torch.empty((B, self.A, 9), dtype=torch.float32, device=self.device))
+        cls_t, reg_t = out
+        if cls_t.shape != (B, self.A, self.num_classes) or reg_t.shape != (B, self.A, 9) or \
+                cls_t.dtype != torch.float32 or reg_t.dtype != torch.float32 or \
+                not (cls_t.is_contiguous() and reg_t.is_contiguous()):
+            raise ValueError("out: contiguous f32 (cls[B,A,C], reg[B,A,9])")
+        base = packed.data_ptr()
+        gp = [ctypes.c_void_p(base + 8 * T * k) if T else None for k in (0, 8, 11, 14, 17, 18)]
+        counts = (ctypes.c_int32 * B)(*g_counts)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.grid is not None:
+            c = self.grid
+            rc = _lib.lib().pp_assign_targets_grid_batch_dev(
+                self._ctx.handle, stream, B, counts, c.fm_height, c.fm_width, float(c.fm_scale), c.per_cell,
+                _vp(self.types), *gp, ctypes.byref(self._prm), _vp(cls_t), _vp(reg_t))
+        else:
+            rc = _lib.lib().pp_assign_targets_batch_dev(
+                self._ctx.handle, stream, B, counts, self.A, _vp(self.a_corners), _vp(self.a_centers),
+                _vp(self.a_wlh), _vp(self.a_yaw), *gp, ctypes.byref(self._prm), _vp(cls_t), _vp(reg_t))
+        _lib.check(rc, "pp_assign_targets_batch_dev")
+        if check:
+            _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_batch_dev")
+        return cls_t, reg_t
+
     def ious(self, g_corners_img, g_centers_img, check=True):
         """Dense [A,G] f64 IoU matrix on the device (make_ious, pillars.cpp:400-427)."""
         if self.grid is not None:

@@ -313,7 +313,7 @@ def main():
     gts_host = [synth.gt_boxes(40, cfg.canvas_height, s) for s in sweep_ids]
     gts = gts_host
     if a.mode == "train":   # boxes resident on the device like the points (a loader would prefetch them)
-        gts = [pipe.upload_ground_truth(g) for g in gts_host]
+        gts = pipe.upload_ground_truth_batch(gts_host)
 
     def train_step(p_, gts_):
         p_.model.zero_grad(set_to_none=True)
@@ -453,7 +453,7 @@ def main():
         torch.backends.cudnn.benchmark = False          # immediate mode, see above
         tp = PillarPipeline(cfg, device=dev, seed=0, with_targets=True)
         tp.model.train()
-        tg = [tp.upload_ground_truth(g) for g in gts_host]
+        tg = tp.upload_ground_truth_batch(gts_host)      # the step's boxes: one buffer, one launch for the batch
         for _ in range(3):
             train_step(tp, tg)
         torch.cuda.synchronize()
@@ -468,13 +468,36 @@ def main():
         tr_el = shard.max_over_ranks(ctx, time.perf_counter() - t3, device=dev)
         # the pieces, on this rank: target assignment of the batch, the two all-reduces
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_out = tp.assigner.assign_batch_device(*tg)
+        for _ in range(10):
+            tp.assigner.assign_batch_device(*tg, out=t_out)
+        e0.record()
+        for _ in range(100):
+            tp.assigner.assign_batch_device(*tg, out=t_out)
+        e1.record()
+        torch.cuda.synchronize()
+        assign_call_us = e0.elapsed_time(e1) * 1e3 / 100
+        assign_us = assign_call_us / a.batch
+        tg1 = [tp.upload_ground_truth(g) for g in gts_host]     # ... and one launch per sample (rounds 1-3)
+        for g in tg1:
+            tp.assigner.assign_device(*g)
         e0.record()
         for _ in range(20):
-            for g in tg:
+            for g in tg1:
                 tp.assigner.assign_device(*g)
         e1.record()
         torch.cuda.synchronize()
-        assign_us = e0.elapsed_time(e1) * 1e3 / (20 * len(tg))
+        assign1_us = e0.elapsed_time(e1) * 1e3 / (20 * len(tg1))
+        t_bytes = 112 * tp.assigner.A * a.batch
+        targets_rec = {"bound": "hbm by its bytes; measured: a chain of latencies (gate, clip rounds of f64, the "
+                                "last-workgroup tail) -- see DESIGN.md",
+                       "kernel": "pp::k_targets<false> (grid = samples x tiles of 256 anchors; one launch per step)",
+                       "bytes_per_launch": t_bytes, "bytes_what": "112 * A per sample (SURVEY 8d) x the batch",
+                       "us_per_call": assign_call_us, "achieved": t_bytes / (assign_call_us * 1e-6) / 1e9,
+                       "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": t_bytes / (assign_call_us * 1e-6) / HBM_PEAK,
+                       "one_sample_per_launch_us": assign1_us,
+                       "one_sample_per_launch_frac": 112 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK}
+        del tg1, t_out
         e0.record()
         for _ in range(10):
             shard.allreduce_gradients(ctx, tp.model.parameters())
@@ -485,7 +508,7 @@ def main():
         nbytes = sum(p_.numel() * p_.element_size() for p_ in tp.model.parameters() if p_.requires_grad)
         train = {"value": a.train_steps * a.batch * ctx.world_size / tr_el, "unit": "sweeps/s",
                  "ms_per_step": tr_el / a.train_steps * 1e3, "steps": a.train_steps,
-                 "target_assign_us_per_sweep": assign_us,
+                 "target_assign_us_per_sweep": assign_us, "targets": targets_rec,
                  "allreduce_ms": ar_ms if ctx.distributed else 0.0,
                  "collectives": {"backend": ctx.backend if ctx.distributed else None,
                                  "world_size": torch.distributed.get_world_size() if ctx.distributed else 1,
@@ -557,6 +580,19 @@ def main():
         t_us = e0.elapsed_time(e1) * 1e3 / 100
         refdef["target_assign_us"] = t_us
         refdef["target_assign_frac"] = 112 * ta.A / (t_us * 1e-6) / HBM_PEAK
+        gb_ = ta.upload_batch([synth.gt_boxes(40, 600, s) for s in range(a.batch)])   # the step's batch in one launch
+        ob_ = ta.assign_batch_device(*gb_)
+        for _ in range(10):
+            ta.assign_batch_device(*gb_, out=ob_)
+        e0.record()
+        for _ in range(50):
+            ta.assign_batch_device(*gb_, out=ob_)
+        e1.record()
+        torch.cuda.synchronize()
+        tb_us = e0.elapsed_time(e1) * 1e3 / 50
+        refdef["target_assign_batch"] = {"samples": a.batch, "us_per_call": tb_us, "us_per_sample": tb_us / a.batch,
+                                         "frac": 112 * ta.A * a.batch / (tb_us * 1e-6) / HBM_PEAK}
+        del gb_, ob_
         del ta
         torch.cuda.empty_cache()
 

@@ -285,6 +285,7 @@ int pp_make_ious_dev(pp_ctx_t *ctx, void *stream, const double *a_corners_dev,
  *   g_class [G] int32
  * Outputs f32 (data/dataset.py:117-118 casts to float):
  *   cls_targets [A,num_classes], reg_targets [A,9]
+ * Limits (PP_ERR_VALUE beyond): 1 <= A <= 16 776 960 anchors, 0 <= G <= 65535, 1..1024 classes.
  */
 typedef struct pp_target_params {
   double pos_thresh;    /* cfg.DATA.IOU_POS_THRESH, config.py:122 */
@@ -318,6 +319,38 @@ int pp_assign_targets_grid_dev(pp_ctx_t *ctx, void *stream, int fm_height, int f
                                const double *g_wlh_dev, const double *g_yaw_dev,
                                const int32_t *g_class_dev, const pp_target_params_t *prm,
                                float *cls_targets_dev, float *reg_targets_dev);
+
+/*
+ * The target assignment of ALL samples of a step in one launch.  The reference prepares
+ * BATCH_SIZE samples per step (config.py:135, train.py:120-121), each through create_target
+ * (data/dataset.py:113-118, utils/box_utils.py:162-232); the kernel is a chain of latencies, not
+ * bytes, so the samples' chains run side by side (grid.y = sample) instead of one after the other.
+ *   batch      1..PP_MAX_BATCH samples; the anchors are shared by all of them
+ *   g_counts   HOST array [batch]: sample b has g_counts[b] ground truths (0 allowed: its targets
+ *              are all zero), 0..65535 each
+ *   g_*        the samples' ground truths CONCATENATED in sample order: sample b owns rows
+ *              [g_counts[0]+..+g_counts[b-1], ..+g_counts[b]) of every g_ array (device memory, layouts
+ *              as pp_assign_targets_dev)
+ *   cls_targets [batch][A][num_classes], reg_targets [batch][A][9] f32
+ * Every sample's result equals what pp_assign_targets_dev / pp_assign_targets_grid_dev writes for
+ * that sample alone, bit for bit (same code; the list, counter, ticket and column scratch the
+ * last-workgroup tail depends on are per sample).
+ */
+int pp_assign_targets_batch_dev(pp_ctx_t *ctx, void *stream, int32_t batch, const int32_t *g_counts,
+                                int64_t A, const double *a_corners, const double *a_centers,
+                                const double *a_wlh, const double *a_yaw, const double *g_corners,
+                                const double *g_centers_img, const double *g_centers,
+                                const double *g_wlh, const double *g_yaw, const int32_t *g_class,
+                                const pp_target_params_t *prm, float *cls_targets,
+                                float *reg_targets);
+int pp_assign_targets_grid_batch_dev(pp_ctx_t *ctx, void *stream, int32_t batch,
+                                     const int32_t *g_counts, int fm_height, int fm_width,
+                                     double fm_scale, int per_cell, const double *anchor_types_dev,
+                                     const double *g_corners_dev, const double *g_centers_img_dev,
+                                     const double *g_centers_dev, const double *g_wlh_dev,
+                                     const double *g_yaw_dev, const int32_t *g_class_dev,
+                                     const pp_target_params_t *prm, float *cls_targets_dev,
+                                     float *reg_targets_dev);
 
 /*
  * Lidar sweep ingest pre-pass: replaces, per sweep, the point

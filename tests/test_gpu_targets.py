@@ -296,3 +296,172 @@ def test_repeated_calls_are_identical(gpu, oracle):
         torch.cuda.synchronize()
         assert bad == 0
         assert (r0[:, 0] == 1).sum().item() >= n_gt // 2
+
+
+# --------------------------------------------------------------------------- a batch of samples per launch
+def _ragged_batch(H, seeds, counts):
+    from pp_amd import synth
+    out = []
+    for s, n in zip(seeds, counts):
+        g = synth.gt_boxes(max(n, 1), H, s)
+        out.append({k: v[:n] for k, v in g.items()})
+    return out
+
+
+@pytest.mark.parametrize("source", ["arrays", "grid"])
+def test_batch_equals_per_sample_calls_and_oracle_config3(gpu, oracle, source):
+    """One launch for the B samples of a step (config.py:135: BATCH_SIZE = 4; data/dataset.py:113-118 per sample):
+    a ragged batch -- 40, 0, 17 and 33 boxes -- at BASELINE config 3 (A = 125 000) must give, sample by sample, the
+    bits of the single-sample call and the oracle's targets.  The list, counter, ticket and column scratch of the
+    last-workgroup tail are per sample: a shared ticket would show up here as a missing forced row."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    cfg = boxes.AnchorConfig(250, 250)
+    anchors = boxes.make_anchors(cfg)
+    ta = TargetAssigner(anchors if source == "arrays" else cfg, canvas_height=500, device=gpu)
+    gts = _ragged_batch(500, (0, 1, 2, 3), (40, 0, 17, 33))
+    cls_b, reg_b = ta.assign_batch(gts, check=True)
+    torch.cuda.synchronize()
+    assert cls_b.shape == (4, 125000, 9) and reg_b.shape == (4, 125000, 9)
+    for b, g in enumerate(gts):
+        c1, r1 = ta.assign(g["centers"], g["wlh"], g["yaw"], g["classes"], check=True)
+        assert torch.equal(cls_b[b], c1) and torch.equal(reg_b[b], r1), f"sample {b} differs from its own call"
+        if len(g["yaw"]):
+            ref_c, ref_r, _ = _oracle_targets(oracle, anchors, g, 500)
+            _check(cls_b[b], reg_b[b], ref_c, ref_r)
+        else:
+            assert not cls_b[b].any() and not reg_b[b].any()
+    # the same batch again, and a differently ragged one on the same context (the tails re-armed their words)
+    c2, r2 = ta.assign_batch(gts)
+    assert torch.equal(c2, cls_b) and torch.equal(r2, reg_b)
+    gts2 = [gts[3], gts[0], gts[2]]
+    c3, r3 = ta.assign_batch(gts2)
+    assert torch.equal(c3[0], cls_b[3]) and torch.equal(c3[1], cls_b[0]) and torch.equal(r3[2], reg_b[2])
+
+
+def test_batch_reference_default_anchor_set_full_size(gpu, oracle):
+    """config.py's shipped anchor set (540 000 anchors) as a batch of four, against the oracle per sample."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    cfg = boxes.AnchorConfig.reference_default()
+    anchors = boxes.make_anchors(cfg)
+    ta = TargetAssigner(cfg, canvas_height=600, device=gpu)
+    gts = _ragged_batch(600, (3, 4, 5, 6), (40, 25, 1, 31))
+    gts[0]["wlh"][::3, :2] = boxes.SMALL[:2] * 1.05
+    gts[0]["wlh"][1::3, :2] = boxes.LARGE[:2] * 0.95
+    cls_b, reg_b = ta.assign_batch(gts, check=True)
+    torch.cuda.synchronize()
+    for b, g in enumerate(gts):
+        ref_c, ref_r, _ = _oracle_targets(oracle, anchors, g, 600)
+        _check(cls_b[b], reg_b[b], ref_c, ref_r)
+
+
+def test_batch_all_empty_max_batch_and_bad_arguments(gpu, oracle):
+    import ctypes
+    import torch
+    from pp_amd import _lib, boxes, synth
+    from pp_amd.targets import TargetAssigner, _vp
+    cfg = boxes.AnchorConfig(40, 40)
+    anchors = boxes.make_anchors(cfg)
+    ta = TargetAssigner(cfg, canvas_height=80, device=gpu)
+    empty = {"centers": np.zeros((0, 3)), "wlh": np.zeros((0, 3)), "yaw": np.zeros(0), "classes": np.zeros(0, np.int32)}
+    c, r = ta.assign_batch([empty, empty, empty], check=True)
+    assert c.shape == (3, ta.A, 9) and not c.any() and not r.any()
+    # PP_MAX_BATCH samples, a different number of boxes each (incl. none), crowded small canvas
+    gts = _ragged_batch(80, range(100, 132), [(7 * k) % 23 for k in range(32)])
+    cls_b, reg_b = ta.assign_batch(gts, check=True)
+    torch.cuda.synchronize()
+    for b in (0, 1, 5, 17, 31):
+        g = gts[b]
+        if len(g["yaw"]) == 0:
+            assert not cls_b[b].any() and not reg_b[b].any()
+            continue
+        ref_c, ref_r, _ = _oracle_targets(oracle, anchors, g, 80)
+        _check(cls_b[b], reg_b[b], ref_c, ref_r)
+    with pytest.raises(ValueError):
+        ta.assign_batch(gts + [empty])                              # 33 samples
+    # C ABI: a negative count is refused before anything is launched
+    counts, packed = ta.upload_batch(gts[:2])
+    bad = (ctypes.c_int32 * 2)(3, -1)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(ta.device).cuda_stream)
+    out = torch.empty((2, ta.A, 9), dtype=torch.float32, device=gpu)
+    rc = _lib.lib().pp_assign_targets_grid_batch_dev(
+        ta._ctx.handle, stream, 2, bad, cfg.fm_height, cfg.fm_width, float(cfg.fm_scale), cfg.per_cell,
+        _vp(ta.types), *[ctypes.c_void_p(packed.data_ptr())] * 6, ctypes.byref(ta._prm), _vp(out), _vp(out))
+    assert rc == _lib.PP_ERR_VALUE and b"sample 1" in _lib.lib().pp_last_error()
+
+
+def test_batch_many_boxes_tail_beyond_lds(gpu, oracle):
+    """A sample with more ground truths than the tail keeps in LDS (> 2048: its column words live in the
+    sample's own slice of the global scratch) next to small samples."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    rng = np.random.default_rng(5)
+    cfg = boxes.AnchorConfig(40, 40)
+    anchors = boxes.make_anchors(cfg)
+    H = 80
+    gts = [_crowded_gt(rng, 30, H, 10, np.array([30.0, 40.0])), _crowded_gt(rng, 2100, H, 64, np.array([36.0, 48.0])),
+           _crowded_gt(rng, 12, H, 6, np.array([50.0, 20.0])), _crowded_gt(rng, 2060, H, 30, np.array([20.0, 60.0]))]
+    ta = TargetAssigner(cfg, canvas_height=H, pos_thresh=0.45, device=gpu)
+    for _ in range(2):
+        cls_b, reg_b = ta.assign_batch(gts, check=True)
+    torch.cuda.synchronize()
+    for b, g in enumerate(gts):
+        c_img, k_img = boxes.boxes_to_image_space(g["centers"], g["wlh"], g["yaw"], H)
+        ref_c, ref_r, _ = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                               anchors["yaw"], g["centers"], g["wlh"], g["yaw"], g["classes"], H,
+                                               pos_thresh=0.45)
+        _check(cls_b[b], reg_b[b], ref_c, ref_r)
+
+
+def test_batch_repeated_calls_are_identical(gpu, oracle):
+    """The 300-call soak of the single-sample form, for the batch: four tails run in one launch, each behind its
+    own ticket; cache-flushing traffic in between."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    for cfg, H in ((boxes.AnchorConfig(250, 250), 500), (boxes.AnchorConfig.reference_default(), 600)):
+        ta = TargetAssigner(cfg, canvas_height=H, device=gpu)
+        gts = _ragged_batch(H, (13, 14, 15, 16), (40, 35, 0, 22))
+        counts, packed = ta.upload_batch(gts)
+        c0, r0 = ta.assign_batch_device(counts, packed)
+        c0, r0 = c0.clone(), r0.clone()
+        out = (torch.empty_like(c0), torch.empty_like(r0))
+        junk = torch.empty((64 << 20,), dtype=torch.float32, device=gpu)
+        bad = 0
+        for it in range(300):
+            if it % 3 == 0:
+                junk.add_(1.0)
+            c, r = ta.assign_batch_device(counts, packed, out=out)
+            bad += int(not (torch.equal(c, c0) and torch.equal(r, r0)))
+        torch.cuda.synchronize()
+        assert bad == 0
+        assert (r0[0, :, 0] == 1).sum().item() >= 20 and not r0[2].any()
+
+
+def test_feature_map_scale_not_a_power_of_two(gpu, oracle):
+    """The anchor grid's cell centres are (x + .5) / fm_scale (box_utils.py:137-138).  For a power-of-two scale the
+    kernels multiply by the exact reciprocal; any other scale takes the true f64 division -- both must give the bits
+    of the uploaded make_anchors arrays and the oracle's targets."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    for scale, H in ((0.4, 150), (0.25, 240), (1.0, 60), (0.3, 200)):
+        cfg = boxes.AnchorConfig(60, 60, scale)
+        anchors = boxes.make_anchors(cfg)
+        gt = synth.gt_boxes(14, H, 21, margin=20.0)
+        ref_c, ref_r, _ = _oracle_targets(oracle, anchors, gt, H)
+        outs = []
+        for src in (cfg, anchors):
+            ta = TargetAssigner(src, canvas_height=H, device=gpu)
+            cls_t, reg_t = ta.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+            cb, rb = ta.assign_batch([gt, gt], check=True)
+            torch.cuda.synchronize()
+            assert torch.equal(cb[0], cls_t) and torch.equal(cb[1], cls_t) and torch.equal(rb[1], reg_t)
+            _check(cls_t, reg_t, ref_c, ref_r)
+            outs.append((cls_t, reg_t))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
+        assert (ref_r[:, 0] == 1).sum() > 0

@@ -106,3 +106,32 @@ def test_hip_target_assignment_equals_the_reference_run(gpu, cases, source):
         assert np.array_equal(cls_t, ref_c), name
         assert np.array_equal(reg_t[:, 0], ref_r[:, 0]) and np.array_equal(reg_t[:, 8], ref_r[:, 8]), name
         assert np.abs(reg_t - ref_r).max() <= REG_TOL, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["arrays", "grid"])
+def test_hip_batched_target_assignment_equals_the_reference_run(gpu, cases, source):
+    """The batch form (one launch for the samples of a step): the fixture's cases that share an anchor set go
+    through ONE pp_assign_targets*_batch_dev call each and must equal the reference's own outputs."""
+    import torch
+    from pp_amd.targets import TargetAssigner
+    groups = {}
+    for name, c in cases.items():
+        if "cls" not in c:
+            continue
+        key = (c["fm"].tobytes(), c["dims"].tobytes(), c["yaws_deg"].tobytes(), c["zs"].tobytes())
+        groups.setdefault(key, []).append(name)
+    assert max(len(v) for v in groups.values()) >= 2           # at least one real batch
+    for names in groups.values():
+        acfg, anchors, _, H, thresh = _setup(cases[names[0]])
+        ta = TargetAssigner(anchors if source == "arrays" else acfg, canvas_height=H, pos_thresh=thresh, device=gpu)
+        gts = [_setup(cases[n])[2] for n in names]
+        cls_b, reg_b = ta.assign_batch(gts, check=True)
+        torch.cuda.synchronize()
+        for b, name in enumerate(names):
+            c = cases[name]
+            cls_t, reg_t = cls_b[b].cpu().numpy(), reg_b[b].cpu().numpy()
+            ref_c, ref_r = c["cls"].astype(np.float32), c["reg"].astype(np.float32)
+            assert np.array_equal(cls_t, ref_c), name
+            assert np.array_equal(reg_t[:, 0], ref_r[:, 0]) and np.array_equal(reg_t[:, 8], ref_r[:, 8]), name
+            assert np.abs(reg_t - ref_r).max() <= REG_TOL, name
