@@ -201,12 +201,13 @@ class PPError(RuntimeError):
     pass
 
 
-def check(rc, what=""):
+def check(rc, what="", msg=None):
     """Map a PP_ERR_* code to the exception the reference's pybind11 module
-    raises for the same condition (IndexError) or to a loud failure."""
+    raises for the same condition (IndexError) or to a loud failure.  ``msg``: the error text, when the
+    caller read pp_last_error() before making further library calls."""
     if rc == PP_OK:
         return
-    msg = lib().pp_last_error().decode("utf-8", "replace")
+    msg = (msg if msg is not None else lib().pp_last_error()).decode("utf-8", "replace")
     msg = f"{what}: {msg}" if what else msg
     if rc == PP_ERR_INDEX:
         raise IndexError(msg)          # pybind11 index_error

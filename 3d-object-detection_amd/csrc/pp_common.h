@@ -55,7 +55,7 @@ struct GridGeom {
   unsigned long long barrett;         // floor(2^64 / ncells), for the device-side modulo
 };
 
-// step_mode: tile sizes for k_step's 4-wave tile role (more, smaller tiles)
+// step_mode: tile sizes for k_step's 4-wave tile role (half as many, fatter tiles: kTargetTiles / 2)
 int make_grid(const pp_voxel_params_t *prm, GridGeom *g, int step_mode = 0);
 
 #ifdef __HIPCC__
@@ -117,10 +117,10 @@ __device__ __forceinline__ double wave_minmax_f64(double v) {
 
 }  // namespace pp
 
-// A batch on its way through k_step's three roles (pp_voxelize_step_dev).
+// A batch on its way through k_step's four roles (pp_voxelize_step_dev): split, tile, order, emit.
 struct pp_step_batch {
   bool valid = false;
-  int slot = 0;      // workspace slot (1..3)
+  int slot = 0;      // workspace slot (1..4)
   int batch = 0, maxn = 0;
   int n_points[PP_MAX_BATCH] = {0};
   int64_t points_stride = 0;
@@ -138,6 +138,7 @@ struct pp_ctx {
   pp_step_batch step_batch[3];   // [0]: split done, waits for its tile role; [1]: tiled, waits for the order role;
                                  // [2]: descriptors in pillar order, waits for its emit role
   int step_next_slot = 1;
+  hipStream_t step_stream = nullptr;  // the stream the batches in flight were submitted on
   bool sort_lds_armed = false;     // k_sort_runs' dynamic-LDS attribute set on this context's device
   int force_tile_waves = 0;  // development knob: PP_TILE_WAVES in the environment
   size_t dbg_stamps_off = 0, dbg_stamps_bytes = 0;  // PP_STAMPS builds (tools/lab)

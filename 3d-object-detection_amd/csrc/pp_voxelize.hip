@@ -1471,15 +1471,16 @@ __global__ __launch_bounds__(kEmitThreads, emit_minwaves(MODE)) void k_emit(Emit
 }
 
 // ------------------------------------------------------------------------- //
-// k_step: the three stages of three CONSECUTIVE batches in one launch         //
+// k_step: the four stages of four CONSECUTIVE batches in one launch           //
 // ------------------------------------------------------------------------- //
 // Software pipelining across calls.  k_split / k_tile are latency chains that leave the memory system
-// idle, k_emit is the dense store; inside one call they depend on each other, but tile(batch i-1),
-// split(batch i) and emit(batch i-2) do not.  One launch runs all three as ROLES of one grid -- the
-// block id decides: first the tile role's workgroups, then the split role's, then the emit role's
-// (the few latency-bound ones are dispatched first and run beside the thousands that store) -- and
-// the launch boundary is the only synchronisation: the tile role reads what the previous launch's
-// split role wrote, the emit role what the previous launch's tile role wrote.  One launch per call
+// idle, k_emit is the dense store; inside one call they depend on each other, but split(batch i),
+// tile(batch i-1), order(batch i-2: the tiles' descriptor lists copied into pillar order) and
+// emit(batch i-3) do not.  One launch runs all four as ROLES of one grid -- the block id decides: a
+// prefetch role first, then groups of {one binning block, one emit block} (tile role, order role,
+// split role: the few latency-bound ones are dispatched early and run beside the thousands that
+// store), then the remaining emit blocks -- and the launch boundary is the only synchronisation:
+// every role reads what a role of the PREVIOUS launch wrote for its batch.  One launch per call
 // instead of three, one drain instead of three, and the binning chains hide behind the store.
 // All roles run 256-thread workgroups (emit: 4 waves x 4 pillars as in k_emit; tile: 4 waves; split:
 // 4 physical waves x 4 virtual waves) and share the dynamic LDS.
@@ -1903,6 +1904,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
       ev0[k] = ctx->ev_start[k][ctx->ev_next];
       ev1[k] = ctx->ev_stop[k][ctx->ev_next];
     }
+    if (ctx->ev_columns != 7) ctx->ev_count = 0;  // the ring held k_step launches: their entries have no split / tile pair
     ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
     ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
     ctx->ev_columns = 7;  // all three kernels recorded
@@ -1990,7 +1992,7 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-      // the armed invariant (look-back words zero) can no longer be assumed
+      // whatever the slot holds is unknown now: lay it out (and clear it) again on the next call
       std::memset(ctx->vox_layout_key[slot], 0, sizeof ctx->vox_layout_key[slot]);
       set_error("voxelizer launch failed: %s", hipGetErrorString(e));
       return PP_ERR_HIP;
@@ -2187,6 +2189,13 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(ctx->device);
   pp_step_batch &sb_tile = ctx->step_batch[0], &sb_order = ctx->step_batch[1], &sb_emit = ctx->step_batch[2];
+  // Stream order is what carries a batch from one role to the next: a call on another stream while batches
+  // are in flight would race with the launch that wrote what it reads.
+  if ((sb_tile.valid || sb_order.valid || sb_emit.valid) && stream != ctx->step_stream) {
+    set_error("pp_voxelize_step_dev: pipeline in flight on another stream (drain it, or pp_voxelize_step_reset)");
+    return PP_ERR_VALUE;
+  }
+  ctx->step_stream = stream;
   if (sb_emit.valid) {
     if (!pillars_dev || !indices_dev) {
       set_error("pp_voxelize_step_dev: a batch is due, its output buffers are NULL");
@@ -2377,7 +2386,8 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->ev_slots > 0) {
-      e0 = ctx->ev_start[PP_KERNEL_EMIT][ctx->ev_next];
+      if (ctx->ev_columns != (1 << PP_KERNEL_EMIT)) ctx->ev_count = 0;  // the ring held three-launch calls: do not
+      e0 = ctx->ev_start[PP_KERNEL_EMIT][ctx->ev_next];                   // mix k_emit and k_step durations
       e1 = ctx->ev_stop[PP_KERNEL_EMIT][ctx->ev_next];
       ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
       ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
@@ -2402,6 +2412,9 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
   sb_emit = sb_order;
   sb_order = sb_tile;
   sb_tile = sb_new;
+  // slots 1..kVoxSlots-1 rotate: a slot comes round again only after its batch was emitted, which takes
+  // as many calls as there are batches in flight
+  static_assert(pp_ctx::kVoxSlots - 1 >= 4, "one workspace slot per batch in flight (split, tile, order, emit)");
   if (sb_new.valid) ctx->step_next_slot = ctx->step_next_slot % (pp_ctx::kVoxSlots - 1) + 1;
   return PP_OK;
 }

@@ -40,6 +40,8 @@ class PillarPipeline:
         self._bufs = None
         self._fbufs = None
         self._cbuf = None
+        self._cidx = None          # the indices of the last fused-scatter call: the canvas's non-zero pixels
+        self._canvas_key = None
         #: forward_fused also fuses PPScatter and runs the backbone channels-last
         self.fused_scatter = True
 
@@ -87,8 +89,8 @@ class PillarPipeline:
         if points.dim() == 2:
             points = points.unsqueeze(0)
         B = points.shape[0]
+        P = self.vox_cfg.max_pillars
         if self._fbufs is None or self._fbufs[0].shape[0] != B:
-            P = self.vox_cfg.max_pillars
             self._fbufs = (torch.empty((B, 64, P), dtype=torch.float32, device=self.device),
                            torch.empty((B, P, 3), dtype=torch.int64, device=self.device))
         if self.fused_scatter:
@@ -96,12 +98,17 @@ class PillarPipeline:
             # channels-last canvas pixel
             H, W = self.model.scatter.h, self.model.scatter.w
             cbuf = self._canvas(B, H, W)
-            # the canvas and index buffers are this pipeline's own and nothing else writes them: after the
-            # first call only the previous call's pixels are non-zero, and only those are cleared again
-            key = (cbuf.data_ptr(), self._fbufs[1].data_ptr(), B)
+            # The canvas and ITS index buffer are written by this branch only (the feature path below has its
+            # own indices): after the first call only the previous call's pixels are non-zero, and only those
+            # are cleared again.  The key is dropped before the call, so an error cannot leave a stale one.
+            if self._cidx is None or self._cidx.shape[0] != B:
+                self._cidx = torch.empty((B, P, 3), dtype=torch.int64, device=self.device)
+                self._canvas_key = None
+            key = (cbuf.data_ptr(), self._cidx.data_ptr(), B)
+            reuse = self._canvas_key == key
+            self._canvas_key = None
             canvas, _ = self.voxelizer.pfn_canvas(points, pfn_params, (H, W), n_points=n_points,
-                                                  out=(cbuf, self._fbufs[1]),
-                                                  reuse=(getattr(self, "_canvas_key", None) == key))
+                                                  out=(cbuf, self._cidx), reuse=reuse)
             self._canvas_key = key
             return self.model.forward_canvas(canvas)
         feats, indices = self.voxelizer.pfn(points, pfn_params, n_points=n_points, out=self._fbufs)

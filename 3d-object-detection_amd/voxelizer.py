@@ -254,8 +254,14 @@ class PillarVoxelizer:
             vp(indices.data_ptr()) if indices is not None else None,
             vp(counts.data_ptr()) if counts is not None else None, ctypes.byref(emitted))
         if rc != _lib.PP_OK:
+            # One rule for both sides: a failed submit abandons the batches in flight (their results are never
+            # returned) and the next submit starts a fresh pipeline.  (The C side alone keeps its batches when it
+            # rejects a call before the launch and drops them when the launch fails; without the reset here the
+            # two could disagree about what is due.)
+            msg = _lib.lib().pp_last_error()
+            _lib.lib().pp_voxelize_step_reset(self._ctx.handle)
             self._inflight = [None, None, None]
-        _lib.check(rc, "pp_voxelize_step_dev")
+            _lib.check(rc, "pp_voxelize_step_dev (pipeline reset)", msg)
         self._inflight = [nxt[1] if nxt else None, inflight[0], inflight[1]]
         if due is None:
             return None

@@ -409,7 +409,8 @@ def main():
         # per pillar, the indices, and the canvas clear (the dense [9,P,N] tensor does not exist here)
         pfn_tab = pipe.model.feature_net.fused_table(dev)
         H_, W_ = pipe.model.scatter.h, pipe.model.scatter.w
-        f_out = (pipe._canvas(a.batch, H_, W_), pipe._fbufs[1])
+        f_out = (pipe._canvas(a.batch, H_, W_), torch.empty((a.batch, P, 3), dtype=torch.int64, device=dev))
+        pipe._canvas_key = None      # the pipeline's record of the canvas's non-zero pixels ends here
 
         def fused_wall(reuse):
             for _ in range(10):

@@ -104,8 +104,9 @@ int pp_voxelize_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
  *                 call's batch / prm shapes; may be NULL while no batch is due
  *   emitted       (may be NULL) 1 when this call wrote outputs, else 0
  * Everything runs on `stream` -- the SAME stream for all calls of one pipeline (stream order is what
- * carries a batch from one stage to the next); plain calls on the same context are unaffected (own
- * workspace).
+ * carries a batch from one stage to the next): a call on another stream while batches are in flight is
+ * refused with PP_ERR_VALUE and changes nothing (drain first, or pp_voxelize_step_reset); plain calls on
+ * the same context are unaffected (own workspace).
  * HIP graphs: a single call must NOT be captured and replayed -- the workspace slot of every stage
  * rotates from call to call on the host, and a replay would repeat one call's slots.  (The plain
  * pp_voxelize_dev is the capturable form.)

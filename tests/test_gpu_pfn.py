@@ -188,6 +188,43 @@ def test_fused_scatter_pipeline_equals_dense_pipeline(gpu):
         assert (r - r0).abs().max().item() <= 1e-4 * max(1.0, r0.abs().max().item()), name
 
 
+def test_fused_scatter_toggled_between_clouds_never_sees_stale_pixels(gpu):
+    """forward_fused clears only the pixels ITS previous fused-scatter call wrote.  Order that broke it: fused
+    scatter on cloud A, the feature path (fused_scatter False) on cloud B, fused scatter on cloud C -- with one
+    shared index buffer the sparse clear zeroed B's pixels and A's stayed.  Every call must equal a
+    fresh pipeline's result for its cloud."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    cfg = VoxelConfig.square(16.0, 0.2, 4000, 32)
+    pipe = PillarPipeline(cfg, feature_channels=64, device=gpu, seed=0)
+    pipe.model.eval()
+    clouds = [torch.from_numpy(np.stack([synth.lidar_like(n, r, s) for s in (sd, sd + 1)])).to(gpu)
+              for n, r, sd in ((15000, 16.0, 3), (9000, 6.0, 40), (12000, 11.0, 80), (15000, 16.0, 3))]
+
+    def fresh(pts):
+        q = PillarPipeline(cfg, feature_channels=64, device=gpu, seed=0)
+        q.model.eval()
+        return tuple(t.clone() for t in q.forward_fused(pts))
+    want = [fresh(c) for c in clouds]
+    for k, (pts, fs) in enumerate(zip(clouds, (True, False, True, True))):
+        pipe.fused_scatter = fs
+        c, r = pipe.forward_fused(pts)
+        torch.cuda.synchronize()
+        tol = 1e-4 if not fs else 2e-6          # the same path up to MIOpen's choice of algorithm (a stale pixel
+                                                # carries a whole feature vector: errors of 1e-2 and more)
+        assert (c - want[k][0]).abs().max().item() <= tol * max(1.0, want[k][0].abs().max().item()), k
+        assert (r - want[k][1]).abs().max().item() <= tol * max(1.0, want[k][1].abs().max().item()), k
+    # a raised error must not leave a key that claims the canvas is known
+    pipe.fused_scatter = True
+    with pytest.raises(ValueError):
+        pipe.forward_fused(clouds[0].double())
+    assert pipe._canvas_key is None
+    c, r = pipe.forward_fused(clouds[2])
+    assert (c - want[2][0]).abs().max().item() <= 2e-6 and (r - want[2][1]).abs().max().item() <= 2e-6
+
+
 def test_training_feature_net_matches_pytorch_autograd(gpu):
     """PPFeatureNet in train() on the HIP kernels (batch statistics, forward, parameter
     gradients; no [B,64,P,N] intermediate) against the PyTorch module sequence + autograd in

@@ -218,6 +218,15 @@ def test_full_size_configs(gpu, oracle, cfg, order):
     assert np.array_equal(live[:nrow], np.minimum(want, N))
     ref_p, ref_i, m = oracle_stage(oracle, pts, P, N, cfg["half"], cfg["step"], order=order)
     assert _check_exact(pil, idx, ref_p, ref_i)
+    # ... and the same cloud through the software-pipelined form (k_step: submit, then drain), against the
+    # ORACLE's arrays directly, not only against the three-launch path
+    import torch
+    t = torch.from_numpy(pts).to(gpu)[None]
+    outs = [vox.submit(t, return_counts=True)] + [vox.submit(None, return_counts=True) for _ in range(vox.LAG)]
+    torch.cuda.synchronize()
+    assert [o is None for o in outs] == [True] * vox.LAG + [False]
+    sp, si, sc = (x.cpu().numpy() for x in outs[-1])
+    assert np.array_equal(sc, cnt) and np.array_equal(sp[0], ref_p) and np.array_equal(si[0], ref_i)
 
 
 def test_hip_graph_capture_and_replay(gpu, oracle):
@@ -529,3 +538,80 @@ def test_pipelined_mode_soak(gpu):
     bad = [k for k, (r, i) in enumerate(zip(got, order))
            if not (torch.equal(r[0], want[i][0]) and torch.equal(r[1], want[i][1]))]
     assert not bad, bad[:10]
+
+
+def test_pipelined_mode_stream_is_enforced_and_failed_submit_resets(gpu):
+    """pp_voxelize_step_dev carries a batch from role to role by STREAM ORDER: a submit on another stream while
+    batches are in flight is refused (PP_ERR_VALUE, "another stream") instead of racing; once drained, any stream
+    may start the next pipeline.  And a submit that is rejected in the middle of a full pipeline (here: more
+    sweeps than PP_MAX_BATCH) abandons the batches in flight on BOTH sides -- the next submits start an empty
+    pipeline instead of failing with 'a batch is due'."""
+    import torch
+    from pp_amd import synth
+    half, step, P, N = 20.0, 0.25, 2000, 16
+    a, b = _vox(gpu, half, step, P, N, order=1), _vox(gpu, half, step, P, N, order=1)
+    ts = [torch.from_numpy(synth.lidar_like(6000, half, 70 + i)).to(gpu)[None] for i in range(3)]
+    want = [tuple(x.clone() for x in a(t)) for t in ts]
+    other = torch.cuda.Stream(device=gpu)
+    assert b.submit(ts[0]) is None and b.submit(ts[1]) is None
+    torch.cuda.synchronize()
+    with torch.cuda.stream(other):
+        with pytest.raises(ValueError, match="another stream"):
+            b.submit(ts[2])
+    # the refusal reset the pipeline (one rule for every failed submit): start again, on the other stream
+    with torch.cuda.stream(other):
+        outs = list(b.stream(ts))
+    other.synchronize()
+    assert len(outs) == 3 and all(torch.equal(o[0], w[0]) and torch.equal(o[1], w[1]) for o, w in zip(outs, want))
+    # C ABI directly: the refusal itself changes nothing -- the batches in flight come out on their own stream
+    import ctypes
+    from pp_amd import _lib
+    c = _vox(gpu, half, step, P, N, order=1)
+    assert c.submit(ts[0]) is None
+    s_other = ctypes.c_void_p(other.cuda_stream)
+    em = ctypes.c_int(0)
+    n1 = (ctypes.c_int32 * 1)(6000)
+    rc = _lib.lib().pp_voxelize_step_dev(c._ctx.handle, s_other, ctypes.c_void_p(ts[1].data_ptr()), 6000, n1, 1,
+                                         ctypes.byref(c._prm), None, None, None, ctypes.byref(em))
+    assert rc == _lib.PP_ERR_VALUE and b"another stream" in _lib.lib().pp_last_error()
+    got = [c.submit(None) for _ in range(c.LAG)]
+    torch.cuda.synchronize()
+    assert got[:2] == [None, None] and torch.equal(got[2][0], want[0][0]) and torch.equal(got[2][1], want[0][1])
+    # a rejected submit in the middle of a FULL pipeline
+    d = _vox(gpu, half, step, P, N, order=1)
+    for t in ts:
+        assert d.submit(t) is None
+    too_many = torch.zeros((33, 16, 4), device=gpu)                 # PP_MAX_BATCH is 32
+    with pytest.raises(ValueError):
+        d.submit(too_many)
+    assert d.submit(None) is None                                    # nothing is due any more, on either side
+    outs = list(d.stream(ts[:2]))
+    torch.cuda.synchronize()
+    assert len(outs) == 2 and torch.equal(outs[0][0], want[0][0]) and torch.equal(outs[1][1], want[1][1])
+
+
+def test_timing_ring_does_not_mix_launch_kinds(gpu):
+    """pp_ctx_read_kernel_ms after plain calls FOLLOWING pipelined calls (and the other way round) without a
+    set_timing in between: only the entries of the current kind are reported -- no stale or never-recorded
+    event pairs, no k_emit durations among k_step's."""
+    import torch
+    from pp_amd import _lib, synth
+    half, step, P, N = 20.0, 0.25, 2000, 16
+    v = _vox(gpu, half, step, P, N, order=1)
+    t = torch.from_numpy(synth.lidar_like(6000, half, 3)).to(gpu)[None]
+    v.set_timing(8)
+    for _ in range(5):
+        v.submit(t)                                   # five k_step launches
+    for _ in range(2):
+        v(t)                                          # then two three-launch calls
+    torch.cuda.synchronize()
+    sp, tl, em = (v.read_kernel_ms(w) for w in (_lib.KERNEL_SPLIT, _lib.KERNEL_TILE, _lib.KERNEL_EMIT))
+    assert len(sp) == len(tl) == len(em) == 2 and all(0 < x < 50 for x in sp + tl + em)
+    for _ in range(3):
+        v(t)
+    for _ in range(4):
+        v.submit(t)
+    torch.cuda.synchronize()
+    assert v.read_kernel_ms(_lib.KERNEL_SPLIT) == [] and len(v.read_kernel_ms(_lib.KERNEL_EMIT)) == 4
+    v.set_timing(0)
+    v.reset_stream()
