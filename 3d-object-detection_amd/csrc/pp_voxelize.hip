@@ -726,6 +726,8 @@ struct EmitArgs {
 enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 };
 constexpr int kAuxPlain = 0, kAuxSc1 = 16;           // buffer-store cache policy bits (gfx950: sc1 = 16)
 constexpr size_t kSc1MaxBytes = 128u << 20;          // write-through stores pay off up to about half the Infinity Cache
+constexpr size_t kStepLaunchBytes = 0;               // dense output per k_step launch; 0 = one launch per call (see
+                                                     // pp_voxelize_step_dev: splitting was measured and gains nothing)
 
 
 // Fused PPFeatureNet (inference): y[c,p] = max_n BN_c(ReLU(b_c + sum_d W[c,d] x[d,p,n]))
@@ -1523,7 +1525,7 @@ struct PrefetchRole {
 // The emit role of the NEXT launch then starts with one descriptor load instead of prefix + search + load.
 struct OrderRole {
   GridGeom g;
-  int P, B;
+  int P, B, b0;   // this launch: sweeps [b0, b0 + B) of the batch
   const int4 *tile_meta;
   const u64 *tile_agg;
   int4 *ordered_meta;
@@ -1533,7 +1535,7 @@ __device__ __forceinline__ void order_body(const OrderRole &o, int blk) {
   const int lane = threadIdx.x & 63, wid = blk * kEmitWaves + (threadIdx.x >> 6);
   const int ntiles = o.g.ntiles;
   if (wid >= o.B * ntiles) return;
-  const int b = wid / ntiles, t = wid - b * ntiles;
+  const int b = o.b0 + wid / ntiles, t = wid - (wid / ntiles) * ntiles;
   const u64 *agg = o.tile_agg + (int64_t)b * ntiles;
   const int nv = (ntiles + kWave - 1) / kWave;
   u64 before = 0, all = 0;
@@ -1561,10 +1563,14 @@ __device__ __forceinline__ void order_body(const OrderRole &o, int blk) {
 
 struct StepArgs {
   int n_pref_blocks;
+  int n_unscatter_blocks;  // fused feature-net form: un.nblocks workgroups per sample of the canvas being cleared
+  UnscatterArgs un;
   int n_order_blocks;
   OrderRole o;
   PrefetchRole pf;
   int n_tile_blocks, n_split_blocks, emit_nbx;
+  int tile_b0, split_b0, emit_b0;  // first sweep of each role's batch in this launch (a call whose dense output is
+                                   // beyond the Infinity Cache goes out as several launches, a few sweeps each)
   int mix, mix_groups;  // block order: mix_groups groups of {1 binning block, mix-1 emit blocks}, then the rest
   TileRole t;
   SplitRole s;
@@ -1574,8 +1580,12 @@ constexpr int kStepWaves = 4;
 constexpr int kStepThreads = kStepWaves * kWave;
 static_assert(kStepWaves == kEmitWaves, "the emit role is k_emit's workgroup");
 
+#ifndef PP_STEP_PFN_MINWAVES
+#define PP_STEP_PFN_MINWAVES 5
+#endif
+constexpr int step_minwaves(int mode) { return mode == kModePfn ? PP_STEP_PFN_MINWAVES : 5; }
 template <int MODE, int AUX>
-__global__ __launch_bounds__(kStepThreads, 5) void k_step(StepArgs a) {   // five waves per SIMD: <= 96 VGPRs
+__global__ __launch_bounds__(kStepThreads, step_minwaves(MODE)) void k_step(StepArgs a) {   // five waves per SIMD: <= 96 VGPRs
   extern __shared__ __attribute__((aligned(32))) unsigned char step_smem[];
   int id = (int)blockIdx.x;
   if (id < a.n_pref_blocks) {
@@ -1607,6 +1617,16 @@ __global__ __launch_bounds__(kStepThreads, 5) void k_step(StepArgs a) {   // fiv
     return;
   }
   id -= a.n_pref_blocks;
+  if constexpr (MODE == kModePfn) {
+    // CLEAR role (fused feature-net form): zero the pixels of the OTHER canvas -- the one the previous call
+    // filled and the network has consumed since; its indices say which.  The canvas this launch's emit role
+    // writes was cleared the same way one call ago, so neither role waits for the other.
+    if (id < a.n_unscatter_blocks) {
+      unscatter_body(a.un, id % a.un.nblocks, id / a.un.nblocks, kStepThreads);
+      return;
+    }
+    id -= a.n_unscatter_blocks;
+  }
   // Block order.  Workgroups are dispatched in id order.  The binning roles' (tile, split) are few and
   // latency-bound, the emit role's many and store-bound: the grid starts with groups of one binning block
   // and mix-1 emit blocks, so that the stores flow from the first microsecond AND every binning chain starts
@@ -1625,7 +1645,7 @@ __global__ __launch_bounds__(kStepThreads, 5) void k_step(StepArgs a) {   // fiv
   }
   if (id < a.n_tile_blocks) {
     const int nt = a.t.g.ntiles;
-    const int b = id / nt, tile = id - b * nt;
+    const int b = a.tile_b0 + id / nt, tile = id - (id / nt) * nt;
     tile_body<float, kStepWaves>(a.t.np, a.t.g, a.t.ncap, a.t.nchunks_cap, a.t.kslot,
                                  reinterpret_cast<const float4 *>(a.t.kpts), a.t.mat,
                                  reinterpret_cast<float4 *>(a.t.sorted_pts), a.t.tile_meta, a.t.tile_agg,
@@ -1640,15 +1660,16 @@ __global__ __launch_bounds__(kStepThreads, 5) void k_step(StepArgs a) {   // fiv
   id -= a.n_order_blocks;
   if (id < a.n_split_blocks) {
     const int nc = a.s.nchunks;
-    const int b = id / nc, chunk = id - b * nc;
+    const int b = a.split_b0 + id / nc, chunk = id - (id / nc) * nc;
     split_body<float, kStepWaves>(reinterpret_cast<const float *>(a.s.pts), a.s.sweep_stride, 4, 1, 1, a.s.np,
                                   a.s.g, a.s.ncap, a.s.nchunks_cap, a.s.kslot,
                                   reinterpret_cast<float4 *>(a.s.kpts), a.s.mat, step_smem, chunk, b);
     return;
   }
   id -= a.n_split_blocks;
-  const int b = id / a.emit_nbx, bx = id - b * a.emit_nbx;
-  emit_body<float, MODE, AUX, CAPW, true>(a.e, reinterpret_cast<WaveLds<float, CAPW> *>(step_smem), bx, b, a.emit_nbx);
+  const int b = a.emit_b0 + id / a.emit_nbx, bx = id - (id / a.emit_nbx) * a.emit_nbx;
+  emit_body<float, MODE, AUX, emit_cap(MODE), true>(a.e, reinterpret_cast<WaveLds<float, emit_cap(MODE)> *>(step_smem), bx,
+                                                    b, a.emit_nbx);
 }
 
 // ------------------------------------------------------------------------- //
@@ -2177,10 +2198,21 @@ int step_geometry(const pp_step_batch &sb, GridGeom *g, VoxLayout *l) {
 }
 }  // namespace
 
-extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
-                                    int64_t points_stride, const int32_t *n_points, int batch,
-                                    const pp_voxel_params_t *prm, float *pillars_dev,
-                                    int64_t *indices_dev, int32_t *num_cells_dev, int *emitted) {
+namespace {
+// the emit role as the fused feature net (pp_voxelize_step_pfn_canvas_dev): canvas instead of the dense tensor
+struct StepPfn {
+  const float *params;            // [64][12]
+  float *canvas;                  // receives the batch that is due; all zero on entry
+  int h, w, nhwc;
+  float *clear_canvas;            // the other canvas (may be NULL) ...
+  const int64_t *clear_indices;   // ... and the indices of the batch that filled it: its non-zero pixels
+  int clear_batch;
+};
+}  // namespace
+
+static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int64_t points_stride,
+                     const int32_t *n_points, int batch, const pp_voxel_params_t *prm, float *pillars_dev,
+                     int64_t *indices_dev, int32_t *num_cells_dev, int *emitted, const StepPfn *pfn) {
   if (emitted) *emitted = 0;
   if (!ctx) {
     set_error("ctx is NULL");
@@ -2197,8 +2229,14 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
   }
   ctx->step_stream = stream;
   if (sb_emit.valid) {
-    if (!pillars_dev || !indices_dev) {
-      set_error("pp_voxelize_step_dev: a batch is due, its output buffers are NULL");
+    if (!(pfn ? (void *)pfn->canvas : (void *)pillars_dev) || !indices_dev) {
+      set_error("pp_voxelize_step*_dev: a batch is due, its output buffers are NULL");
+      return PP_ERR_VALUE;
+    }
+    if (pfn && (!pfn->params || (reinterpret_cast<uintptr_t>(pfn->canvas) & 15) || pfn->h < 1 || pfn->w < 1 ||
+                (double)pfn->h != sb_emit.prm.canvas_height)) {
+      set_error("pp_voxelize_step_pfn_canvas_dev: canvas %dx%d: height must equal the due batch's canvas_height=%g "
+                "(16-byte aligned tensor, parameters not NULL)", pfn->h, pfn->w, sb_emit.prm.canvas_height);
       return PP_ERR_VALUE;
     }
     if ((reinterpret_cast<uintptr_t>(pillars_dev) & 15) || (reinterpret_cast<uintptr_t>(indices_dev) & 7) ||
@@ -2291,8 +2329,7 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     a.n_order_blocks = (g.ntiles * sb_order.batch + kEmitWaves - 1) / kEmitWaves;   // one wave per (sweep, tile)
   }
   int mode = kModeDenseVec4;
-  bool sc1 = false;
-  int n_emit_blocks = 0;
+  bool sc1 = false;  // write-through stores: decided per launch, by the bytes it writes
   if (sb_emit.valid) {
     GridGeom g;
     VoxLayout l;
@@ -2314,68 +2351,139 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
     a.e.out = pillars_dev;
     a.e.idx_out = reinterpret_cast<long long *>(indices_dev);
     a.emit_nbx = (P + KW * kEmitWaves - 1) / (KW * kEmitWaves);
-    n_emit_blocks = a.emit_nbx * sb_emit.batch;
     mode = (N % 4 == 0 && N <= 4096) ? kModeDenseVec4 : kModeDenseScalar;
-    static const int forced = [] {  // development knob: PP_EMIT_SC1=0/1
-      const char *e = getenv("PP_EMIT_SC1");
-      return e ? (atoi(e) ? 1 : 0) : -1;
-    }();
-    sc1 = forced >= 0 ? forced == 1 : (size_t)sb_emit.batch * 36u * (size_t)P * (size_t)N <= kSc1MaxBytes;
-    lds = std::max(lds, sizeof(WaveLds<float>) * kEmitWaves);
+    lds = std::max(lds, pfn ? sizeof(WaveLds<float, emit_cap(kModePfn)>) * kEmitWaves : sizeof(WaveLds<float>) * kEmitWaves);
+    if (pfn) {
+      mode = kModePfn;
+      a.e.out = nullptr;
+      a.e.pfn_w = pfn->params;
+      a.e.pfn_out = nullptr;
+      a.e.canvas = pfn->canvas;
+      a.e.canvas_h = pfn->h;
+      a.e.canvas_w = pfn->w;
+      a.e.canvas_nhwc = pfn->nhwc;
+    }
+  }
+  if (pfn && pfn->clear_canvas && pfn->clear_indices && pfn->clear_batch > 0) {
+    // the other canvas: only the pixels its last batch wrote are non-zero (same geometry as the due batch's)
+    if ((reinterpret_cast<uintptr_t>(pfn->clear_canvas) & 15) || (reinterpret_cast<uintptr_t>(pfn->clear_indices) & 7) ||
+        pfn->clear_batch > PP_MAX_BATCH || !sb_emit.valid) {
+      set_error("pp_voxelize_step_pfn_canvas_dev: bad clear arguments (alignment, batch <= %d, and a batch must be due "
+                "whose shapes describe the canvas)", PP_MAX_BATCH);
+      return PP_ERR_VALUE;
+    }
+    a.un.prev_idx = reinterpret_cast<const long long *>(pfn->clear_indices);
+    a.un.canvas = pfn->clear_canvas;
+    a.un.P = sb_emit.prm.max_pillars;
+    a.un.h = pfn->h;
+    a.un.w = pfn->w;
+    a.un.nhwc = pfn->nhwc;
+    a.un.nblocks = (a.un.P + kUnscatterPixels - 1) / kUnscatterPixels;
+    a.n_unscatter_blocks = a.un.nblocks * pfn->clear_batch;
   }
   if (a.emit_nbx == 0) a.emit_nbx = 1;
-  {
-    static const int pref_blocks = [] {  // development knob: PP_STEP_PREFETCH=<workgroups> (0 = off)
-      const char *e = getenv("PP_STEP_PREFETCH");
-      return e ? std::max(0, atoi(e)) : 128;
-    }();
-    int r = 0;
-    auto add = [&](const void *ptr, size_t bytes) {
-      a.pf.ptr[r] = ptr;
-      a.pf.n16[r] = (unsigned)(bytes / 16);
-      ++r;
+  static const int pref_blocks = [] {  // development knob: PP_STEP_PREFETCH=<workgroups> (0 = off)
+    const char *e = getenv("PP_STEP_PREFETCH");
+    return e ? std::max(0, atoi(e)) : 128;
+  }();
+  static const int mix_env = [] {  // development knob: PP_STEP_MIX=m (1 = binning blocks first)
+    const char *e = getenv("PP_STEP_MIX");
+    return e ? std::max(1, atoi(e)) : 0;
+  }();
+  // A call CAN go out as several launches of a few sweeps each (sweeps are independent, so every role's
+  // batch splits the same way).  Round 3's driver line suggested it should when the dense output exceeds the
+  // 256 MB Infinity Cache: per sweep, one 172.8 MB sweep per launch ran at 0.73 of the roofline, four in
+  // one launch at 0.64.  Measured in round 4 (tools/lab/sweep_sub.sh): four launches of one sweep each take
+  // 154 us against 146 us for the one launch -- the one-sweep figure came from re-writing the SAME 172.8 MB
+  // buffer call after call, which the memory-side cache absorbs; four launches writing four different
+  // regions go to HBM like the single launch does, and pay three more launch ramps.  Default: one launch.
+  static const size_t sub_bytes = [] {  // development knob: PP_STEP_SUB_MB (dense MB per launch; 0 = never split)
+    const char *e = getenv("PP_STEP_SUB_MB");
+    return e ? (size_t)std::max(0, atoi(e)) << 20 : kStepLaunchBytes;
+  }();
+  int n_launch = 1;
+  if (sb_emit.valid && sub_bytes && !pfn) {
+    const size_t per_sweep = 36u * (size_t)sb_emit.prm.max_pillars * (size_t)sb_emit.prm.max_points_per_pillar;
+    const int per_launch = (int)std::max<size_t>(1, sub_bytes / std::max<size_t>(per_sweep, 1));
+    n_launch = (sb_emit.batch + per_launch - 1) / per_launch;
+  }
+  const StepArgs whole = a;
+  const int nt_t = sb_tile.valid ? whole.t.g.ntiles : 0, nt_o = sb_order.valid ? whole.o.g.ntiles : 0;
+  for (int k = 0; k < n_launch; ++k) {
+    auto part = [&](bool valid, int B, int *lo, int *n) {  // role's share of launch k: sweeps [lo, lo + n)
+      *lo = valid ? (int)((long long)B * k / n_launch) : 0;
+      *n = valid ? (int)((long long)B * (k + 1) / n_launch) - *lo : 0;
     };
-    if (pref_blocks > 0 && sb_emit.valid) {   // what the emit role reads
-      add(a.e.ordered_meta, (size_t)sb_emit.batch * a.e.P * 16);
-      add(a.e.sorted_pts, (size_t)sb_emit.batch * a.e.ncap * 16);
+    int tb, tn, ob, on, sb, sn, eb, en;
+    part(sb_tile.valid, sb_tile.batch, &tb, &tn);
+    part(sb_order.valid, sb_order.batch, &ob, &on);
+    part(sb_new.valid, sb_new.batch, &sb, &sn);
+    part(sb_emit.valid, sb_emit.batch, &eb, &en);
+    a = whole;
+    a.tile_b0 = tb;
+    a.n_tile_blocks = nt_t * tn;
+    a.o.b0 = ob;
+    a.o.B = on;
+    a.n_order_blocks = (nt_o * on + kEmitWaves - 1) / kEmitWaves;   // one wave per (sweep, tile)
+    a.split_b0 = sb;
+    a.n_split_blocks = sb_new.valid ? whole.s.nchunks * sn : 0;
+    a.emit_b0 = eb;
+    const int n_emit = whole.emit_nbx * en;
+    if (sb_emit.valid && !pfn) {
+      static const int forced = [] {  // development knob: PP_EMIT_SC1=0/1
+        const char *e = getenv("PP_EMIT_SC1");
+        return e ? (atoi(e) ? 1 : 0) : -1;
+      }();
+      sc1 = forced >= 0 ? forced == 1 : (size_t)en * 36u * (size_t)a.e.P * (size_t)a.e.N <= kSc1MaxBytes;
     }
-    if (pref_blocks > 0 && sb_order.valid) {  // ... the order role: the occupied heads of the tiles' lists
-      a.pf.tile_agg = a.o.tile_agg;
-      a.pf.tile_meta = a.o.tile_meta;
-      a.pf.nlists = sb_order.batch * a.o.g.ntiles;
-      a.pf.list_stride = 1 << a.o.g.tile_shift;
+    {
+      int r = 0;
+      auto add = [&](const void *ptr, size_t per_sweep, int lo, int n) {
+        a.pf.ptr[r] = static_cast<const char *>(ptr) + per_sweep * (size_t)lo;
+        a.pf.n16[r] = (unsigned)(per_sweep * (size_t)n / 16);
+        ++r;
+      };
+      std::memset(&a.pf, 0, sizeof a.pf);
+      if (pref_blocks > 0 && en > 0) {   // what the emit role reads
+        add(a.e.ordered_meta, (size_t)a.e.P * 16, eb, en);
+        add(a.e.sorted_pts, (size_t)a.e.ncap * 16, eb, en);
+      }
+      if (pref_blocks > 0 && on > 0) {  // ... the order role: the occupied heads of the tiles' lists
+        a.pf.tile_agg = a.o.tile_agg + (size_t)ob * nt_o;
+        a.pf.tile_meta = a.o.tile_meta + ((size_t)ob * nt_o << a.o.g.tile_shift);
+        a.pf.nlists = on * nt_o;
+        a.pf.list_stride = 1 << a.o.g.tile_shift;
+      }
+      if (pref_blocks > 0 && tn > 0) {   // what the tile role reads
+        add(a.t.mat, (size_t)nt_t * a.t.nchunks_cap * 8, tb, tn);
+        add(a.t.kslot, (size_t)a.t.ncap * 4, tb, tn);
+        add(a.t.kpts, (size_t)a.t.ncap * 16, tb, tn);
+      }
+      a.n_pref_blocks = r > 0 || a.pf.nlists > 0 ? pref_blocks : 0;
     }
-    if (pref_blocks > 0 && sb_tile.valid) {   // what the tile role reads
-      add(a.t.mat, (size_t)sb_tile.batch * a.t.g.ntiles * a.t.nchunks_cap * 8);
-      add(a.t.kslot, (size_t)sb_tile.batch * a.t.ncap * 4);
-      add(a.t.kpts, (size_t)sb_tile.batch * a.t.ncap * 16);
+    if (mode != kModePfn) a.n_unscatter_blocks = 0;
+    const long long nblocks = (long long)a.n_pref_blocks + a.n_unscatter_blocks + a.n_tile_blocks + a.n_order_blocks +
+                              a.n_split_blocks + n_emit;
+    {
+      const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
+      a.mix = mix_env ? mix_env : 2;
+      a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit / (a.mix - 1)) : 0;
+      if (a.mix < 2) a.mix = 2, a.mix_groups = 0;
     }
-    a.n_pref_blocks = r > 0 || a.pf.nlists > 0 ? pref_blocks : 0;
-  }
-  const long long nblocks = (long long)a.n_pref_blocks + a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks + n_emit_blocks;
-  {
-    static const int mix_env = [] {  // development knob: PP_STEP_MIX=m (1 = binning blocks first)
-      const char *e = getenv("PP_STEP_MIX");
-      return e ? std::max(1, atoi(e)) : 0;
-    }();
-    const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
-    a.mix = mix_env ? mix_env : 2;
-    a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit_blocks / (a.mix - 1)) : 0;
-    if (a.mix < 2) a.mix = 2, a.mix_groups = 0;
-  }
-  if (nblocks > 0) {
+    if (nblocks <= 0) continue;
     if (nblocks > INT_MAX) {
       set_error("pp_voxelize_step_dev: grid too large");
       return PP_ERR_VALUE;
     }
-    const void *fn = mode == kModeDenseScalar ? reinterpret_cast<const void *>(&k_step<kModeDenseScalar, kAuxPlain>)
-                   : sc1 ? reinterpret_cast<const void *>(&k_step<kModeDenseVec4, kAuxSc1>)
-                         : reinterpret_cast<const void *>(&k_step<kModeDenseVec4, kAuxPlain>);
+    const void *fn = mode == kModePfn          ? reinterpret_cast<const void *>(&k_step<kModePfn, kAuxPlain>)
+                     : mode == kModeDenseScalar ? reinterpret_cast<const void *>(&k_step<kModeDenseScalar, kAuxPlain>)
+                     : sc1                      ? reinterpret_cast<const void *>(&k_step<kModeDenseVec4, kAuxSc1>)
+                                                : reinterpret_cast<const void *>(&k_step<kModeDenseVec4, kAuxPlain>);
     {
       // dynamic LDS beyond 64 KiB (16.7 M-cell grids) needs the attribute: once per process, device and
       // instance, at the worst case
       static std::atomic<unsigned> armed[64];
-      const unsigned bit = mode == kModeDenseScalar ? 1u : sc1 ? 2u : 4u;
+      const unsigned bit = mode == kModePfn ? 8u : mode == kModeDenseScalar ? 1u : sc1 ? 2u : 4u;
       const int dev = ctx->device & 63;
       if (!(armed[dev].load(std::memory_order_acquire) & bit)) {
         const size_t worst = std::max(std::max(tile_lds_bytes(kMaxTileSlots, kStepWaves), split_lds_bytes(kMaxTiles)),
@@ -2384,17 +2492,25 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
         armed[dev].fetch_or(bit, std::memory_order_release);
       }
     }
+    // timing ring: ONE entry per call -- the start event rides on the call's first launch, the stop event on
+    // its last, so the entry is what the call's launches took together (bench.py's per-call duration)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->ev_slots > 0) {
-      if (ctx->ev_columns != (1 << PP_KERNEL_EMIT)) ctx->ev_count = 0;  // the ring held three-launch calls: do not
-      e0 = ctx->ev_start[PP_KERNEL_EMIT][ctx->ev_next];                   // mix k_emit and k_step durations
-      e1 = ctx->ev_stop[PP_KERNEL_EMIT][ctx->ev_next];
-      ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
-      ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
-      ctx->ev_columns = 1 << PP_KERNEL_EMIT;
+      if (k == 0) {
+        if (ctx->ev_columns != (1 << PP_KERNEL_EMIT)) ctx->ev_count = 0;  // the ring held three-launch calls: do not
+        ctx->ev_columns = 1 << PP_KERNEL_EMIT;                              // mix k_emit and k_step durations
+        e0 = ctx->ev_start[PP_KERNEL_EMIT][ctx->ev_next];
+      }
+      if (k == n_launch - 1) {
+        e1 = ctx->ev_stop[PP_KERNEL_EMIT][ctx->ev_next];
+        ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_slots;
+        ctx->ev_count = std::min(ctx->ev_count + 1, ctx->ev_slots);
+      }
     }
     const dim3 grid((unsigned)nblocks), block(kStepThreads);
-    if (mode == kModeDenseScalar)
+    if (mode == kModePfn)
+      hipExtLaunchKernelGGL((k_step<kModePfn, kAuxPlain>), grid, block, lds, stream, e0, e1, 0, a);
+    else if (mode == kModeDenseScalar)
       hipExtLaunchKernelGGL((k_step<kModeDenseScalar, kAuxPlain>), grid, block, lds, stream, e0, e1, 0, a);
     else if (sc1)
       hipExtLaunchKernelGGL((k_step<kModeDenseVec4, kAuxSc1>), grid, block, lds, stream, e0, e1, 0, a);
@@ -2417,6 +2533,38 @@ extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *p
   static_assert(pp_ctx::kVoxSlots - 1 >= 4, "one workspace slot per batch in flight (split, tile, order, emit)");
   if (sb_new.valid) ctx->step_next_slot = ctx->step_next_slot % (pp_ctx::kVoxSlots - 1) + 1;
   return PP_OK;
+}
+
+extern "C" int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                    int64_t points_stride, const int32_t *n_points, int batch,
+                                    const pp_voxel_params_t *prm, float *pillars_dev,
+                                    int64_t *indices_dev, int32_t *num_cells_dev, int *emitted) {
+  return step_impl(ctx, stream_, points_dev, points_stride, n_points, batch, prm, pillars_dev, indices_dev,
+                   num_cells_dev, emitted, nullptr);
+}
+
+extern "C" int pp_voxelize_step_pfn_canvas_dev(pp_ctx_t *ctx, void *stream_, const float *points_dev,
+                                               int64_t points_stride, const int32_t *n_points, int batch,
+                                               const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                                               int channels, float *canvas_dev, int canvas_h, int canvas_w,
+                                               int channels_last, int64_t *indices_dev, int32_t *num_cells_dev,
+                                               float *clear_canvas_dev, const int64_t *clear_indices_dev,
+                                               int clear_batch, int *emitted) {
+  if (channels != kPfnChannels) {
+    set_error("the fused feature net is built for %d output channels (got %d)", kPfnChannels, channels);
+    return PP_ERR_VALUE;
+  }
+  StepPfn pfn;
+  pfn.params = pfn_params_dev;
+  pfn.canvas = canvas_dev;
+  pfn.h = canvas_h;
+  pfn.w = canvas_w;
+  pfn.nhwc = channels_last ? 1 : 0;
+  pfn.clear_canvas = clear_canvas_dev;
+  pfn.clear_indices = clear_indices_dev;
+  pfn.clear_batch = clear_batch;
+  return step_impl(ctx, stream_, points_dev, points_stride, n_points, batch, prm, nullptr, indices_dev,
+                   num_cells_dev, emitted, &pfn);
 }
 
 extern "C" int pp_voxelize_step_reset(pp_ctx_t *ctx) {

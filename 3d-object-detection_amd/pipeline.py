@@ -114,6 +114,22 @@ class PillarPipeline:
         feats, indices = self.voxelizer.pfn(points, pfn_params, n_points=n_points, out=self._fbufs)
         return self.model.forward_features(feats, indices)
 
+    @torch.no_grad()
+    def forward_fused_pipelined(self, points, n_points=None):
+        """``forward_fused`` as a software pipeline over consecutive batches: ONE voxelizer launch per call
+        (``PillarVoxelizer.submit_pfn_canvas``: the split stage of ``points``, the tile and order stages of the two
+        previous batches, and the emit stage of the batch before those AS the fused feature net writing straight
+        into the channels-last canvas), and the network runs on that oldest batch's canvas.  Returns its
+        ``(cls, reg)`` -- ``None`` for the first ``PillarVoxelizer.LAG`` calls; ``points=None`` drains."""
+        if self.model.training:
+            raise RuntimeError("forward_fused_pipelined is inference only: call model.eval() first")
+        if self.voxelizer.data_mean is not None:
+            raise RuntimeError("the fused feature net has no data_mean form: use forward_pipelined")
+        pfn_params = self.model.feature_net.fused_table(self.device)
+        H, W = self.model.scatter.h, self.model.scatter.w
+        r = self.voxelizer.submit_pfn_canvas(points, pfn_params, (H, W), n_points=n_points, channels_last=True)
+        return None if r is None else self.model.forward_canvas(r[0])
+
     def _canvas(self, B, H, W):
         if self._cbuf is None or self._cbuf.shape != (B, 64, H, W):
             self._cbuf = torch.empty((B, 64, H, W), dtype=torch.float32, device=self.device,

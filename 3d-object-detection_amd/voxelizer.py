@@ -273,6 +273,78 @@ class PillarVoxelizer:
             _lib.check(rc, "pp_subtract_mean_dev")
         return (pillars, indices, counts) if return_counts else (pillars, indices)
 
+    def submit_pfn_canvas(self, points, pfn_params, canvas_hw, n_points=None, channels_last=True,
+                          return_counts=False):
+        """``submit`` with the emit stage as the fused feature net + scatter (pp_voxelize_step_pfn_canvas_dev;
+        PPFeatureNet.forward and PPScatter.forward, model/model.py:31-62): ONE launch per call; the batch
+        submitted ``LAG`` calls ago comes back as ``(canvas[B,64,H,W] f32, indices[B,P,3] i64[, counts])`` -- the
+        result of ``pfn_canvas`` on that batch, bit for bit -- or ``None`` while the pipeline fills;
+        ``points=None`` drains.  The batches in flight are shared with ``submit`` (same pipeline; the call
+        that is made when a batch is due decides which form it comes out in).
+
+        Two canvases are used in turn: a call fills one and, in the same launch, zeroes the pixels the previous
+        call wrote into the other.  THE RETURNED CANVAS IS THEREFORE VALID UNTIL THE NEXT ``submit_pfn_canvas``
+        CALL (in stream order: work enqueued before that call reads it safely); clone it to keep it."""
+        cfg = self.cfg
+        P = cfg.max_pillars
+        self._no_mean("submit_pfn_canvas")
+        H, W = int(canvas_hw[0]), int(canvas_hw[1])
+        if (pfn_params.shape != (64, 12) or pfn_params.dtype != torch.float32
+                or pfn_params.device != self.device or not pfn_params.is_contiguous()):
+            raise ValueError("pfn_params must be a contiguous float32 [64,12] tensor on " + str(self.device))
+        inflight = getattr(self, "_inflight", None)
+        if inflight is None:
+            inflight = self._inflight = [None, None, None]
+        due = inflight[2]
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        st = getattr(self, "_pc", None)
+        key = (due, H, W, bool(channels_last))
+        if due is not None and (st is None or st["key"] != key):
+            st = self._pc = {"key": key, "turn": 0, "filled": [0, 0],
+                             "canvas": [torch.zeros((due, 64, H, W), dtype=torch.float32, device=self.device)
+                                        .contiguous(memory_format=fmt) for _ in range(2)],
+                             "indices": [torch.empty((due, P, 3), dtype=torch.int64, device=self.device)
+                                         for _ in range(2)]}
+        vp = ctypes.c_void_p
+        canvas = indices = counts = clear_c = clear_i = None
+        clear_b = 0
+        if due is not None:
+            k = st["turn"]
+            if st["filled"][k]:                      # (a canvas that could not be cleared by a launch: rare)
+                st["canvas"][k].zero_()
+                st["filled"][k] = 0
+            canvas, indices = st["canvas"][k], st["indices"][k]
+            if st["filled"][1 - k]:
+                clear_c, clear_i, clear_b = st["canvas"][1 - k], st["indices"][1 - k], st["filled"][1 - k]
+            if return_counts:
+                counts = torch.empty((due, 2), dtype=torch.int32, device=self.device)
+        nxt = self._prep(points, n_points) if points is not None else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        emitted = ctypes.c_int(0)
+        rc = _lib.lib().pp_voxelize_step_pfn_canvas_dev(
+            self._ctx.handle, vp(stream), vp(nxt[0].data_ptr()) if nxt else None,
+            nxt[2] if nxt else 0, nxt[3] if nxt else None, nxt[1] if nxt else 0, ctypes.byref(self._prm),
+            vp(pfn_params.data_ptr()), 64, vp(canvas.data_ptr()) if canvas is not None else None, H, W,
+            1 if channels_last else 0, vp(indices.data_ptr()) if indices is not None else None,
+            vp(counts.data_ptr()) if counts is not None else None,
+            vp(clear_c.data_ptr()) if clear_c is not None else None,
+            vp(clear_i.data_ptr()) if clear_i is not None else None, clear_b, ctypes.byref(emitted))
+        if rc != _lib.PP_OK:                        # same rule as submit(): a failed call abandons the pipeline
+            msg = _lib.lib().pp_last_error()
+            _lib.lib().pp_voxelize_step_reset(self._ctx.handle)
+            self._inflight = [None, None, None]
+            self._pc = None                          # the canvases' state is unknown: start from zeroed ones
+            _lib.check(rc, "pp_voxelize_step_pfn_canvas_dev (pipeline reset)", msg)
+        self._inflight = [nxt[1] if nxt else None, inflight[0], inflight[1]]
+        if due is None:
+            return None
+        assert emitted.value == 1
+        st["filled"][k] = due
+        if clear_c is not None:
+            st["filled"][1 - k] = 0
+        st["turn"] = 1 - k
+        return (canvas, indices, counts) if return_counts else (canvas, indices)
+
     def reset_stream(self):
         """Forgets the batches in flight in ``submit``'s pipeline (their results are never returned)."""
         _lib.check(_lib.lib().pp_voxelize_step_reset(self._ctx.handle), "pp_voxelize_step_reset")

@@ -116,6 +116,34 @@ int pp_voxelize_step_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
                          const pp_voxel_params_t *prm, float *pillars_dev,
                          int64_t *indices_dev, int32_t *num_cells_dev, int *emitted);
 
+/*
+ * The software-pipelined form of pp_voxelize_pfn_canvas_reuse_dev (PPFeatureNet.forward and
+ * PPScatter.forward, model/model.py:31-62, inside the voxelizer): the SAME pipeline as pp_voxelize_step_dev --
+ * split, tile and order roles unchanged, batches in flight are shared between the two entry points -- with
+ * the EMIT role as the fused feature net: the batch handed in three calls ago comes out as its BEV canvas
+ * instead of the dense [9,P,N] tensor.  One launch per call instead of three dependent ones.
+ *   canvas_dev        [batch'][64][H][W] f32 (channels_last: memory [batch'][H][W][64]) for the batch that is
+ *                     due (batch' = that call's batch).  It must be ALL ZERO on entry: only the pillars'
+ *                     pixels are written.
+ *   clear_canvas_dev, clear_indices_dev, clear_batch   (optional) ANOTHER canvas of the same shape whose
+ *                     only non-zero pixels are those clear_indices_dev [clear_batch][P][3] names (the
+ *                     indices this function returned when it filled that canvas): a CLEAR role of the
+ *                     same launch zeroes them.  With two canvases used in turn -- emit into one, clear the
+ *                     other, which the network has consumed in between -- no call waits for a clear
+ *                     (pp_voxelize_pfn_canvas_reuse_dev clears and fills ONE canvas: a kernel boundary).
+ *   pfn_params_dev, channels, canvas_h/w, channels_last, indices_dev, num_cells_dev: as
+ *                     pp_voxelize_pfn_canvas_dev; points_dev / n_points / batch / prm / emitted / the stream
+ *                     rule: as pp_voxelize_step_dev.
+ * Results equal pp_voxelize_pfn_canvas_dev's for the same input bit for bit.
+ */
+int pp_voxelize_step_pfn_canvas_dev(pp_ctx_t *ctx, void *stream, const float *points_dev,
+                                    int64_t points_stride, const int32_t *n_points, int batch,
+                                    const pp_voxel_params_t *prm, const float *pfn_params_dev,
+                                    int channels, float *canvas_dev, int canvas_h, int canvas_w,
+                                    int channels_last, int64_t *indices_dev, int32_t *num_cells_dev,
+                                    float *clear_canvas_dev, const int64_t *clear_indices_dev,
+                                    int clear_batch, int *emitted);
+
 /* Forgets the batches in flight in pp_voxelize_step_dev's pipeline (end of an epoch, an abandoned
  * stream): the next call starts an empty pipeline.  Nothing is launched. */
 int pp_voxelize_step_reset(pp_ctx_t *ctx);

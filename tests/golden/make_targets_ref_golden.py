@@ -25,7 +25,8 @@ and every arithmetic statement of make_target (diagonal, y flip, quotients, logs
 orientation bit) -- executed by the reference's own source text under this image's numpy.
 Also run from the reference's source: make_anchor_boxes (box_utils.py:111-159) on two small maps -- the anchor
 ORDER (y, x, d), the centre formula and the anchor_xy corner choice; the corner values come from this repo's
-bottom_corners_xy standing in for the absent SDK method (section 5 below).
+bottom_corners_xy standing in for the absent SDK method (section 5 below) -- and boxes_to_image_space
+(box_utils.py:19-32) on three box sets: the y flip of centres and corners and the corner transpose (section 6).
 WHAT IT DOES NOT PIN: the IoU values themselves (they come from the oracle: Boost.Geometry stays
 unpinned), ``Box.bottom_corners`` (corner arrays are inputs here, made by the repo's boxes.py) and
 ``Quaternion.yaw_pitch_roll`` (the yaw is handed over as a number; the SDK would derive it from a
@@ -270,6 +271,27 @@ for tag, acfg in (("anchors_c3_8x5", boxes.AnchorConfig(8, 5)),
                       dims=np.asarray(acfg.dims, np.float64), yaws_deg=np.asarray(acfg.yaws_deg, np.float64),
                       zs=np.asarray(acfg.zs, np.float64), anchor_corners=corners, anchor_centers=centers, anchor_xy=xy)
     print(f"{tag}: make_anchor_boxes from the reference's source == boxes.make_anchors ({len(corners)} anchors)")
+
+# 6. boxes_to_image_space (box_utils.py:19-32) run from the reference's source on field-holder boxes: the y flip
+#    (CANVAS_HEIGHT - 1) - y of centres and corners, the [3,4] -> [4,2] corner transpose, the stacking.  As in
+#    section 5, Box.bottom_corners() -- the SDK's arithmetic -- is answered by boxes.bottom_corners_xy, so the
+#    corner VALUES before the flip are this repo's; what is pinned is everything the reference's function does.
+for tag, n_box, Hc, seed in (("image_space_c3", 40, 500, 0), ("image_space_default", 25, 600, 5),
+                             ("image_space_one_box", 1, 41, 2)):
+    g = synth.gt_boxes(n_box, Hc, seed, margin=min(50.0, Hc / 4))
+    g["wlh"][::3] *= 0.6
+    cfg.DATA.CANVAS_HEIGHT = Hc
+    held = [_AnchorBoxFields(center=c, size=w, orientation=_Orientation(y))
+            for c, w, y in zip(g["centers"], g["wlh"], g["yaw"])]
+    before = [b.center.copy() for b in held]
+    centers_img, corners_img = ref.boxes_to_image_space(held)              # reference-run
+    assert ref.boxes_to_image_space.__code__.co_filename.startswith(REF)
+    assert all(np.array_equal(b.center, c0) for b, c0 in zip(held, before))    # it copies the centres
+    mine_c, mine_k = boxes.boxes_to_image_space(g["centers"], g["wlh"], g["yaw"], Hc)
+    assert np.array_equal(mine_c, centers_img) and np.array_equal(mine_k, corners_img)
+    cases[tag] = dict(fm=np.array([0, 0, 0, Hc, 0], np.float64), gt_centers=g["centers"], gt_wlh=g["wlh"],
+                      gt_yaw=g["yaw"], centers_img=centers_img, corners_img=corners_img)
+    print(f"{tag}: boxes_to_image_space from the reference's source == boxes.boxes_to_image_space ({n_box} boxes)")
 
 flat = {}
 for name, c in cases.items():

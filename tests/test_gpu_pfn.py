@@ -385,3 +385,116 @@ def test_fused_canvas_and_dense_feature_net_in_a_hip_graph(gpu):
         want_feats, _ = vox.pfn(c, params)
         assert torch.equal(canvas, want_canvas)
         assert torch.equal(feats, want_feats)
+
+
+def test_pipelined_fused_canvas_equals_three_launch_form_and_pytorch(gpu):
+    """PillarVoxelizer.submit_pfn_canvas / pp_voxelize_step_pfn_canvas_dev (ONE launch per call: split | tile | order
+    roles of three younger batches, the emit role as the fused feature net writing the canvas, and a CLEAR role for
+    the other canvas): a sequence of DIFFERENT batches -- changing batch size, ragged counts, an empty sweep, an
+    overflowing sweep -- comes out in order, each canvas bit-identical to pp_voxelize_pfn_canvas_reuse_dev's for
+    that batch (both memory layouts), and equal to PyTorch's PPFeatureNet + PPScatter on the dense tensor
+    (model/model.py:31-62) within f32 rounding.  Dense submits on the same pipeline in between stay exact."""
+    import torch
+    import pp_amd.model as M
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    half, step, P, N = 24.0, 0.2, 3000, 16
+    cfg = VoxelConfig.square(half, step, P, N)
+    H = W = cfg.canvas_height
+    fn = _net(gpu)
+    tab = fn.fused_params()
+    ref_vox = PillarVoxelizer(cfg, device=gpu)
+    seq = []
+    for i, (B, n) in enumerate([(2, 9000), (2, 20000), (2, 5000), (3, 9000), (3, 12000), (1, 300), (1, 20000)]):
+        pts = np.stack([synth.lidar_like(n, half, 50 + 7 * i + s) for s in range(B)])
+        npts = [n - 37 * s for s in range(B)]
+        if i == 2:
+            npts[1] = 0
+        seq.append((torch.from_numpy(pts).to(gpu), npts))
+    for cl in (True, False):
+        want = []
+        for t, npts in seq:
+            c, ix, cnt = ref_vox.pfn_canvas(t, tab, (H, W), n_points=npts, channels_last=cl, return_counts=True)
+            want.append((c.clone(), ix.clone(), cnt.clone()))
+        assert want[1][2][0, 0].item() > P                      # an overflowing sweep is in the sequence
+        vs = PillarVoxelizer(cfg, device=gpu)
+        for rep in range(2):                                     # twice: slots and canvases reused with stale contents
+            got = []
+            for k, (t, npts) in enumerate(seq):
+                r = vs.submit_pfn_canvas(t, tab, (H, W), n_points=npts, channels_last=cl, return_counts=True)
+                assert (r is None) == (k < vs.LAG)
+                if r is not None:
+                    got.append(tuple(x.clone() for x in r))      # valid until the next call only
+            for _ in range(vs.LAG):
+                got.append(tuple(x.clone() for x in vs.submit_pfn_canvas(None, tab, (H, W), channels_last=cl,
+                                                                           return_counts=True)))
+            assert vs.submit_pfn_canvas(None, tab, (H, W), channels_last=cl) is None
+            torch.cuda.synchronize()
+            assert len(got) == len(seq)
+            for k, (w, g) in enumerate(zip(want, got)):
+                assert g[0].is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+                assert torch.equal(w[1], g[1]) and torch.equal(w[2], g[2]), k
+                assert torch.equal(w[0], g[0]), (cl, rep, k)
+    # against PyTorch's modules on the dense tensor (the reference's own sequence of ops)
+    sc = M.PPScatter(H, W)
+    sc.channels_last_inference = False
+    with torch.no_grad():
+        for (t, npts), w in zip(seq[:3], want[:3]):
+            pil, idx = ref_vox(t, n_points=npts)
+            ref = sc(fn(pil), idx)
+            assert (ref - w[0]).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    # dense and fused calls share ONE pipeline: whatever call is made when a batch is due decides its form
+    vs = PillarVoxelizer(cfg, device=gpu)
+    outs = []
+    for k, (t, npts) in enumerate(seq[:5] + [(None, None)] * vs.LAG):
+        if k % 2 == 0:
+            r = vs.submit_pfn_canvas(t, tab, (H, W), n_points=npts, channels_last=False)
+        else:
+            r = vs.submit(t, n_points=npts)
+        outs.append(None if r is None else (k % 2, tuple(x.clone() for x in r)))
+    torch.cuda.synchronize()
+    got = [o for o in outs if o is not None]
+    assert len(got) == 5
+    for (kind, g), w, (t, npts) in zip(got, want, seq):
+        if kind == 0:
+            assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1])
+        else:
+            pil, idx = ref_vox(t, n_points=npts)
+            assert torch.equal(g[0], pil) and torch.equal(g[1], idx)
+
+
+def test_pipelined_fused_full_size_and_pipeline(gpu):
+    """The pipelined fused form at BASELINE config 2's sizes (B = 4, 60k points, 500x500, P = 12000, N = 100),
+    bit-identical to the three-launch fused call; and PillarPipeline.forward_fused_pipelined == forward_fused
+    batch for batch."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    from util import C2
+    cfg = VoxelConfig.square(C2["half"], C2["step"], C2["P"], C2["N"])
+    H = W = cfg.canvas_height
+    tab = _net(gpu).fused_params()
+    a, b = PillarVoxelizer(cfg, device=gpu), PillarVoxelizer(cfg, device=gpu)
+    ts = [torch.from_numpy(np.stack([synth.lidar_like(C2["n"], C2["half"], 10 * i + s) for s in range(4)])).to(gpu)
+          for i in range(3)]
+    got = []
+    for t in ts + [None] * b.LAG:
+        r = b.submit_pfn_canvas(t, tab, (H, W))
+        if r is not None:
+            got.append((r[0].clone(), r[1].clone()))
+    for t, g in zip(ts, got):
+        c, ix = a.pfn_canvas(t, tab, (H, W))
+        assert torch.equal(c, g[0]) and torch.equal(ix, g[1])
+    pipe = PillarPipeline(VoxelConfig.square(16.0, 0.2, 4000, 32), feature_channels=64, device=gpu, seed=0)
+    pipe.model.eval()
+    clouds = [torch.from_numpy(np.stack([synth.lidar_like(n, 16.0, s) for s in (sd, sd + 1)])).to(gpu)
+              for n, sd in ((15000, 3), (9000, 40), (12000, 80), (15000, 5))]
+    want = [tuple(x.clone() for x in pipe.forward_fused(c)) for c in clouds]
+    outs = [pipe.forward_fused_pipelined(c) for c in clouds] + \
+           [pipe.forward_fused_pipelined(None) for _ in range(pipe.voxelizer.LAG)]
+    outs = [o for o in outs if o is not None]
+    torch.cuda.synchronize()
+    assert len(outs) == len(clouds)
+    for (c, r), (wc, wr) in zip(outs, want):
+        assert (c - wc).abs().max().item() <= 2e-6 and (r - wr).abs().max().item() <= 2e-6

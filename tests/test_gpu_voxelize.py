@@ -615,3 +615,46 @@ def test_timing_ring_does_not_mix_launch_kinds(gpu):
     assert v.read_kernel_ms(_lib.KERNEL_SPLIT) == [] and len(v.read_kernel_ms(_lib.KERNEL_EMIT)) == 4
     v.set_timing(0)
     v.reset_stream()
+
+
+def test_pipelined_mode_split_into_sub_batch_launches(gpu):
+    """pp_voxelize_step_dev can send a call out as several launches of a few sweeps each (development knob
+    PP_STEP_SUB_MB; off by default: measured, no gain).  The roles' sweep offsets must then address the same
+    arrays: in a child process with the knob set so that a 3-sweep batch takes three launches and a 2-sweep batch
+    two, every result equals the plain call's, ragged counts and an empty sweep included."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import pp_amd
+from pp_amd import synth
+from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+cfg = VoxelConfig.square(25.0, 0.25, 3000, 64)          # 36 * 3000 * 64 = 6.9 MB per sweep, knob = 8 MB: one sweep per launch
+a, b = PillarVoxelizer(cfg), PillarVoxelizer(cfg)
+seq = []
+for i, (B, n) in enumerate([(3, 9000), (1, 20000), (4, 5000), (2, 9000), (3, 12000)]):
+    pts = torch.from_numpy(np.stack([synth.lidar_like(n, 25.0, 50 + 7 * i + s) for s in range(B)])).cuda()
+    npts = [n - 37 * s for s in range(B)]
+    if i == 2:
+        npts[1] = 0
+    seq.append((pts, npts))
+want = [tuple(x.clone() for x in a(t, n_points=n, return_counts=True)) for t, n in seq]
+got = []
+for t, n in seq:
+    r = b.submit(t, n_points=n, return_counts=True)
+    if r is not None:
+        got.append(r)
+got += [b.submit(None, return_counts=True) for _ in range(b.LAG)]
+torch.cuda.synchronize()
+assert len(got) == len(want)
+for w, g in zip(want, got):
+    assert all(torch.equal(x, y) for x, y in zip(w, g))
+print("sub-batch launches ok")
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, PP_STEP_SUB_MB="8"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sub-batch launches ok" in r.stdout, r.stderr[-2000:]

@@ -76,6 +76,28 @@ def test_anchor_grid_equals_the_reference_run(cases):
     assert n == 2
 
 
+def test_boxes_to_image_space_equals_the_reference_run(cases):
+    """boxes_to_image_space (box_utils.py:19-32) executed from the reference's source on field-holder boxes: the
+    y flip of centres and corners and the [3,4] -> [4,2] corner transpose == boxes.boxes_to_image_space (what the
+    device path uploads) and the oracle's restatement."""
+    from oracle import oracle as O
+    from pp_amd import boxes
+    n = 0
+    for name, c in cases.items():
+        if "centers_img" not in c:
+            continue
+        H = float(c["fm"][3])
+        mc, mk = boxes.boxes_to_image_space(c["gt_centers"], c["gt_wlh"], c["gt_yaw"], H)
+        assert mc.shape == c["centers_img"].shape and mk.shape == c["corners_img"].shape == (len(mc), 4, 2), name
+        assert np.array_equal(mc, c["centers_img"]) and np.array_equal(mk, c["corners_img"]), name
+        oc, ok = O.boxes_to_image_space(c["gt_centers"], c["gt_wlh"], c["gt_yaw"], H)
+        assert np.array_equal(oc, c["centers_img"]), name
+        assert np.allclose(ok, c["corners_img"], rtol=0, atol=1e-12), name     # the oracle's own cos / sin loop
+        assert np.array_equal(c["centers_img"][:, 1], (H - 1) - c["gt_centers"][:, 1]), name
+        n += 1
+    assert n == 3
+
+
 def test_the_vectors_cover_the_quirks(cases):
     """the fixture is only worth its name if the branches are in it"""
     c = cases["duplicate_forced"]
@@ -135,3 +157,27 @@ def test_hip_batched_target_assignment_equals_the_reference_run(gpu, cases, sour
             assert np.array_equal(cls_t, ref_c), name
             assert np.array_equal(reg_t[:, 0], ref_r[:, 0]) and np.array_equal(reg_t[:, 8], ref_r[:, 8]), name
             assert np.abs(reg_t - ref_r).max() <= REG_TOL, name
+
+
+@pytest.mark.gpu
+def test_uploaded_ground_truths_equal_the_reference_run(gpu, cases):
+    """What TargetAssigner puts on the DEVICE for a batch (upload_batch: image-space corners and centres next to the
+    canvas-space box fields) against boxes_to_image_space run from the reference's source."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    names = [n for n, c in cases.items() if "centers_img" in c]
+    for name in names:
+        c = cases[name]
+        H = int(c["fm"][3])
+        ta = TargetAssigner(boxes.AnchorConfig(8, 8), canvas_height=H, device=gpu)
+        g = {"centers": c["gt_centers"], "wlh": c["gt_wlh"], "yaw": c["gt_yaw"],
+             "classes": np.zeros(len(c["gt_yaw"]), np.int32)}
+        counts, packed = ta.upload_batch([g, g])
+        T = sum(counts)
+        host = packed.cpu().numpy()
+        corners, cimg = host[:T * 8].reshape(T, 4, 2), host[T * 8:T * 11].reshape(T, 3)
+        n = counts[0]
+        for o in (0, n):
+            assert np.array_equal(corners[o:o + n], c["corners_img"]), name
+            assert np.array_equal(cimg[o:o + n], c["centers_img"]), name

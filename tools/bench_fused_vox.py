@@ -32,3 +32,22 @@ for reuse in (False, True):
     ke = np.mean(vox.read_kernel_ms(_lib.KERNEL_EMIT)) * 1e3
     vox.set_timing(0)
     print(f"fused voxelizer B={B} reuse={reuse}: {dt*1e6:.1f} us per call; k_split {ks:.1f} k_tile {kt:.1f} k_emit<pfn> {ke:.1f}")
+# the software-pipelined form: ONE launch per call (k_step<pfn>: split | tile | order | fused emit | clear)
+for _ in range(10):
+    vox.submit_pfn_canvas(pts, tab, (H, W))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    vox.submit_pfn_canvas(pts, tab, (H, W))
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 200
+vox.set_timing(64)
+for _ in range(64):
+    vox.submit_pfn_canvas(pts, tab, (H, W))
+torch.cuda.synchronize()
+ke = np.mean(vox.read_kernel_ms(_lib.KERNEL_EMIT)) * 1e3
+vox.set_timing(0)
+vox.reset_stream()
+byt = (16 * 60000 + 2 * (256 * 12000 + 24 * 12000)) * B
+print(f"fused voxelizer B={B} pipelined (k_step<pfn>): {dt*1e6:.1f} us per call; kernel {ke:.1f} us; its bytes {byt/1e6:.1f} MB "
+      f"-> {byt/dt/8e12:.3f} of 8 TB/s")

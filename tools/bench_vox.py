@@ -29,6 +29,9 @@ ap.add_argument("--cold", type=int, default=0,
                      "(event pairs) then include the cold start")
 ap.add_argument("--lanes", type=int, default=0,
                 help="experiment: K independent (context, stream) lanes, batch i entirely on lane i %% K, no joins")
+ap.add_argument("--rotate", type=int, default=1,
+                help="K output buffers used in turn (a real consumer does not re-write one buffer call after call: with "
+                     "K = 1 a buffer smaller than the 256 MB Infinity Cache is absorbed by it)")
 a = ap.parse_args()
 
 cfg = VoxelConfig.square(a.half, a.step, a.P, a.N, order=a.order)
@@ -36,7 +39,16 @@ vox = PillarVoxelizer(cfg)
 pts = torch.from_numpy(np.stack([synth.lidar_like(a.n, a.half, s) for s in range(a.batch)])).cuda()
 out = (torch.empty((a.batch, 9, a.P, a.N), dtype=torch.float32, device="cuda"),
        torch.empty((a.batch, a.P, 3), dtype=torch.int64, device="cuda"))
-call = (lambda: vox.submit(pts, out=out)) if a.pipelined else (lambda: vox(pts, out=out))
+outs = [out] + [(torch.empty_like(out[0]), torch.empty_like(out[1])) for _ in range(a.rotate - 1)]
+turn = {"k": 0}
+
+
+def next_out():
+    turn["k"] += 1
+    return outs[turn["k"] % len(outs)]
+
+
+call = (lambda: vox.submit(pts, out=next_out())) if a.pipelined else (lambda: vox(pts, out=next_out()))
 if a.lanes:
     lanes = [(PillarVoxelizer(cfg), torch.cuda.Stream(),
               (torch.empty_like(out[0]), torch.empty_like(out[1]))) for _ in range(a.lanes)]
