@@ -25,7 +25,7 @@ KERNEL_SPLIT, KERNEL_TILE, KERNEL_EMIT = 0, 1, 2
 
 EXPORTS = [
     "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
-    "pp_voxelize_reserve", "pp_voxelize_dev", "pp_voxelize_step_dev", "pp_voxelize_step_pfn_canvas_dev", "pp_voxelize_step_reset", "pp_subtract_mean_dev", "pp_voxelize_pfn_dev", "pp_voxelize_pfn_canvas_dev", "pp_voxelize_pfn_canvas_reuse_dev", "pp_pfn_dense_dev", "pp_scatter_canvas_dev", "pp_pfn_train_stats_dev", "pp_pfn_train_backward_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
+    "pp_voxelize_reserve", "pp_voxelize_dev", "pp_voxelize_step_dev", "pp_voxelize_step_pfn_canvas_dev", "pp_voxelize_step_kernel_name", "pp_voxelize_step_reset", "pp_subtract_mean_dev", "pp_voxelize_pfn_dev", "pp_voxelize_pfn_canvas_dev", "pp_voxelize_pfn_canvas_reuse_dev", "pp_pfn_dense_dev", "pp_scatter_canvas_dev", "pp_pfn_train_stats_dev", "pp_pfn_train_backward_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
     "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_assign_targets_batch_dev", "pp_assign_targets_grid_batch_dev", "pp_ingest_dev", "pp_ingest_sweeps_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_decode_batch_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_relu_bn_train_fwd_dev", "pp_relu_bn_train_bwd_dev", "pp_ctx_set_timing",
     "pp_ctx_read_emit_ms", "pp_ctx_read_kernel_ms", "pp_voxelize_check",
 ]
@@ -144,6 +144,7 @@ def lib():
         L.pp_voxelize_step_pfn_canvas_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
                                                       ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
                                                       c_int, vp, vp, vp, vp, c_int, ctypes.POINTER(c_int)]
+        L.pp_voxelize_step_kernel_name.argtypes = [ctypes.POINTER(VoxelParams), c_int, ctypes.c_char_p, c_int]
         L.pp_voxelize_step_reset.argtypes = [vp]
         L.pp_subtract_mean_dev.argtypes = [vp, vp, vp, c_int, i64, vp]
         L.pp_voxelize_pfn_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,

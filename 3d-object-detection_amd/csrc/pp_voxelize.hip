@@ -2567,6 +2567,20 @@ extern "C" int pp_voxelize_step_pfn_canvas_dev(pp_ctx_t *ctx, void *stream_, con
                    num_cells_dev, emitted, &pfn);
 }
 
+extern "C" int pp_voxelize_step_kernel_name(const pp_voxel_params_t *prm, int batch, char *name, int cap) {
+  if (!prm || !name || cap < 24 || batch < 1) {
+    set_error("pp_voxelize_step_kernel_name: bad argument");
+    return PP_ERR_VALUE;
+  }
+  const int N = prm->max_points_per_pillar;
+  const int mode = (N % 4 == 0 && N <= 4096) ? kModeDenseVec4 : kModeDenseScalar;
+  // the same rule as step_impl's (one launch per call: the development knobs PP_EMIT_SC1 / PP_STEP_SUB_MB aside)
+  const bool sc1 = mode == kModeDenseVec4 &&
+                   (size_t)batch * 36u * (size_t)prm->max_pillars * (size_t)N <= kSc1MaxBytes;
+  std::snprintf(name, (size_t)cap, "pp::k_step<%d, %d>", mode, sc1 ? kAuxSc1 : kAuxPlain);
+  return PP_OK;
+}
+
 extern "C" int pp_voxelize_step_reset(pp_ctx_t *ctx) {
   if (!ctx) {
     set_error("ctx is NULL");

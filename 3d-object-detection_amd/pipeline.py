@@ -76,6 +76,48 @@ class PillarPipeline:
         return None if r is None else self.model(r[0], r[1])
 
     @torch.no_grad()
+    def forward_overlapped(self, points, n_points=None):
+        """``forward_pipelined`` with the voxelizer's launch on a SECOND stream, side by side with the network (what
+        the reference's DataLoader workers do on CPU cores, train.py:120-121): call i launches ``k_step`` on the side
+        stream (it emits an older batch into one of two output buffers) and, on the caller's stream, runs the network
+        on the batch the PREVIOUS call's launch emitted into the other buffer.  The two only meet through events that
+        were recorded a whole step earlier, so neither queue waits: the voxelizer leaves the step's critical path.
+        ``points`` must be ready when the call is made (resident, or produced on the caller's stream before an event
+        this method can order against: the side stream waits for the caller's stream as of the PREVIOUS call).
+        Returns ``(cls, reg)`` of the batch handed in ``PillarVoxelizer.LAG + 1`` calls ago, else ``None``;
+        ``points=None`` drains."""
+        ov = getattr(self, "_ov", None)
+        if ov is None:
+            ov = self._ov = {"stream": torch.cuda.Stream(device=self.device), "i": 0, "bufs": [None, None],
+                             "vox_done": [torch.cuda.Event(), torch.cuda.Event()], "net_done": torch.cuda.Event(),
+                             "ready": [None, None], "armed": False}
+        main = torch.cuda.current_stream(self.device)
+        i, side = ov["i"], ov["stream"]
+        k = i % 2
+        if ov["armed"]:
+            side.wait_event(ov["net_done"])      # buffer k was read by the network of the previous call
+        B = self.voxelizer._inflight[-1] if getattr(self.voxelizer, "_inflight", None) else None
+        with torch.cuda.stream(side):
+            if B and (ov["bufs"][k] is None or ov["bufs"][k][0].shape[0] != B):
+                cfg = self.vox_cfg
+                ov["bufs"][k] = (torch.empty((B, 9, cfg.max_pillars, cfg.max_points_per_pillar), dtype=torch.float32,
+                                             device=self.device),
+                                 torch.empty((B, cfg.max_pillars, 3), dtype=torch.int64, device=self.device))
+            r = self.voxelizer.submit(points, n_points=n_points, out=ov["bufs"][k] if B else None)
+            ov["vox_done"][k].record(side)
+        ov["ready"][k] = r
+        ov["i"] = i + 1
+        prev = ov["ready"][1 - k]
+        ov["ready"][1 - k] = None
+        out = None
+        if prev is not None:
+            main.wait_event(ov["vox_done"][1 - k])
+            out = self.model(prev[0], prev[1])
+        ov["net_done"].record(main)
+        ov["armed"] = True
+        return out
+
+    @torch.no_grad()
     def forward_fused(self, points, n_points=None):
         """Inference with PPFeatureNet fused into the voxelizer:
         the dense [9,P,N] tensor and the [64,P,N] intermediate never exist.  Needs

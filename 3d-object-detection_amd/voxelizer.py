@@ -345,6 +345,13 @@ class PillarVoxelizer:
         st["turn"] = 1 - k
         return (canvas, indices, counts) if return_counts else (canvas, indices)
 
+    def step_kernel_name(self, batch):
+        """The k_step instance ``submit`` emits a batch of ``batch`` sweeps with, as a kernel trace prints it."""
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(_lib.lib().pp_voxelize_step_kernel_name(ctypes.byref(self._prm), int(batch), buf, 64),
+                   "pp_voxelize_step_kernel_name")
+        return buf.value.decode()
+
     def reset_stream(self):
         """Forgets the batches in flight in ``submit``'s pipeline (their results are never returned)."""
         _lib.check(_lib.lib().pp_voxelize_step_reset(self._ctx.handle), "pp_voxelize_step_reset")

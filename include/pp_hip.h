@@ -144,6 +144,11 @@ int pp_voxelize_step_pfn_canvas_dev(pp_ctx_t *ctx, void *stream, const float *po
                                     float *clear_canvas_dev, const int64_t *clear_indices_dev,
                                     int clear_batch, int *emitted);
 
+/* The instance of k_step a pp_voxelize_step_dev call emits a batch of `batch` sweeps with, as a profiler's
+ * kernel trace prints it ("pp::k_step<0, 16>": 16-byte stores, write-through; "<0, 0>": plain stores, beyond
+ * 128 MB of dense output; "<1, 0>": N not a multiple of 4) -- bench.py names its roofline kernel with it. */
+int pp_voxelize_step_kernel_name(const pp_voxel_params_t *prm, int batch, char *name, int cap);
+
 /* Forgets the batches in flight in pp_voxelize_step_dev's pipeline (end of an epoch, an abandoned
  * stream): the next call starts an empty pipeline.  Nothing is launched. */
 int pp_voxelize_step_reset(pp_ctx_t *ctx);

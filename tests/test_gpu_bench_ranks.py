@@ -63,6 +63,17 @@ def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
         tr = out["train_c3"]
         assert tr["collectives"]["world_size"] == 2 and tr["collectives"]["backend"] == "gloo"
         assert tr["allreduce_ms"] > 0 and tr["ms_per_step"] > 0
+        assert tr["targets"]["bytes_per_launch"] == 112 * 125000 * 4 and tr["targets"]["us_per_call"] > 0
+        # BASELINE configs[3] as named: one sweep per GPU and step, forward and training step, with its collectives
+        c3 = tr["configs3_one_sweep_per_gpu"]
+        assert c3["global_batch"] == 2 and c3["sweeps_per_gpu_per_step"] == 1
+        assert c3["collectives"]["world_size"] == 2 and c3["collectives"]["backend"] == "gloo"
+        for leg in ("forward", "train"):
+            assert c3[leg]["value"] > 0 and abs(c3[leg]["value"] - 2 * c3[leg]["steps"] /
+                                               (c3[leg]["ms_per_step"] * c3[leg]["steps"] * 1e-3)) < 1e-6 * c3[leg]["value"]
+        assert c3["allreduce_ms"] > 0
+        assert out["pipelined"] is True and out["latency_calls"] == 3 and out["three_launch_value"] > 0
+        assert out["overlapped"]["value"] > 0 and out["overlapped"]["latency_calls"] == 4
         assert "cpu_baseline" not in out and "stress_c5" not in out     # N = 1 legs only
     # every rank used its own MIOpen directories under TMPDIR
     roots = [d for d in os.listdir(tmp_path) if d.startswith("pp_miopen_")]

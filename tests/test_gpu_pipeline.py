@@ -366,3 +366,35 @@ def test_fused_tables_follow_the_weights(gpu):
     sd = {k: (v * 1.05 if v.dtype.is_floating_point else v) for k, v in pipe.model.state_dict().items()}
     pipe.model.load_state_dict(sd)
     fused_vs_plain()
+
+
+def test_forward_overlapped_equals_forward(gpu):
+    """PillarPipeline.forward_overlapped (k_step on a side stream beside the network, two output buffers, events one
+    step old): the same results as forward(), batch for batch, LAG + 1 calls later -- over changing clouds and batch
+    sizes, with cache-flushing traffic on the main stream in between."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    pipe = PillarPipeline(VoxelConfig.square(16.0, 0.2, 4000, 32), feature_channels=64, device=gpu, seed=0)
+    pipe.model.eval()
+    clouds = [torch.from_numpy(np.stack([synth.lidar_like(n, 16.0, sd + s) for s in range(B)])).to(gpu)
+              for n, sd, B in ((15000, 3, 2), (9000, 40, 2), (12000, 80, 1), (15000, 5, 3), (7000, 9, 2), (15000, 3, 2),
+                               (11000, 60, 2))]
+    want = [tuple(x.clone() for x in pipe.forward(c)) for c in clouds]
+    torch.cuda.synchronize()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=gpu)
+    outs = []
+    lag = pipe.voxelizer.LAG + 1
+    for k, c in enumerate(clouds + [None] * lag):
+        r = pipe.forward_overlapped(c)
+        assert (r is None) == (k < lag)
+        if r is not None:
+            outs.append(tuple(x.clone() for x in r))
+        if k % 2 == 0:
+            junk.zero_()
+    torch.cuda.synchronize()
+    assert len(outs) == len(clouds)
+    for (c, r), (wc, wr) in zip(outs, want):
+        assert c.shape == wc.shape
+        assert (c - wc).abs().max().item() <= 2e-6 and (r - wr).abs().max().item() <= 2e-6
