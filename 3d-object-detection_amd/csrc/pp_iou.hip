@@ -305,8 +305,10 @@ struct TgtLds {
       double terms[kMaxNP][kPairsPerRound][kGroup];      // shoelace terms on their way to the ordered sum
       double iou[kPairCap];
     };
-    float stage[kTgtThreads * kStageCols];  // ... and, after it, the target rows on their way out
+    float stage[kTgtThreads * kStageCols];  // ... and, after it, the class rows on their way out
   };
+  float rstage[kTgtThreads * 9];          // the regression rows on their way out
+  int gcls[kGtChunk];                     // classes of the chunk's ground truths
   u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
   int carg[kGtChunk];                     // first anchor reaching it
   unsigned short pair_lane[kPairCap], pair_gt[kPairCap];
@@ -662,7 +664,7 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
         same &= bit ? bal : ~bal;
       }
       const bool later = ((same >> ln) >> 1) != 0ull;
-      u64 mask = 0ull, rest = same;
+      u64 mask = 0ull, rest = i != 0 ? same : 0ull;  // (the rows without a forced anchor all "share" anchor 0)
       while (__ballot(rest != 0ull)) {  // as many turns as the largest group has members: one, as a rule
         const int src = rest ? __ffsll((long long)rest) - 1 : ln;
         const int c2 = __shfl(cbit, src);
@@ -850,7 +852,9 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   // runs.  Every wave fetches the chunk's centres for itself (lane = ground truth): the "is any box
   // near this workgroup" decision below then needs no LDS and no barrier.
   double2 pre_c = make_double2(0.0, 0.0), pre_k = make_double2(0.0, 0.0);
+  int pre_cls = 0;
   auto load_chunk = [&](int j0, int gn) {
+    if (!MATRIX && tid < gn) pre_cls = t.g_class[j0 + tid];  // (a positive's class used to be a load of its own, late)
     if (lane < gn) {
       const double *gp = t.g_centers_img + (int64_t)(j0 + lane) * t.g_center_cols;
       pre_c = make_double2(gp[0], gp[1]);
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     if (lds_types && tid < t.per_cell * kTypeCols) S.types[0][tid] = pre_ty;
   }
   double best = 0.0;  // np.max over a row that is all zeros is 0, argmax 0
-  int best_j = 0;
+  int best_j = 0, best_c = -1;
   bool bad = false;
   // this workgroup's columns of a chunk -> the list (at most one entry per ground truth)
   // wave 0: reserve list slots for the chunk's touched columns (one counter bump), write them later
@@ -969,6 +973,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     __syncthreads();
     if (tid < gn) {  // wave 0's copy
       S.gc[tid] = pre_c;
+      S.gcls[tid] = pre_cls;
       S.cmax[tid] = 0ull;
       S.cseen[tid] = 0ull;
       S.carg[tid] = INT_MAX;
@@ -1054,6 +1059,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
           if (val > best) {
             best = val;
             best_j = j0 + S.pair_gt[q - wb];
+            best_c = S.gcls[S.pair_gt[q - wb]];
           }
         }
       }
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   const int nc = t.num_classes;
   const int nrows = (int)min((int64_t)kTgtThreads, t.A - i0);
   const bool pos = live && best > t.pos_thresh;  // box_utils.py:195 (strict >)
-  const int cj = pos ? t.g_class[best_j] : -1;
+  const int cj = pos ? best_c : -1;
   float *cls_dst = t.cls_targets + i0 * nc, *reg_dst = t.reg_targets + i0 * 9;
   // Does the tail depend on this workgroup at all?  It reads the list entries and overwrites forced
   // rows, and a forced anchor has IoU > 0 with its ground truth: only a workgroup with a touched
@@ -1136,20 +1142,18 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
       S.pair_gt[k] = (unsigned short)best_j;
     }
     const bool cls_staged = nc <= kStageCols && ((uintptr_t)t.cls_targets & 15) == 0;
-    if (cls_staged) {
-      if (live)
+    if (live) {
+      if (cls_staged)
         for (int c = 0; c < nc; ++c) S.stage[tid * nc + c] = (c == cj) ? 1.0f : 0.0f;
-      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < 9; ++d) S.rstage[tid * 9 + d] = 0.0f;
+    }
+    __syncthreads();
+    if (cls_staged) {
       store_rows(cls_dst, S.stage, nrows * nc, tid);
     } else if (live) {
       for (int c = 0; c < nc; ++c) store_f32_sc1(&cls_dst[(int64_t)tid * nc + c], (c == cj) ? 1.0f : 0.0f);
     }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-      for (int d = 0; d < 9; ++d) S.stage[tid * 9 + d] = 0.0f;
-    }
-    __syncthreads();
     // The positives' regression rows, one KIND of value per wave (a wave executes every branch its lanes take:
     // eight lanes per row, one value each, made every wave pay for a square root, divisions, a logarithm and
     // a sine per 32 rows): wave 0 the sine and the orientation bit, wave 1 two logarithms (independent chains:
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
           const BoxVals a = anchor_vals(t, i0 + pl);
           ax = a.x, ay = a.y, az = a.z, aw = a.w, al = a.l, ah = a.h, ayaw = a.yaw;
         }
-        float *row = S.stage + pl * 9;
+        float *row = S.rstage + pl * 9;
         auto gval = [&](int k) -> double {  // k: x, y, z, w, l, h, yaw
           return k < 3 ? t.g_centers[pj * 3 + k] : k < 6 ? t.g_wlh[pj * 3 + k - 3] : t.g_yaw[pj];
         };
@@ -1189,10 +1193,10 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     }
     __syncthreads();
     if (((uintptr_t)t.reg_targets & 15) == 0) {
-      store_rows(reg_dst, S.stage, nrows * 9, tid);
+      store_rows(reg_dst, S.rstage, nrows * 9, tid);
     } else if (live) {
 #pragma unroll
-      for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], S.stage[tid * 9 + d]);
+      for (int d = 0; d < 9; ++d) store_f32_sc1(&reg_dst[(int64_t)tid * 9 + d], S.rstage[tid * 9 + d]);
     }
   }
   IOU_STAMP(6);

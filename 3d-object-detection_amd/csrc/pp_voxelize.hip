@@ -2428,6 +2428,14 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
     a.split_b0 = sb;
     a.n_split_blocks = sb_new.valid ? whole.s.nchunks * sn : 0;
     a.emit_b0 = eb;
+#ifdef PP_STEP_SKIP_KNOB  // tools/lab timing builds only (results are garbage): PP_STEP_SKIP = bit mask of roles left out
+    {
+      static const int skip = [] { const char *e = getenv("PP_STEP_SKIP"); return e ? atoi(e) : 0; }();
+      if (skip & 1) a.n_tile_blocks = 0;
+      if (skip & 2) a.n_order_blocks = 0;
+      if (skip & 4) a.n_split_blocks = 0;
+    }
+#endif
     const int n_emit = whole.emit_nbx * en;
     if (sb_emit.valid && !pfn) {
       static const int forced = [] {  // development knob: PP_EMIT_SC1=0/1

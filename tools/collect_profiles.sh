@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/collect_profiles.sh: the rocprofv3 evidence of one round (run on the GPU box through gpurun):
+# tools/collect_profiles.sh: the rocprofv3 evidence of one round (round 4: + batched target assignment, rotating
+# output buffers, cache counters of k_step, the fused path's one-launch form) (run on the GPU box through gpurun):
 # kernel stats of the driver's bench command and of the voxelizer-only loop at C2/C5, B=1/4, software-pipelined
 # (k_step) and as three launches; FETCH_SIZE / WRITE_SIZE in separate --pmc passes; SQ counters of the binning
 # kernels.  Output: gpurun_out/prof/
@@ -58,4 +59,23 @@ done
 pmc sq1_c5_b4_three "$SQ1" $V --batch 4 $C5 --iters 50
 pmc sq2_c5_b4_three "$SQ2" $V --batch 4 $C5 --iters 50
 T="python3 $R/tools/bench_targets.py"
-stats targets_c3 $T
+stats targets_c3 $T 250 40 4 2 single          # one sample per launch (rounds 1-3's form)
+stats targets_c3_b4 $T 250 40 4 2 batch         # the batch of a step in one launch
+stats targets_default_b4 $T 300 40 4 6 batch    # the reference's shipped anchor set (540 000 anchors)
+pmc pmc_targets_c3_b4_fetch FETCH_SIZE $T 250 40 4 2 batch
+pmc pmc_targets_c3_b4_write WRITE_SIZE $T 250 40 4 2 batch
+pmc sq1_targets_c3_b4 "$SQ1" $T 250 40 4 2 batch
+pmc sq2_targets_c3_b4 "$SQ2" $T 250 40 4 2 batch
+# k_step with its outputs rotating through >= 512 MB of buffers (real HBM traffic) against the one-buffer loop
+stats vox_c2_b4_step_rotate $V --batch 4 --pipelined --rotate 4
+stats vox_c2_b4_three_rotate $V --batch 4 --rotate 4
+pmc pmc_c2_b4_step_rotate_fetch FETCH_SIZE $V --batch 4 --iters 50 --pipelined --rotate 4
+pmc pmc_c2_b4_step_rotate_write WRITE_SIZE $V --batch 4 --iters 50 --pipelined --rotate 4
+# cache counters of k_step: the end-to-end loop (the network's activations between two launches), the
+# voxelizer-only loop with rotating outputs, and the one-buffer loop
+TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
+pmc tcc_bench_headline "$TCC" python3 $R/bench.py --steps 20 --warmup 5 --headline-only
+pmc tcc_c2_b4_step_rotate "$TCC" $V --batch 4 --iters 50 --pipelined --rotate 4
+pmc tcc_c2_b4_step_onebuf "$TCC" $V --batch 4 --iters 50 --pipelined
+# the fused feature-net call: three launches and the one-launch form
+stats fused_c2_b4 python3 $R/tools/bench_fused_vox.py 4

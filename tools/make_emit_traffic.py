@@ -1,4 +1,4 @@
-"""profiles/emit_traffic.json from the committed PMC summaries of the current round (profiles/r03/pmc_*_summary.csv):
+"""profiles/emit_traffic.json from the committed PMC summaries of the current round (profiles/<round>/pmc_*_summary.csv):
 HBM bytes per launch of the dominant voxelizer kernel = FETCH_SIZE + WRITE_SIZE medians (KiB * 1024).
 bench.py prints these constants as `roofline.traffic` (labelled static: they are not measured in the bench run)."""
 import csv
@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 D = os.path.join(ROOT, "profiles", rnd)
 
 
