@@ -1513,8 +1513,8 @@ struct TileRole {
 // load.  A few workgroups at the head of the grid read those arrays once, front to back, with many loads in
 // flight: the lines land in the memory-side Infinity Cache before most of the chains ask for them.
 struct PrefetchRole {
-  const void *ptr[6];
-  unsigned n16[6];       // 16-byte units
+  const void *ptr[7];
+  unsigned n16[7];       // 16-byte units
   const u64 *tile_agg;   // [nlists] {points << 32 | occupied cells}: how much of each tile's list is in use
   const int4 *tile_meta;
   int nlists, list_stride;
@@ -1599,7 +1599,7 @@ __global__ __launch_bounds__(kStepThreads, step_minwaves(MODE)) void k_step(Step
       for (unsigned e = threadIdx.x & 63; e < c; e += kWave) acc ^= (unsigned)lst[e].x;
     }
 #pragma unroll 1
-    for (int r = 0; r < 6; ++r) {
+    for (int r = 0; r < 7; ++r) {
       const uint4 *p = reinterpret_cast<const uint4 *>(a.pf.ptr[r]);
       const unsigned n = a.pf.n16[r];
       for (unsigned i = worker; i < n; i += 8u * nworkers) {
@@ -1627,10 +1627,11 @@ __global__ __launch_bounds__(kStepThreads, step_minwaves(MODE)) void k_step(Step
     }
     id -= a.n_unscatter_blocks;
   }
-  // Block order.  Workgroups are dispatched in id order.  The binning roles' (tile, split) are few and
-  // latency-bound, the emit role's many and store-bound: the grid starts with groups of one binning block
-  // and mix-1 emit blocks, so that the stores flow from the first microsecond AND every binning chain starts
-  // early (a chain that starts late is the launch's tail); what is left of either kind follows.
+  // Block order.  Workgroups are dispatched in id order.  The binning roles' (tile, order, split) are few and
+  // latency-bound, the emit role's many and store-bound; a binning chain that starts late is the launch's
+  // tail.  mix_groups = 0 (the default, host side): all binning blocks first, then the emit blocks.
+  // mix_groups > 0 (PP_STEP_MIX = m >= 2): the grid starts with groups of one binning block and m-1 emit
+  // blocks, so that the stores also flow from the first microsecond; what is left of either kind follows.
   {
     const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
     const int head = a.mix_groups * a.mix;
@@ -2467,6 +2468,12 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
         add(a.t.kslot, (size_t)a.t.ncap * 4, tb, tn);
         add(a.t.kpts, (size_t)a.t.ncap * 16, tb, tn);
       }
+      static const int pref_points = [] {  // development knob: PP_STEP_PREFETCH_POINTS=0/1
+        const char *e = getenv("PP_STEP_PREFETCH_POINTS");
+        return e ? atoi(e) : 1;
+      }();
+      if (pref_blocks > 0 && sn > 0 && pref_points)   // ... and the split role: the caller's points, cold after a network pass
+        add(a.s.pts, (size_t)a.s.sweep_stride * 16, sb, sn);
       a.n_pref_blocks = r > 0 || a.pf.nlists > 0 ? pref_blocks : 0;
     }
     if (mode != kModePfn) a.n_unscatter_blocks = 0;
@@ -2474,7 +2481,11 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
                               a.n_split_blocks + n_emit;
     {
       const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
-      a.mix = mix_env ? mix_env : 2;
+      // Default: every binning block ahead of the emit blocks.  After a network pass (the real caller: a GiB of
+      // activations between two launches) the binning roles' chains run on cold lines and are the launch's
+      // tail unless they start first: 39 -> 35 us in bench.py's end-to-end loop; in a voxelizer-only loop, where
+      // their inputs are still cached, the 1:1 interleave (mix 2) was 2 us better (42.4 vs 40.6 us, round 4).
+      a.mix = mix_env ? mix_env : 1;
       a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit / (a.mix - 1)) : 0;
       if (a.mix < 2) a.mix = 2, a.mix_groups = 0;
     }
