@@ -838,7 +838,20 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   // Batch launches are (sample, tile of 256 anchors): workgroups are dispatched x first, so the samples
   // advance side by side -- with the samples one after the other the last one's workgroups all started
   // late, its heavy ones last, and the launch ended ~10 us after everything else had drained.
-  const unsigned tile = MATRIX ? blockIdx.x : blockIdx.y, nwg = MATRIX ? gridDim.x : gridDim.y;
+  // ... and centre-out over the tiles (dispatch position k -> tile mid, mid+1, mid-1, ...): anchors are laid out row
+  // by row, so the tiles dispatched LAST are the canvas' first and last rows -- where boxes are rarest (objects
+  // gather around the ego vehicle, the centre of the canvas; the synthetic boxes keep a margin) -- and a launch
+  // whose last workgroups are the cheap ones drains sooner (C3 B=4: see profiles/r04/NOTES.md).
+  const unsigned nwg = MATRIX ? gridDim.x : gridDim.y;
+  unsigned tile = blockIdx.x;
+  if constexpr (!MATRIX) {
+    const unsigned k = blockIdx.y, mid = nwg >> 1, up = mid + ((k + 1u) >> 1);
+    // k odd: mid + (k+1)/2, k even: mid - k/2; once one side is used up, the rest of the other side in order
+    if (k & 1u)
+      tile = up < nwg ? up : nwg - 1u - k;            // upper side exhausted: what is left below, downwards
+    else
+      tile = (k >> 1) <= mid ? mid - (k >> 1) : k;    // lower side exhausted: what is left above, upwards
+  }
   if constexpr (!MATRIX) sample_view(t, bt, (int)blockIdx.x, nwg);
   __shared__ __align__(16) unsigned char smem[kTgtLdsBytes];
   TgtLds &S = *reinterpret_cast<TgtLds *>(smem);
