@@ -126,3 +126,66 @@ def test_random_target_assignment(gpu, oracle, case):
         assert np.array_equal(reg_t[:, 0], ref_r[:, 0].astype(np.float32))
         assert np.array_equal(reg_t[:, 8], ref_r[:, 8].astype(np.float32))
         assert np.abs(reg_t - ref_r.astype(np.float32)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("case", list(range(12)))
+def test_random_target_assignment_batches(gpu, oracle, case):
+    """Random BATCHES through the one-launch form (pp_assign_targets[_grid]_batch_dev): 1-7 samples with 0-150 boxes
+    each (so that a batch mixes the one-box-per-lane tail, the LDS tail with wave-specialised rows and samples of
+    several 64-box chunks), 1-3 anchor types, feature-map scales that are and are not powers of two, 3-12 classes,
+    clustered boxes (several clip rounds per workgroup), exact duplicates -- every sample against the oracle's
+    create_target, anchors on the fly and uploaded."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    rng = np.random.default_rng(9100 + case)
+    fm = int(rng.integers(24, 64))
+    per_cell = int(rng.integers(1, 4))
+    scale = float(rng.choice([0.5, 0.5, 0.25, 0.4]))
+    H = int(round(fm / scale))
+    unit = H / (2.0 * fm)                                           # anchor spacing in canvas units / 2
+    dims = tuple(tuple(float(v) for v in (rng.uniform(4, 14) * unit, rng.uniform(8, 30) * unit, rng.uniform(1, 3)))
+                 for _ in range(per_cell))
+    yaws = tuple(float(rng.choice([0.0, 90.0, 30.0])) for _ in range(per_cell))
+    zs = tuple(float(rng.uniform(0.3, 1.2)) for _ in range(per_cell))
+    acfg = boxes.AnchorConfig(fm, fm, scale, dims, yaws, zs)
+    anchors = boxes.make_anchors(acfg)
+    classes = int(rng.choice([3, 9, 12]))
+    B = int(rng.integers(1, 8))
+    gts = []
+    for b in range(B):
+        G = int(rng.choice([0, 1, 5, 30, 64, 65, 150]))
+        c = np.column_stack([rng.uniform(-5, H + 5, G), rng.uniform(-5, H + 5, G), rng.uniform(0, 2, G)])
+        if G >= 10:                                                  # a cluster: many pairs in a few workgroups
+            n_cl = G // 2
+            c[:n_cl, :2] = rng.uniform(0.2 * H, 0.8 * H, 2) + rng.uniform(-6, 6, (n_cl, 2))
+        g = {"centers": c,
+             "wlh": np.column_stack([rng.uniform(4, 14, G) * unit, rng.uniform(8, 30, G) * unit, rng.uniform(1, 3, G)]),
+             "yaw": rng.uniform(-np.pi, np.pi, G), "classes": rng.integers(0, classes, G).astype(np.int32)}
+        if G >= 4:
+            for k in ("centers", "wlh", "yaw"):
+                g[k][1] = g[k][0]                                    # an exact duplicate
+            i = int(rng.integers(1, acfg.num_anchors))
+            g["centers"][2], g["wlh"][2], g["yaw"][2] = anchors["centers"][i], anchors["wlh"][i], anchors["yaw"][i]
+        gts.append(g)
+    refs = []
+    for g in gts:
+        if len(g["yaw"]) == 0:          # no box: all-zero targets (the reference's create_target has nothing to reduce)
+            refs.append((np.zeros((acfg.num_anchors, classes)), np.zeros((acfg.num_anchors, 9))))
+            continue
+        c_img, k_img = boxes.boxes_to_image_space(g["centers"], g["wlh"], g["yaw"], H)
+        refs.append(oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                         anchors["yaw"], g["centers"], g["wlh"], g["yaw"], g["classes"], H,
+                                         pos_thresh=0.5, num_classes=classes)[:2])
+    for src in (acfg, anchors):
+        ta = TargetAssigner(src, canvas_height=H, pos_thresh=0.5, num_classes=classes, device=gpu)
+        for _ in range(2):                                           # twice: every sample's scratch was re-armed
+            cls_b, reg_b = ta.assign_batch(gts, check=True)
+        torch.cuda.synchronize()
+        cls_b, reg_b = cls_b.cpu().numpy(), reg_b.cpu().numpy()
+        for b, (ref_c, ref_r) in enumerate(refs):
+            tag = (case, fm, per_cell, scale, B, b, len(gts[b]["yaw"]))
+            assert np.array_equal(cls_b[b], ref_c.astype(np.float32)), tag
+            assert np.array_equal(reg_b[b][:, 0], ref_r[:, 0].astype(np.float32)), tag
+            assert np.array_equal(reg_b[b][:, 8], ref_r[:, 8].astype(np.float32)), tag
+            assert np.abs(reg_b[b] - ref_r.astype(np.float32)).max() <= 1e-6, tag
