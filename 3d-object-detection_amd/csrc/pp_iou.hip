@@ -80,11 +80,28 @@ struct TargetArgs {
   // that word and bumps `ticket`.  (One word for all workgroups: atomics on one address are served one
   // after the other, ~25 ns each -- 2110 workgroups of the reference's anchor set queued 50 us there.)
   unsigned *ticket1;
-  int ticket_shift;
+  int ticket_shift, ticket_groups;  // first-level tickets reserved per sample
+  // The box-centric form (k_targets_gt, grid anchors): see there
+  int fm_h, gt_splits;       // feature-map rows; workgroups per ground truth
+  unsigned cand_per_gt;      // list entries reserved per ground truth (anchor-centric form: its workgroups)
+  struct PosEntry *pos;      // [boxes][pos_per_gt] pairs above the threshold {anchor, box, IoU}
+  unsigned pos_per_gt;
+  unsigned *pos_count;       // per sample
+  float *cand_rows;          // [boxes][gt_splits][kRowPitch]: the regression row of each column-list slot's pair
+  u64 *best;                 // [samples][A]: highest IoU above the threshold an anchor has seen (0 = none); and
+  unsigned *bestj;           // [samples][A]: the first box reaching it (~0 = none) -- armed, re-armed by the tail
   // outputs
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
 };
+struct PosEntry {
+  unsigned anchor, gt;
+  u64 bits;
+  float row[9];  // the regression row of (anchor, box), worked out where the pair was clipped
+  float pad[3];
+};
+static_assert(sizeof(PosEntry) == 64, "pair entry layout");
+constexpr int kRowPitch = 12;  // floats between two rows of cand_rows (48 B)
 
 constexpr int kTypeCols = 13;
 
@@ -105,7 +122,7 @@ struct AnchorId {
 };
 
 // the view of sample b: everything per-sample moved to its rows (all wave-uniform: SGPR arithmetic)
-__device__ __forceinline__ void sample_view(TargetArgs &t, const TargetBatch &bt, int b, unsigned nwg) {
+__device__ __forceinline__ void sample_view(TargetArgs &t, const TargetBatch &bt, int b) {
   const int o = bt.g_off[b];
   t.G = bt.g_off[b + 1] - o;
   t.g_corners += (int64_t)o * 8;
@@ -116,10 +133,17 @@ __device__ __forceinline__ void sample_view(TargetArgs &t, const TargetBatch &bt
   t.g_class += o;
   t.col_max += o;
   t.col_win += o;
-  t.cand += (size_t)nwg * (size_t)o;  // sample b appends at most nwg * G_b entries
+  t.cand += (size_t)t.cand_per_gt * (size_t)o;  // sample b appends at most cand_per_gt * G_b entries
+  t.pos += (size_t)t.pos_per_gt * (size_t)o;
+  if (t.cand_rows) t.cand_rows += (size_t)t.cand_per_gt * (size_t)o * kRowPitch;
+  t.pos_count += b * kCounterStride;
+  if (t.best) {
+    t.best += (int64_t)b * t.A;
+    t.bestj += (int64_t)b * t.A;
+  }
   t.cand_count += b * kCounterStride;
   t.ticket += b * kCounterStride;
-  t.ticket1 += (size_t)b * (((nwg - 1u) >> t.ticket_shift) + 1u) * kTicketPad;
+  t.ticket1 += (size_t)b * (size_t)t.ticket_groups * kTicketPad;
   t.cls_targets += (int64_t)b * t.A * t.num_classes;
   t.reg_targets += (int64_t)b * t.A * 9;
 }
@@ -309,6 +333,9 @@ struct TgtLds {
   };
   float rstage[kTgtThreads * 9];          // the regression rows on their way out
   int gcls[kGtChunk];                     // classes of the chunk's ground truths
+  double gv7[8];                          // box-centric form: x, y, z, w, l, h, yaw of the workgroup's box
+  float colrow[12];                       // ... the regression row of its column maximum's pair
+  u64 need;                               // ... which lanes' pairs need a row
   u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
   int carg[kGtChunk];                     // first anchor reaching it
   unsigned short pair_lane[kPairCap], pair_gt[kPairCap];
@@ -531,10 +558,13 @@ __device__ unsigned long long g_iou_stamps[16 * 4096];
 #define IOU_STAMP(k) do {} while (0)
 #endif
 
+// n_fixed >= 0: the list has exactly that many slots, every one written by this launch (an unused one carries
+// the bits 0): the box-centric form, no counter to wait for
 template <bool IN_LDS>
-__device__ void targets_tail(const TargetArgs &t, TailLds &T) {
+__device__ void targets_tail(const TargetArgs &t, TailLds &T, int n_fixed = -1) {
   const int G = t.G, tid = threadIdx.x;
-  const unsigned n = __hip_atomic_load(t.cand_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned n = n_fixed >= 0 ? (unsigned)n_fixed
+                                  : __hip_atomic_load(t.cand_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   auto cmax_at = [&](int j) -> u64 * { return IN_LDS ? &T.colmax[j] : &t.col_max[j]; };
   auto cwin_at = [&](int j) -> u64 * { return IN_LDS ? &T.colwin[j] : &t.col_win[j]; };
   auto cmax_ld = [&](int j) -> u64 { return IN_LDS ? T.colmax[j] : ld_agent(&t.col_max[j]); };
@@ -601,7 +631,8 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
   for (unsigned e = kTailBatch * kTgtThreads + tid; e < n; e += kTgtThreads) {
     const u64 key = ld_agent(&t.cand[e].key);
     const int j = (int)(key & 0xFFFFFFFFull);
-    if (ld_agent(&t.cand[e].bits) == cmax_ld(j)) atomicMin(cwin_at(j), (key & 0xFFFFFFFF00000000ull) | e);
+    const u64 b = ld_agent(&t.cand[e].bits);
+    if (b != 0ull && b == cmax_ld(j)) atomicMin(cwin_at(j), (key & 0xFFFFFFFF00000000ull) | e);
   }
   sync();
   IOU_STAMP(12);
@@ -611,7 +642,8 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
     if (IN_LDS) {
       // anchor, class (63: a class outside the row, ignored like numpy would raise -- never written)
       const unsigned gc = (unsigned)t.g_class[j];
-      T.colwin[j] = (w & 0xFFFFFFFF00000000ull) | (gc < 63u ? gc : 63u);
+      // ... and the list entry it came in (bits 6..31)
+      T.colwin[j] = (w & 0xFFFFFFFF00000000ull) | ((w & 0x03FFFFFFull) << 6) | (gc < 63u ? gc : 63u);
     } else {
       __hip_atomic_store(&t.col_win[j], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -675,6 +707,18 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T) {
       if (i != 0) {
         float *cls = t.cls_targets + (int64_t)i * t.num_classes;
         for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;
+      }
+    } else if (i != 0 && t.cand_rows) {
+      // box-centric form: the PAIR workgroup that clipped (anchor i, box j) worked the row out: fetch it
+      // (the list entry is in bits 6..31 of colwin; other XCDs wrote it: sc1 loads)
+      const float *src = t.cand_rows + (size_t)((unsigned)(w & 0xFFFFFFFFull) >> 6) * kRowPitch;
+      auto ldf = [&](int k) { return __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      if (wv == 0) {
+        r0 = ldf(7), r1 = ldf(8);
+      } else if (wv == 1) {
+        r0 = ldf(4), r1 = ldf(5);
+      } else {
+        r0 = ldf(6), r1 = ldf(1), r2 = ldf(2), r3 = ldf(3);
       }
     } else if (i != 0) {
       if (wv == 0) {
@@ -852,7 +896,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     else
       tile = (k >> 1) <= mid ? mid - (k >> 1) : k;    // lower side exhausted: what is left above, upwards
   }
-  if constexpr (!MATRIX) sample_view(t, bt, (int)blockIdx.x, nwg);
+  if constexpr (!MATRIX) sample_view(t, bt, (int)blockIdx.x);
   __shared__ __align__(16) unsigned char smem[kTgtLdsBytes];
   TgtLds &S = *reinterpret_cast<TgtLds *>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1246,6 +1290,583 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   IOU_STAMP(10);
 }
 
+// ------------------------------------------------------------------------- //
+// k_targets_gt: create_target, box-centric (anchors on the fly)               //
+// ------------------------------------------------------------------------- //
+// k_targets walks the ANCHORS: 489 workgroups per sample at BASELINE config 3, every one paying ~2 us of
+// staging before it knows whether a box is anywhere near, the pairs spread thinly over them (21 of 32 slots
+// of a clip round filled), and the launch drains behind whichever workgroup happens to hold 100 pairs.  With
+// the anchors a regular grid (make_anchor_boxes, box_utils.py:111-159) the pairs can be enumerated from the
+// BOX side instead: the anchors within the +-10 centre gate (pillars.cpp:418-419) of box j are the cells
+// x0..x1 x y0..y1 around its centre -- computed one cell generous, then put through the SAME gate test on
+// the SAME centre values, so the set of pairs is exactly make_ious' -- about 200 per box at config 3.
+//   ZERO role   kZeroWgs workgroups per sample stream zeros over both target arrays (99.9 % of the bytes),
+//               a plain grid-stride fill;
+//   PAIR role   gt_splits workgroups per box, kCandPerWg candidate anchors each: gate, queue, clip with 8
+//               lanes per pair (clip_round: the code k_targets runs), then
+//                 - the box's column maximum and the first anchor reaching it among this workgroup's
+//                   pairs -> ONE list entry (the tail reduces a box's entries as it does k_targets'),
+//                 - every pair above the threshold -> the sample's positive list, and an atomic maximum
+//                   on best[anchor] (row maximum: np.max(ious, axis=1) can only exceed the threshold
+//                   through such a pair);
+//   tail        the sample's last workgroup (two-level ticket over ZERO and PAIR workgroups alike: the
+//               zeros must be down before a row is written): a positive-list entry wins its anchor when it
+//               holds best[anchor] and, among equals, the lowest box index (np.argmax: first maximum) --
+//               class and regression rows of the winners -- then k_targets' tail: column argmax, forced rows.
+// Results equal k_targets' bit for bit (same gate, same clip, same row expressions; tests run both forms
+// against each other and the oracle).
+#ifndef PP_CAND_PER_WG
+#define PP_CAND_PER_WG 64
+#endif
+constexpr int kCandPerWg = PP_CAND_PER_WG;   // candidate anchors per PAIR workgroup (<= 64): one wave gates, four clip
+static_assert(kCandPerWg >= 8 && kCandPerWg <= 64, "one lane of wave 0 per candidate");
+constexpr int kZeroWgs = 64;     // ZERO workgroups per sample (x 4 samples = a hipMemset-shaped grid)
+
+// `n` zero floats to dst (any 4-byte alignment, n * 4 < 2^31), this workgroup's share of a grid-stride fill by
+// `nwg` workgroups: ONE buffer resource for the array (wave-uniform: a per-lane base would make every store a
+// 64-trip waterfall loop), the lane's place in it as the 32-bit offset
+__device__ __forceinline__ void zero_share(float *dst, int64_t n, int wg, int nwg, int tid) {
+  const int head = (int)min((int64_t)((16 - ((uintptr_t)dst & 15)) & 15) / 4, n);  // floats before 16-byte alignment
+  if (wg == 0 && tid < head) store_f32_sc1(dst + tid, 0.0f);
+  const int n4 = (int)((n - head) >> 2);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(dst + head), 0, n4 * 16, 0x00020000);
+  const v4u z = {0u, 0u, 0u, 0u};
+  for (int k = wg * kTgtThreads + tid; k < n4; k += nwg * kTgtThreads) __builtin_amdgcn_raw_buffer_store_b128(z, rs, k * 16, 0, kAuxSc1);
+  const int64_t done = head + 4 * (int64_t)n4;
+  if (wg == 0 && tid < (int)(n - done)) store_f32_sc1(dst + done + tid, 0.0f);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+  return v;
+}
+
+// The winners of the positive list: rows of the anchors whose row maximum exceeds the threshold
+// (box_utils.py:193-196, 211, 219-221).  Runs in the sample's last workgroup, before the forced rows.
+// An entry wins its anchor when it holds the anchor's highest IoU and, among equals, the lowest box index
+// (np.argmax: first maximum).  Up to kPosLds entries (all real scenes: ~130 at BASELINE config 3) are resolved
+// in an LDS hash table keyed by the anchor; beyond that through the per-anchor words in global memory that the
+// PAIR role keeps current (correct, slower: three passes of dependent loads).
+constexpr int kPosLds = 1024;            // entries resolved in LDS
+constexpr int kPosHash = 2 * kPosLds;    // table slots (a power of two)
+struct PosLds {
+  unsigned key[kPosHash];   // anchor + 1 (0 = empty)
+  u64 bits[kPosHash];       // the anchor's highest IoU
+  unsigned minj[kPosHash];  // the first box reaching it
+};
+static_assert(sizeof(PosLds) <= kTgtLdsBytes, "the positives' stage reuses the workgroup's LDS");
+
+__device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
+  PosLds &W = *reinterpret_cast<PosLds *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned n_raw = __hip_atomic_load(t.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned cap = (unsigned)t.G * t.pos_per_gt;
+  const unsigned n = min(n_raw, cap);
+  if (n_raw > cap && tid == 0) atomicExch(t.errflag, 2);  // cannot happen: one entry per candidate at most
+  if (n == 0) return;
+  constexpr int kPer = kPosLds / kTgtThreads;
+  const bool in_lds = n <= (unsigned)kPosLds;
+  // the entries (other XCDs wrote them: sc1 loads), all in flight together
+  unsigned e_i[kPer], e_j[kPer];
+  u64 e_b[kPer];
+  bool e_win[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const unsigned e = (unsigned)(k * kTgtThreads + tid);
+    e_i[k] = e_j[k] = 0u;
+    e_b[k] = 0ull;
+    e_win[k] = false;
+    if (in_lds && e < n) {
+      const u64 ij = ld_agent(reinterpret_cast<const u64 *>(&t.pos[e]));
+      e_i[k] = (unsigned)ij;
+      e_j[k] = (unsigned)(ij >> 32);
+      e_b[k] = ld_agent(&t.pos[e].bits);
+    }
+  }
+  if (in_lds) {
+    for (int h = tid; h < kPosHash; h += kTgtThreads) {
+      W.key[h] = 0u;
+      W.bits[h] = 0ull;
+      W.minj[h] = ~0u;
+    }
+    __syncthreads();
+    int slot[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      slot[k] = -1;
+      if ((unsigned)(k * kTgtThreads + tid) < n) {
+        unsigned h = (e_i[k] * 2654435761u) >> (32 - 11);
+        static_assert(kPosHash == 2048, "hash width");
+        for (;;) {  // the table is at most half full
+          const unsigned old = atomicCAS(&W.key[h], 0u, e_i[k] + 1u);
+          if (old == 0u || old == e_i[k] + 1u) break;
+          h = (h + 1u) & (kPosHash - 1);
+        }
+        slot[k] = (int)h;
+        atomicMax(&W.bits[h], e_b[k]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (slot[k] >= 0 && e_b[k] == W.bits[slot[k]]) atomicMin(&W.minj[slot[k]], e_j[k]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) e_win[k] = slot[k] >= 0 && e_b[k] == W.bits[slot[k]] && e_j[k] == W.minj[slot[k]];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (e_win[k]) {
+        // class row: a one at the box's class (box_utils.py:211); the row is zero already
+        const int c = t.g_class[e_j[k]];
+        if ((unsigned)c < (unsigned)t.num_classes) t.cls_targets[(int64_t)e_i[k] * t.num_classes + c] = 1.0f;
+        // regression row (box_utils.py:219-221): the PAIR workgroup that clipped the pair worked it out
+        const float *src = t.pos[k * kTgtThreads + tid].row;
+        float *reg = t.reg_targets + (int64_t)e_i[k] * 9;
+        float rv[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) rv[d] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int d = 0; d < 9; ++d) reg[d] = rv[d];
+      }
+    // the per-anchor words of the slow path: back to "none" (the PAIR role raised them)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (slot[k] >= 0) __hip_atomic_store(&t.best[e_i[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    (void)lane;
+    (void)wv;
+  } else {
+    // more pairs above the threshold than the table holds: the per-anchor words in global memory
+    for (unsigned e0 = 0; e0 < n; e0 += kTgtThreads) {
+      const unsigned e = e0 + tid;
+      if (e < n) {
+        const u64 ij = ld_agent(reinterpret_cast<const u64 *>(&t.pos[e]));
+        const unsigned i = (unsigned)ij, j = (unsigned)(ij >> 32);
+        if (ld_agent(&t.pos[e].bits) == ld_agent(&t.best[i])) atomicMin(&t.bestj[i], j);
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    for (unsigned e0 = 0; e0 < n; e0 += kTgtThreads) {
+      const unsigned e = e0 + tid;
+      if (e < n) {
+        const u64 ij = ld_agent(reinterpret_cast<const u64 *>(&t.pos[e]));
+        const unsigned i = (unsigned)ij, j = (unsigned)(ij >> 32);
+        if (ld_agent(&t.pos[e].bits) == ld_agent(&t.best[i]) &&
+            j == __hip_atomic_load(&t.bestj[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          const int c = t.g_class[j];
+          if ((unsigned)c < (unsigned)t.num_classes) t.cls_targets[(int64_t)i * t.num_classes + c] = 1.0f;
+          float *reg = t.reg_targets + (int64_t)i * 9;
+#pragma unroll
+          for (int d = 0; d < 9; ++d)
+            reg[d] = __hip_atomic_load(t.pos[e].row + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    for (unsigned e = tid; e < n; e += kTgtThreads) {
+      const unsigned i = (unsigned)ld_agent(reinterpret_cast<const u64 *>(&t.pos[e]));
+      __hip_atomic_store(&t.best[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&t.bestj[i], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tid == 0) *t.pos_count = 0u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the winners' rows are down before a forced row overwrites one
+  __syncthreads();
+}
+
+// The box-centric tail in its usual shape -- at most 64 boxes, 512 list slots, 256 pairs above the threshold,
+// 63 classes -- as ONE pass: every global load it needs (the pair counter, the pair entries with their rows and
+// classes, the column slots, the boxes' classes) is issued up front and in flight together, the positives' hash
+// and the column argmax share their two LDS phases, and the only dependent round trip left is the forced rows'
+// fetch.  (positives_tail + targets_tail, one after the other: 6.6 us of the launch's 16; this: see NOTES.)
+// Returns false -- workgroup-uniformly, before it has written anything -- when the sample does not fit.
+constexpr int kFastPos = 256, kFastHash = 512;
+struct FastTailLds {
+  unsigned key[kFastHash];   // anchor + 1 (0 = empty)
+  u64 bits[kFastHash];       // the anchor's highest IoU
+  unsigned minj[kFastHash];  // the first box reaching it
+  u64 colmax[64], colwin[64];
+  int cls[64];
+  unsigned later[64];
+};
+static_assert(sizeof(FastTailLds) <= kTgtLdsBytes, "the fast tail reuses the workgroup's LDS");
+
+__device__ bool tail_gt_fast(const TargetArgs &t, unsigned char *smem, int nslots) {
+  FastTailLds &F = *reinterpret_cast<FastTailLds *>(smem);
+  const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, G = t.G;
+  constexpr int kPer = kFastPos / kTgtThreads;
+  const unsigned cap = min((unsigned)G * t.pos_per_gt, (unsigned)kFastPos);
+  auto ldf = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // ---- every load, speculatively (an entry beyond the counter is stale and ignored)
+  const unsigned n_raw = __hip_atomic_load(t.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned e_i[kPer], e_j[kPer];
+  u64 e_b[kPer];
+  int e_c[kPer];
+  float e_row[kPer][9];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const unsigned e = (unsigned)(k * kTgtThreads + tid);
+    e_i[k] = e_j[k] = 0u;
+    e_b[k] = 0ull;
+    e_c[k] = -1;
+    if (e < cap) {
+      const PosEntry *pe = t.pos + e;
+      const u64 ij = ld_agent(reinterpret_cast<const u64 *>(pe));
+      e_i[k] = (unsigned)ij;
+      e_j[k] = (unsigned)(ij >> 32);
+      e_b[k] = ld_agent(&pe->bits);
+      e_c[k] = __float_as_int(ldf(pe->pad));
+#pragma unroll
+      for (int d = 0; d < 9; ++d) e_row[k][d] = ldf(pe->row + d);
+    }
+  }
+  u64 c_key[2], c_bits[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = k * kTgtThreads + tid;
+    c_key[k] = c_bits[k] = 0ull;
+    if (e < nslots) {
+      c_key[k] = ld_agent(&t.cand[e].key);
+      c_bits[k] = ld_agent(&t.cand[e].bits);
+    }
+  }
+  const int my_cls = tid < G ? t.g_class[tid] : 0;
+  if (n_raw > (unsigned)kFastPos || n_raw > (unsigned)G * t.pos_per_gt) return false;  // uniform: one word, every thread
+  const unsigned n = n_raw;
+  // ---- LDS phase 0
+  for (int h = tid; h < kFastHash; h += kTgtThreads) {
+    F.key[h] = 0u;
+    F.bits[h] = 0ull;
+    F.minj[h] = ~0u;
+  }
+  if (tid < 64) {
+    F.colmax[tid] = 0ull;
+    F.colwin[tid] = ~0ull;
+    F.cls[tid] = my_cls;
+  }
+  __syncthreads();
+  // ---- phase 1: maxima (rows: per anchor through the hash table; columns: per box)
+  int slot[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    slot[k] = -1;
+    if ((unsigned)(k * kTgtThreads + tid) < n) {
+      unsigned h = (e_i[k] * 2654435761u) >> (32 - 9);
+      static_assert(kFastHash == 512, "hash width");
+      for (;;) {  // the table is at most half full
+        const unsigned old = atomicCAS(&F.key[h], 0u, e_i[k] + 1u);
+        if (old == 0u || old == e_i[k] + 1u) break;
+        h = (h + 1u) & (kFastHash - 1);
+      }
+      slot[k] = (int)h;
+      atomicMax(&F.bits[h], e_b[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (c_bits[k]) atomicMax(&F.colmax[(int)(c_key[k] & 0xFFFFFFFFull)], c_bits[k]);
+  __syncthreads();
+  // ---- phase 2: first box reaching a row's maximum; first anchor reaching a column's, and its list slot
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    if (slot[k] >= 0 && e_b[k] == F.bits[slot[k]]) atomicMin(&F.minj[slot[k]], e_j[k]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = (int)(c_key[k] & 0xFFFFFFFFull);
+    if (c_bits[k] && c_bits[k] == F.colmax[j])
+      atomicMin(&F.colwin[j], (c_key[k] & 0xFFFFFFFF00000000ull) | (unsigned)(k * kTgtThreads + tid));
+  }
+  __syncthreads();
+  // ---- the positives' rows (box_utils.py:211, 219-221), from registers
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    if (slot[k] >= 0) {
+      if (e_b[k] == F.bits[slot[k]] && e_j[k] == F.minj[slot[k]]) {
+        if ((unsigned)e_c[k] < (unsigned)t.num_classes) t.cls_targets[(int64_t)e_i[k] * t.num_classes + e_c[k]] = 1.0f;
+        float *reg = t.reg_targets + (int64_t)e_i[k] * 9;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) reg[d] = e_row[k][d];
+      }
+      __hip_atomic_store(&t.best[e_i[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slow path's word
+    }
+  // ---- forced rows (box_utils.py:199-205, 212-213, 223-228): lane = box
+  const u64 w = (ln < G && F.colmax[ln] != 0ull) ? F.colwin[ln] : 0ull;
+  const int i = (int)(w >> 32);  // the anchor box ln forces; 0: none (an argmax of 0 is dropped, :204-205)
+  float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+  u64 mask = 0ull;
+  if (wv == 3) {
+    // lanes forcing the same anchor find each other bit by bit: one ballot per bit of the anchor index
+    unsigned gc = (unsigned)F.cls[ln];
+    gc = gc < 63u ? gc : 63u;  // (63: a class outside the row, never written)
+    u64 same = G == 64 ? ~0ull : (1ull << G) - 1ull;
+    const int nbits = 32 - __clz((int)t.A);  // i < A
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = ((unsigned)i >> b) & 1u;
+      const u64 bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const bool later = ((same >> ln) >> 1) != 0ull;
+    u64 rest = i != 0 ? same : 0ull;
+    while (__ballot(rest != 0ull)) {  // as many turns as the largest group has members: one, as a rule
+      const int src = rest ? __ffsll((long long)rest) - 1 : ln;
+      const int c2 = __shfl((int)gc, src);
+      mask |= rest ? (1ull << c2) : 0ull;
+      rest &= rest - 1ull;
+    }
+    F.later[ln] = later ? 1u : 0u;
+  } else if (i != 0) {
+    const float *src = t.cand_rows + (size_t)(unsigned)(w & 0xFFFFFFFFull) * kRowPitch;  // the slot the argmax came in
+    if (wv == 0) {
+      r0 = ldf(src + 7), r1 = ldf(src + 8);
+    } else if (wv == 1) {
+      r0 = ldf(src + 4), r1 = ldf(src + 5);
+    } else {
+      r0 = ldf(src + 6), r1 = ldf(src + 1), r2 = ldf(src + 2), r3 = ldf(src + 3);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the positives' rows are down before a forced row overwrites one
+  __syncthreads();
+  if (i != 0) {
+    if (wv == 3) {
+      float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+      for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;
+    } else if (F.later[ln] == 0u) {
+      float *reg = t.reg_targets + (int64_t)i * 9;
+      if (wv == 0) {
+        reg[0] = 1.0f;
+        reg[7] = r0;
+        reg[8] = r1;
+      } else if (wv == 1) {
+        reg[4] = r0;
+        reg[5] = r1;
+      } else {
+        reg[6] = r0;
+        reg[1] = r1;
+        reg[2] = r2;
+        reg[3] = r3;
+      }
+    }
+  }
+  if (tid == 0) {  // re-armed for the next call on this context
+    *t.pos_count = 0u;
+    *t.cand_count = 0u;
+    *t.ticket = 0u;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArgs t, TargetBatch bt) {
+  sample_view(t, bt, (int)blockIdx.x);
+  __shared__ __align__(16) unsigned char smem[kTgtLdsBytes];
+  TgtLds &S = *reinterpret_cast<TgtLds *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int v = lane & (kGroup - 1), gbase = lane & ~(kGroup - 1);
+  const int G = t.G, nsp = t.gt_splits;
+  const unsigned u = blockIdx.y, n_units = (unsigned)kZeroWgs + (unsigned)G * (unsigned)nsp;
+  if (u >= n_units) return;
+  IOU_STAMP(0);
+  if (u < (unsigned)kZeroWgs) {
+    zero_share(t.cls_targets, t.A * t.num_classes, (int)u, kZeroWgs, tid);
+    zero_share(t.reg_targets, t.A * 9, (int)u, kZeroWgs, tid);
+    if (G == 0) return;  // no box: nothing else runs for this sample, no tail
+  } else {
+    const int pu = (int)u - kZeroWgs, j = pu / nsp, split = pu - j * nsp;
+    const bool lds_types = t.per_cell <= kLdsTypes;
+    // the box: centre (every thread holds it), corners and area in LDS slot 0
+    const double gcx = t.g_centers_img[(int64_t)j * t.g_center_cols], gcy = t.g_centers_img[(int64_t)j * t.g_center_cols + 1];
+    if (tid < 4) {
+      const double *gp = t.g_corners + ((int64_t)j * 4 + tid) * 2;
+      S.gk[0][tid] = make_double2(gp[0], gp[1]);
+    }
+    if (lds_types && tid < t.per_cell * kTypeCols) S.types[0][tid] = t.types[tid];
+    if (tid >= 64 && tid < 71) {  // the box's values for the rows: x, y, z, w, l, h, yaw
+      const int c = tid - 64;
+      S.gv7[c] = c < 3 ? t.g_centers[j * 3 + c] : c < 6 ? t.g_wlh[j * 3 + c - 3] : t.g_yaw[j];
+    }
+    if (tid == 71) S.gcls[0] = t.g_class[j];
+    __syncthreads();
+    if (tid == 0) {
+      double g8[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g8[2 * k] = S.gk[0][k].x;
+        g8[2 * k + 1] = S.gk[0][k].y;
+      }
+      S.garea[0] = -shoelace_dev(g8, 4);
+    }
+    IOU_STAMP(1);
+    // candidate cells: cell_centre(x) = (x + .5) / fm_scale within 10 of the box centre <=> x in [a, a + 20 * fm_scale]
+    // with a = (gcx - 10) * fm_scale - .5; the window is that range in exact arithmetic plus ONE cell either side
+    // (the gate below decides on the centre values themselves); a centre that is not finite passes the gate
+    // with every anchor (NaN compares false): the whole map
+    int x0 = 0, x1 = t.fm_w - 1, y0 = 0, y1 = t.fm_h - 1;
+    if (gcx - gcx == 0.0) {
+      x0 = max(x0, (int)fmax(ceil((gcx - 10.0) * t.fm_scale - 0.5) - 1.0, -1.0e9));
+      x1 = min(x1, (int)fmin(floor((gcx + 10.0) * t.fm_scale - 0.5) + 1.0, 1.0e9));
+    }
+    if (gcy - gcy == 0.0) {
+      y0 = max(y0, (int)fmax(ceil((gcy - 10.0) * t.fm_scale - 0.5) - 1.0, -1.0e9));
+      y1 = min(y1, (int)fmin(floor((gcy + 10.0) * t.fm_scale - 0.5) + 1.0, 1.0e9));
+    }
+    const int ncx = max(x1 - x0 + 1, 0), ncy = max(y1 - y0 + 1, 0);
+    const unsigned ncand = (unsigned)ncx * (unsigned)ncy * (unsigned)t.per_cell;  // <= A < 2^24
+    u64 col_bits = 0ull;          // wave 0: this workgroup's column maximum for box j ...
+    unsigned col_anchor = ~0u;    // ... and the first anchor reaching it
+    bool bad = false;
+    for (unsigned q0 = (unsigned)split * kCandPerWg; q0 < ncand; q0 += (unsigned)nsp * kCandPerWg) {
+      __syncthreads();  // the previous trip's LDS is read
+      int wn = 0;
+      if (wv == 0) {
+        const unsigned q = q0 + (unsigned)lane;
+        bool pass = false;
+        if (lane < kCandPerWg && q < ncand) {
+          const unsigned cell = q / (unsigned)t.per_cell, d = q - cell * (unsigned)t.per_cell;
+          const unsigned yy = cell / (unsigned)ncx, xx = cell - yy * (unsigned)ncx;
+          const unsigned x = (unsigned)x0 + xx, y = (unsigned)y0 + yy;
+          const double acx = cell_centre(t, x), acy = cell_centre(t, y);
+          S.acen[lane] = make_double2(acx, acy);
+          S.atype[lane] = (unsigned short)d;
+          S.carg[lane] = (int)((y * (unsigned)t.fm_w + x) * (unsigned)t.per_cell + d);  // the anchor's index
+          pass = !gate_far(acx, acy, gcx, gcy);
+        }
+        const u64 pm = __ballot(pass);
+        if (pass) {
+          const int k = __popcll(pm & ((1ull << lane) - 1ull));
+          S.pair_lane[k] = (unsigned short)lane;
+          S.pair_gt[k] = 0;
+        }
+        wn = __popcll(pm);
+        if (lane == 0) S.woff[0] = wn;
+      }
+      __syncthreads();
+      wn = S.woff[0];
+      IOU_STAMP(2);
+      for (int r0 = 0; r0 < wn; r0 += kPairsPerRound)
+        if (r0 + wv * (64 / kGroup) < wn) clip_round<1>(t, S, r0, wn, 0, tid, v, gbase, lds_types, bad);
+      __syncthreads();
+      IOU_STAMP(4);
+      // wave 0, lane = pair: the column (maximum, then the lowest anchor index among the pairs that reach it)
+      // and the pairs above the threshold
+      double val = 0.0;
+      unsigned ai = ~0u;
+      bool pos = false, newcol = false;
+      int col_lane = -1;
+      if (wv == 0) {
+        val = lane < wn ? S.iou[lane] : 0.0;
+        ai = lane < wn ? (unsigned)S.carg[S.pair_lane[lane]] : ~0u;
+        const double wmax = wave_minmax_f64<true>(val > 0.0 ? val : 0.0);
+        if (wmax > 0.0) {
+          const u64 wb = (u64)__double_as_longlong(wmax);
+          const unsigned first = wave_min_u32(val == wmax ? ai : ~0u);
+          if (wb > col_bits || (wb == col_bits && first < col_anchor)) {
+            newcol = true;
+            col_lane = __ffsll((long long)__ballot(val == wmax && ai == first)) - 1;
+            col_anchor = first;
+            col_bits = wb;
+          }
+        }
+        pos = val > t.pos_thresh;
+        const u64 need = __ballot(pos) | (newcol ? 1ull << col_lane : 0ull);
+        if (lane == 0) S.need = need;
+      }
+      __syncthreads();
+      // The regression rows of those pairs (box_utils.py:70-109), one KIND of value per wave, lane = pair: the
+      // tail then only copies rows -- it used to evaluate them, three or four f64 library chains of ~1 us at the very
+      // end of the launch, for a hundred-odd rows on 256 lanes.
+      const u64 need = S.need;
+      if (need && wv < 3 && ((need >> lane) & 1ull)) {
+        const int pl = S.pair_lane[lane];
+        const double *ty = lds_types ? S.types[S.atype[pl]] : t.types + (int)S.atype[pl] * kTypeCols;
+        float *row = S.rstage + lane * 9;
+        if (wv == 0) {
+          float dt, ort;
+          target_angle(S.gv7[6], ty[11], &dt, &ort);
+          row[0] = 1.0f;
+          row[7] = dt;
+          row[8] = ort;
+        } else if (wv == 1) {
+          row[4] = target_logratio(S.gv7[3], ty[8]);
+          row[5] = target_logratio(S.gv7[4], ty[9]);
+        } else {
+          row[6] = target_logratio(S.gv7[5], ty[10]);
+          row[1] = target_quotient(S.gv7[0], S.acen[pl].x, ty[8], ty[9], ty[10], t.canvas_height, 0);
+          row[2] = target_quotient(S.gv7[1], S.acen[pl].y, ty[8], ty[9], ty[10], t.canvas_height, 1);
+          row[3] = target_quotient(S.gv7[2], ty[12], ty[8], ty[9], ty[10], t.canvas_height, 2);
+        }
+      }
+      if (need) __syncthreads();  // (workgroup-uniform)
+      if (wv == 0) {
+        if (newcol && lane < 9) S.colrow[lane] = S.rstage[col_lane * 9 + lane];
+        const u64 pb = __ballot(pos);
+        if (pb) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(t.pos_count, (unsigned)__popcll(pb));
+          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          if (pos) {
+            const unsigned at = base + (unsigned)__popcll(pb & ((1ull << lane) - 1ull));
+            const u64 bits = (u64)__double_as_longlong(val);
+            if (at < (unsigned)G * t.pos_per_gt) {
+              PosEntry *pe = t.pos + at;
+              __hip_atomic_store(reinterpret_cast<u64 *>(pe), (u64)ai | ((u64)(unsigned)j << 32), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&pe->bits, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+              for (int d = 0; d < 9; ++d) store_f32_sc1(pe->row + d, S.rstage[lane * 9 + d]);
+              store_f32_sc1(pe->pad, __int_as_float(S.gcls[0]));  // the box's class rides along
+            }
+            __hip_atomic_fetch_max(&t.best[ai], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    if (bad) atomicExch(t.errflag, 1);
+    if (wv == 0 && lane == 0) {
+      // this workgroup's slot of the column list, written whether or not a pair overlapped (bits 0 = none): no
+      // counter, nothing stale, and the tail knows the list's length without a load
+      ColEntry *ce = t.cand + pu;
+      __hip_atomic_store(&ce->key, (u64)(unsigned)j | ((u64)(col_bits ? col_anchor : 0u) << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ce->bits, col_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wv == 0 && lane < 9 && col_bits != 0ull) store_f32_sc1(t.cand_rows + (size_t)pu * kRowPitch + lane, S.colrow[lane]);
+  }
+  // every store and atomic above is down before the ticket; the sample's last workgroup finishes the job
+  IOU_STAMP(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  IOU_STAMP(8);
+  if (tid == 0) {
+    unsigned *my_ticket1 = t.ticket1 + (size_t)(u >> t.ticket_shift) * kTicketPad;
+    const unsigned grp = u >> t.ticket_shift, ngrp = ((n_units - 1u) >> t.ticket_shift) + 1u;
+    const unsigned gsize = min(1u << t.ticket_shift, n_units - (grp << t.ticket_shift));
+    int last = 0;
+    if (atomicAdd(my_ticket1, 1u) == gsize - 1u) {
+      __hip_atomic_store(my_ticket1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (atomicAdd(t.ticket, 1u) == ngrp - 1u) ? 1 : 0;
+    }
+    S.is_last = last;
+  }
+  __syncthreads();
+  IOU_STAMP(9);
+  if (!S.is_last) return;
+  if (t.G <= 64 && t.G * nsp <= 2 * kTgtThreads && t.num_classes <= 63 && tail_gt_fast(t, smem, t.G * nsp)) {
+    IOU_STAMP(10);
+    return;
+  }
+  __syncthreads();  // (the fast tail may have touched the LDS before it declined)
+  positives_tail(t, smem);
+  IOU_STAMP(15);
+  if (t.G <= kForcedLds)
+    targets_tail<true>(t, *reinterpret_cast<TailLds *>(smem), t.G * nsp);
+  else
+    targets_tail<false>(t, *reinterpret_cast<TailLds *>(smem), t.G * nsp);
+  IOU_STAMP(10);
+}
+
+
 __global__ void k_targets_init(u64 *col_max, u64 *col_win, int G, int *errflag,
                                unsigned *cand_count, unsigned *ticket, unsigned *ticket1, int n_ticket1) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1259,6 +1880,15 @@ __global__ void k_targets_init(u64 *col_max, u64 *col_win, int G, int *errflag,
     ticket[j * kCounterStride] = 0u;
   }
   if (j == 0) *errflag = 0;
+}
+
+__global__ void k_targets_gt_init(u64 *best, unsigned *bestj, int64_t n, unsigned *pos_count) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    best[k] = 0ull;
+    bestj[k] = ~0u;
+  }
+  if (k < PP_MAX_BATCH) pos_count[k * kCounterStride] = 0u;
 }
 
 namespace {
@@ -1417,7 +2047,7 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
 
 struct AnchorSource {
   const double *corners = nullptr, *centers = nullptr, *wlh = nullptr, *yaw = nullptr;
-  int grid = 0, fm_w = 0, per_cell = 0;
+  int grid = 0, fm_w = 0, fm_h = 0, per_cell = 0;
   double fm_scale = 1.0;
   const double *types = nullptr;
 };
@@ -1445,7 +2075,8 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
     g_total += g_counts[b];
     bt.g_off[b + 1] = (int)g_total;
   }
-  if (A < 1 || A > 65535ll * kTgtThreads || prm->num_classes < 1 || prm->num_classes > 1024) {  // grid.y = tiles of 256
+  if (A < 1 || A > 65535ll * kTgtThreads || prm->num_classes < 1 || prm->num_classes > 1024 ||
+      A * std::max(prm->num_classes, 9) * 4 > INT_MAX) {  // grid.y = tiles of 256; 32-bit offsets into one sample's rows
     set_error("pp_assign_targets*_dev: bad sizes (A=%lld classes=%d)", (long long)A, prm->num_classes);
     return PP_ERR_VALUE;
   }
@@ -1456,25 +2087,53 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard2 guard(ctx->device);
-  // scratch: [0,8192) error flag + every sample's {counter, ticket} | col_max[Gcap] | col_win[Gcap] |
-  // cand[workgroups * Gcap]; sample b owns the rows [g_off[b], g_off[b+1]) of each (Gcap = all samples' G)
+  // Which form: anchors on the fly -> the box-centric kernel (k_targets_gt); anchor arrays -> k_targets.
+  static const int form_env = [] {  // development knob: PP_TARGETS_FORM=anchors|boxes
+    const char *e = getenv("PP_TARGETS_FORM");
+    return !e ? 0 : (e[0] == 'a' ? 1 : 2);
+  }();
+  const bool boxes_form = an.grid && form_env != 1;
+  // scratch: [0,8192) error flag + every sample's {list counter, ticket, pair counter} | col_max[Gcap] |
+  // col_win[Gcap] | first-level tickets | cand[cand_per_gt * Gcap] | pos[pos_per_gt * Gcap] | best, bestj
+  // [batch * A]; sample b owns the rows [g_off[b], g_off[b+1]) of each (Gcap = all samples' G)
   const size_t gcap = (size_t)std::max<int64_t>(g_total, 1);
   const size_t nwg = (size_t)((A + kTgtThreads - 1) / kTgtThreads);
+  int g_max = 0;
+  for (int b = 0; b < batch; ++b) g_max = std::max<int>(g_max, g_counts[b]);
+  // box-centric: candidate cells per axis <= floor(20 * fm_scale) + 3 (the +-10 gate, one cell generous either side)
+  size_t splits = 1;
+  if (boxes_form) {
+    const double per_axis = std::min(std::floor(20.0 * an.fm_scale) + 3.0, 32768.0);
+    const double cand = per_axis * per_axis * an.per_cell;
+    splits = (size_t)std::min(std::max(std::ceil(cand / kCandPerWg), 1.0), 64.0);
+  }
+  const size_t units = boxes_form ? (size_t)kZeroWgs + (size_t)g_max * splits : nwg;  // workgroups per sample
+  if (units > 65535) {
+    set_error("pp_assign_targets*_dev: %zu workgroups per sample (limit 65535)", units);
+    return PP_ERR_VALUE;
+  }
+  const size_t cand_per_gt = boxes_form ? splits : nwg, pos_per_gt = boxes_form ? splits * kCandPerWg : 0;
   const size_t off_cmax = 8192, off_cwin = off_cmax + gcap * 8;
   // first-level tickets: groups of ~sqrt(workgroups) (a power of two), one 64-byte line per group and sample
   int ticket_shift = 0;
-  while (((size_t)1 << (2 * ticket_shift)) < nwg) ++ticket_shift;
-  const size_t ngrp = ((nwg - 1) >> ticket_shift) + 1;
+  while (((size_t)1 << (2 * ticket_shift)) < units) ++ticket_shift;
+  const size_t ngrp = ((units - 1) >> ticket_shift) + 1;
   const size_t n_ticket1 = (size_t)PP_MAX_BATCH * ngrp * kTicketPad;
   const size_t off_tk1 = (off_cwin + gcap * 8 + 255) / 256 * 256;
   const size_t off_cand = (off_tk1 + n_ticket1 * 4 + 255) / 256 * 256;
-  const size_t need = off_cand + nwg * gcap * sizeof(ColEntry);
+  const size_t off_pos = (off_cand + cand_per_gt * gcap * sizeof(ColEntry) + 255) / 256 * 256;
+  const size_t off_crow = (off_pos + pos_per_gt * gcap * sizeof(PosEntry) + 255) / 256 * 256;
+  const size_t off_best = (off_crow + (boxes_form ? cand_per_gt * gcap * kRowPitch * 4 : 0) + 255) / 256 * 256;
+  const size_t n_best = boxes_form ? (size_t)batch * (size_t)A : 0;
+  const size_t off_bestj = off_best + n_best * 8;
+  const size_t need = off_bestj + n_best * 4;
   static_assert(256 + PP_MAX_BATCH * kCounterStride * 4 <= 8192, "counter block");
   bool grew = false;
   int rc = ctx->iou_ws.ensure(need, &grew);
   if (rc) return rc;
   char *ws = static_cast<char *>(ctx->iou_ws.ptr);
   TargetArgs t;
+  std::memset(&t, 0, sizeof t);
   t.A = A;
   t.G = 0;  // per sample: sample_view
   t.a_corners = an.corners;
@@ -1486,6 +2145,7 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   t.ious = nullptr;
   t.grid = an.grid;
   t.fm_w = an.fm_w;
+  t.fm_h = an.fm_h;
   t.per_cell = an.per_cell;
   t.fm_scale = an.fm_scale;
   {
@@ -1505,23 +2165,40 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   t.errflag = reinterpret_cast<int *>(ws);
   t.cand_count = reinterpret_cast<unsigned *>(ws + 256);
   t.ticket = reinterpret_cast<unsigned *>(ws + 256 + 64);
+  t.pos_count = reinterpret_cast<unsigned *>(ws + 256 + 96);
   t.col_max = reinterpret_cast<u64 *>(ws + off_cmax);
   t.col_win = reinterpret_cast<u64 *>(ws + off_cwin);
   t.cand = reinterpret_cast<ColEntry *>(ws + off_cand);
+  t.cand_per_gt = (unsigned)cand_per_gt;
   t.ticket1 = reinterpret_cast<unsigned *>(ws + off_tk1);
   t.ticket_shift = ticket_shift;
+  t.ticket_groups = (int)ngrp;
+  t.gt_splits = (int)splits;
+  t.pos = reinterpret_cast<PosEntry *>(ws + off_pos);
+  t.pos_per_gt = (unsigned)pos_per_gt;
+  t.cand_rows = boxes_form ? reinterpret_cast<float *>(ws + off_crow) : nullptr;
+  t.best = boxes_form ? reinterpret_cast<u64 *>(ws + off_best) : nullptr;
+  t.bestj = boxes_form ? reinterpret_cast<unsigned *>(ws + off_bestj) : nullptr;
   t.cls_targets = cls_targets;
   t.reg_targets = reg_targets;
   // The scratch words are re-armed by every sample's tail at the end of every call; only a
   // fresh / regrown / re-shaped workspace needs the init.
-  const unsigned long long key = ((unsigned long long)A << 24) ^ (unsigned long long)gcap;
+  const unsigned long long key = ((unsigned long long)A << 24) ^ (unsigned long long)gcap ^
+                                 ((unsigned long long)batch << 56) ^ ((unsigned long long)units << 40) ^
+                                 (boxes_form ? 1ull << 63 : 0ull);
   if (grew || ctx->tgt_key != key) {
     const unsigned gb = (unsigned)((std::max<size_t>(std::max<size_t>(gcap, PP_MAX_BATCH), n_ticket1) + 255) / 256);
     hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_win,
                        (int)gcap, t.errflag, t.cand_count, t.ticket, t.ticket1, (int)n_ticket1);
+    if (boxes_form)
+      hipLaunchKernelGGL(k_targets_gt_init, dim3((unsigned)((std::max<size_t>(n_best, PP_MAX_BATCH) + 255) / 256)),
+                         dim3(256), 0, stream, t.best, t.bestj, (int64_t)n_best, t.pos_count);
     ctx->tgt_key = key;
   }
-  hipLaunchKernelGGL(k_targets<false>, dim3((unsigned)batch, (unsigned)nwg), dim3(kTgtThreads), 0, stream, t, bt);
+  if (boxes_form)
+    hipLaunchKernelGGL(k_targets_gt, dim3((unsigned)batch, (unsigned)units), dim3(kTgtThreads), 0, stream, t, bt);
+  else
+    hipLaunchKernelGGL(k_targets<false>, dim3((unsigned)batch, (unsigned)nwg), dim3(kTgtThreads), 0, stream, t, bt);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) {
     ctx->tgt_key = 0;  // counters in an unknown state: re-arm on the next call
     set_error("k_targets launch failed: %s", hipGetErrorString(e));
@@ -1553,6 +2230,7 @@ static int check_anchor_grid(int fm_height, int fm_width, double fm_scale, int p
   }
   an->grid = 1;
   an->fm_w = fm_width;
+  an->fm_h = fm_height;
   an->per_cell = per_cell;
   an->fm_scale = fm_scale;
   an->types = anchor_types_dev;

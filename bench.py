@@ -605,9 +605,10 @@ def main():
         torch.cuda.synchronize()
         assign1_us = e0.elapsed_time(e1) * 1e3 / (20 * len(tg1))
         t_bytes = 112 * tp.assigner.A * a.batch
-        targets_rec = {"bound": "hbm by its bytes; measured: a chain of latencies (gate, clip rounds of f64, the "
-                                "last-workgroup tail) -- see DESIGN.md",
-                       "kernel": "pp::k_targets<false> (grid = samples x tiles of 256 anchors; one launch per step)",
+        targets_rec = {"bound": "hbm by its bytes; measured: a chain of latencies (box loads, gate, clip rounds of f64, rows, "
+                                "the last-workgroup tail) beside a zero fill -- see DESIGN.md",
+                       "kernel": "pp::k_targets_gt (box-centric: grid = samples x {zero-fill workgroups, workgroups per box}; one "
+                                 "launch per step; anchor ARRAYS go through the anchor-centric pp::k_targets<false>)",
                        "bytes_per_launch": t_bytes, "bytes_what": "112 * A per sample (SURVEY 8d) x the batch",
                        "us_per_call": assign_call_us, "achieved": t_bytes / (assign_call_us * 1e-6) / 1e9,
                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": t_bytes / (assign_call_us * 1e-6) / HBM_PEAK,

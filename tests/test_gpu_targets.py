@@ -465,3 +465,85 @@ def test_feature_map_scale_not_a_power_of_two(gpu, oracle):
             outs.append((cls_t, reg_t))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
         assert (ref_r[:, 0] == 1).sum() > 0
+
+
+# --------------------------------------------------------------------------- the box-centric kernel's own corners
+def _both_forms_and_oracle(gpu, oracle, cfg, H, gts, thresh, classes=9):
+    """anchors on the fly (k_targets_gt: box-centric) and uploaded arrays (k_targets: anchor-centric) on the same
+    batch: bit-equal to each other, and every sample against the oracle"""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    anchors = boxes.make_anchors(cfg)
+    outs = []
+    for src in (cfg, anchors):
+        ta = TargetAssigner(src, canvas_height=H, pos_thresh=thresh, num_classes=classes, device=gpu)
+        for _ in range(2):
+            c, r = ta.assign_batch(gts, check=True)
+        torch.cuda.synchronize()
+        outs.append((c.clone(), r.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "the two forms differ"
+    n_pos = []
+    for b, g in enumerate(gts):
+        if len(g["yaw"]) == 0:
+            assert not outs[0][0][b].any() and not outs[0][1][b].any()
+            continue
+        c_img, k_img = boxes.boxes_to_image_space(g["centers"], g["wlh"], g["yaw"], H)
+        ref_c, ref_r, _ = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                               anchors["yaw"], g["centers"], g["wlh"], g["yaw"], g["classes"], H,
+                                               pos_thresh=thresh, num_classes=classes)
+        _check(outs[0][0][b], outs[0][1][b], ref_c, ref_r)
+        n_pos.append(int((ref_r[:, 0] == 1).sum()))
+    return n_pos
+
+
+@pytest.mark.parametrize("thresh,lo,hi", [(0.45, 257, 900),       # more pairs above the threshold than the one-pass tail takes (566)
+                                          (0.02, 1025, 10 ** 9)])  # ... and than the LDS table holds (7945): per-anchor words
+def test_box_centric_many_positives(gpu, oracle, thresh, lo, hi):
+    from pp_amd import boxes, synth
+    cfg = boxes.AnchorConfig(120, 120)
+    gts = [synth.gt_boxes(40, 240, 31, margin=30.0), synth.gt_boxes(12, 240, 32, margin=30.0)]
+    n_pos = _both_forms_and_oracle(gpu, oracle, cfg, 240, gts, thresh)
+    assert lo <= n_pos[0] <= hi, n_pos                  # the sample really takes the path this case is about
+
+
+def test_box_centric_odd_sizes_misaligned_samples_and_boxes_off_the_map(gpu, oracle):
+    """A = 81 anchors x 3 classes: the second and third sample's rows start off 16 bytes (the zero fill's head / tail
+    paths); more list slots per box than the anchor-centric form has workgroups; boxes whose gate window lies
+    partly or wholly outside the feature map; a sample without boxes in the middle."""
+    from pp_amd import boxes
+    rng = np.random.default_rng(77)
+    cfg = boxes.AnchorConfig(9, 9, 0.5, ((5.0, 9.0, 1.5),), (30.0,), (0.6,))
+    H = 18
+
+    def gt(n, lo, hi):
+        return {"centers": np.column_stack([rng.uniform(lo, hi, n), rng.uniform(lo, hi, n), rng.uniform(0, 1, n)]),
+                "wlh": np.column_stack([rng.uniform(4, 7, n), rng.uniform(7, 11, n), rng.uniform(1, 2, n)]),
+                "yaw": rng.uniform(-np.pi, np.pi, n), "classes": rng.integers(0, 3, n).astype(np.int32)}
+    gts = [gt(5, 2, 16), gt(0, 0, 1), gt(7, -30, 48), gt(3, 1000.0, 2000.0), gt(6, 0, 18)]
+    _both_forms_and_oracle(gpu, oracle, cfg, H, gts, 0.3, classes=3)
+
+
+def test_box_centric_centre_not_finite(gpu, oracle):
+    """A box whose image-space centre is NaN passes the reference's centre gate with EVERY anchor (NaN compares
+    false, pillars.cpp:418-419): the box-centric kernel walks the whole map for it; with finite corners it has real
+    overlaps.  The two kernel forms must agree (the oracle's numpy path is not asked: its argmax meets NaN)."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    cfg = boxes.AnchorConfig(40, 40)
+    anchors = boxes.make_anchors(cfg)
+    g = synth.gt_boxes(6, 80, 5, margin=15.0)
+    outs = []
+    for src in (cfg, anchors):
+        ta = TargetAssigner(src, canvas_height=80, device=gpu)
+        counts, packed = ta.upload_batch([g, g])
+        T = sum(counts)
+        packed[T * 8 + 3 * 2] = float("nan")          # centres_img[2].x of sample 0 (its corners stay finite)
+        c, r = ta.assign_batch_device(counts, packed)
+        torch.cuda.synchronize()
+        outs.append((c.clone(), r.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0][1], TargetAssigner(cfg, canvas_height=80, device=gpu).assign(
+        g["centers"], g["wlh"], g["yaw"], g["classes"])[0])
+    assert (outs[0][1][0][:, 0] == 1).sum().item() > 0
