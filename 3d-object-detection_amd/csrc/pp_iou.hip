@@ -83,6 +83,7 @@ struct TargetArgs {
   int ticket_shift, ticket_groups;  // first-level tickets reserved per sample
   // The box-centric form (k_targets_gt, grid anchors): see there
   int fm_h, gt_splits;       // feature-map rows; workgroups per ground truth
+  int cand_per_wg;           // candidate anchors per PAIR workgroup (<= kCandPerWg)
   unsigned cand_per_gt;      // list entries reserved per ground truth (anchor-centric form: its workgroups)
   struct PosEntry *pos;      // [boxes][pos_per_gt] pairs above the threshold {anchor, box, IoU}
   unsigned pos_per_gt;
@@ -1716,13 +1717,14 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
     u64 col_bits = 0ull;          // wave 0: this workgroup's column maximum for box j ...
     unsigned col_anchor = ~0u;    // ... and the first anchor reaching it
     bool bad = false;
-    for (unsigned q0 = (unsigned)split * kCandPerWg; q0 < ncand; q0 += (unsigned)nsp * kCandPerWg) {
+    const unsigned cpw = (unsigned)t.cand_per_wg;
+    for (unsigned q0 = (unsigned)split * cpw; q0 < ncand; q0 += (unsigned)nsp * cpw) {
       __syncthreads();  // the previous trip's LDS is read
       int wn = 0;
       if (wv == 0) {
         const unsigned q = q0 + (unsigned)lane;
         bool pass = false;
-        if (lane < kCandPerWg && q < ncand) {
+        if ((unsigned)lane < cpw && q < ncand) {
           const unsigned cell = q / (unsigned)t.per_cell, d = q - cell * (unsigned)t.per_cell;
           const unsigned yy = cell / (unsigned)ncx, xx = cell - yy * (unsigned)ncx;
           const unsigned x = (unsigned)x0 + xx, y = (unsigned)y0 + yy;
@@ -2101,18 +2103,30 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   int g_max = 0;
   for (int b = 0; b < batch; ++b) g_max = std::max<int>(g_max, g_counts[b]);
   // box-centric: candidate cells per axis <= floor(20 * fm_scale) + 3 (the +-10 gate, one cell generous either side)
-  size_t splits = 1;
+  // ... kCandPerWg of them per PAIR workgroup, fewer when the launch is small: 32 candidates leave ~22 pairs, ONE
+  // clip round, where 64 leave ~45 and take two -- worth it as long as the workgroups still fit the chip at once
+  // (one sample: 15.1 -> 14.2 us; four samples: 22.6 us with 64 against 25.3 with 32)
+  size_t splits = 1, cand_per_wg = kCandPerWg;
   if (boxes_form) {
     const double per_axis = std::min(std::floor(20.0 * an.fm_scale) + 3.0, 32768.0);
     const double cand = per_axis * per_axis * an.per_cell;
-    splits = (size_t)std::min(std::max(std::ceil(cand / kCandPerWg), 1.0), 64.0);
+    static const int cpw_env = [] {  // development knob: PP_TARGETS_CAND=<candidates per workgroup, 8..64>
+      const char *e = getenv("PP_TARGETS_CAND");
+      return e ? std::min(std::max(atoi(e), 8), kCandPerWg) : 0;
+    }();
+    for (size_t c : {(size_t)32, (size_t)40, (size_t)48, (size_t)64}) {
+      cand_per_wg = c;
+      if ((double)g_total * std::ceil(cand / (double)c) + (double)batch * kZeroWgs <= 900.0) break;
+    }
+    if (cpw_env) cand_per_wg = (size_t)cpw_env;
+    splits = (size_t)std::min(std::max(std::ceil(cand / (double)cand_per_wg), 1.0), 64.0);
   }
   const size_t units = boxes_form ? (size_t)kZeroWgs + (size_t)g_max * splits : nwg;  // workgroups per sample
   if (units > 65535) {
     set_error("pp_assign_targets*_dev: %zu workgroups per sample (limit 65535)", units);
     return PP_ERR_VALUE;
   }
-  const size_t cand_per_gt = boxes_form ? splits : nwg, pos_per_gt = boxes_form ? splits * kCandPerWg : 0;
+  const size_t cand_per_gt = boxes_form ? splits : nwg, pos_per_gt = boxes_form ? splits * cand_per_wg : 0;
   const size_t off_cmax = 8192, off_cwin = off_cmax + gcap * 8;
   // first-level tickets: groups of ~sqrt(workgroups) (a power of two), one 64-byte line per group and sample
   int ticket_shift = 0;
@@ -2174,6 +2188,7 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   t.ticket_shift = ticket_shift;
   t.ticket_groups = (int)ngrp;
   t.gt_splits = (int)splits;
+  t.cand_per_wg = (int)cand_per_wg;
   t.pos = reinterpret_cast<PosEntry *>(ws + off_pos);
   t.pos_per_gt = (unsigned)pos_per_gt;
   t.cand_rows = boxes_form ? reinterpret_cast<float *>(ws + off_crow) : nullptr;

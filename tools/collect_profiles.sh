@@ -58,7 +58,7 @@ for b in 1 4; do
 done
 pmc sq1_c5_b4_three "$SQ1" $V --batch 4 $C5 --iters 50
 pmc sq2_c5_b4_three "$SQ2" $V --batch 4 $C5 --iters 50
-T="python3 $R/tools/bench_targets.py"
+T="python3 $R/tools/bench_targets.py"   # (tools/lab/collect_targets.sh runs this part alone)
 stats targets_c3 $T 250 40 4 2 single          # one sample per launch (rounds 1-3's form)
 stats targets_c3_b4 $T 250 40 4 2 batch         # the batch of a step in one launch
 stats targets_default_b4 $T 300 40 4 6 batch    # the reference's shipped anchor set (540 000 anchors)
