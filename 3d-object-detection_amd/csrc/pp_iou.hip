@@ -1478,7 +1478,7 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
   __syncthreads();
 }
 
-// The box-centric tail in its usual shape -- at most 64 boxes, 512 list slots, 256 pairs above the threshold,
+// The box-centric tail in its usual shape -- at most 64 boxes, 1024 list slots, 256 pairs above the threshold,
 // 63 classes -- as ONE pass: every global load it needs (the pair counter, the pair entries with their rows and
 // classes, the column slots, the boxes' classes) is issued up front and in flight together, the positives' hash
 // and the column argmax share their two LDS phases, and the only dependent round trip left is the forced rows'
@@ -1569,6 +1569,12 @@ __device__ bool tail_gt_fast(const TargetArgs &t, unsigned char *smem, int nslot
 #pragma unroll
   for (int k = 0; k < 2; ++k)
     if (c_bits[k]) atomicMax(&F.colmax[(int)(c_key[k] & 0xFFFFFFFFull)], c_bits[k]);
+  // slots 512..1023 (the reference's six anchors per cell: 19 slots per box) are not kept in registers: loaded
+  // here, and once more in phase 2
+  for (int e = 2 * kTgtThreads + tid; e < nslots; e += kTgtThreads) {
+    const u64 b2 = ld_agent(&t.cand[e].bits);
+    if (b2) atomicMax(&F.colmax[(int)(ld_agent(&t.cand[e].key) & 0xFFFFFFFFull)], b2);
+  }
   __syncthreads();
   // ---- phase 2: first box reaching a row's maximum; first anchor reaching a column's, and its list slot
 #pragma unroll
@@ -1579,6 +1585,11 @@ __device__ bool tail_gt_fast(const TargetArgs &t, unsigned char *smem, int nslot
     const int j = (int)(c_key[k] & 0xFFFFFFFFull);
     if (c_bits[k] && c_bits[k] == F.colmax[j])
       atomicMin(&F.colwin[j], (c_key[k] & 0xFFFFFFFF00000000ull) | (unsigned)(k * kTgtThreads + tid));
+  }
+  for (int e = 2 * kTgtThreads + tid; e < nslots; e += kTgtThreads) {
+    const u64 b2 = ld_agent(&t.cand[e].bits), k2 = ld_agent(&t.cand[e].key);
+    const int j = (int)(k2 & 0xFFFFFFFFull);
+    if (b2 && b2 == F.colmax[j]) atomicMin(&F.colwin[j], (k2 & 0xFFFFFFFF00000000ull) | (unsigned)e);
   }
   __syncthreads();
   // ---- the positives' rows (box_utils.py:211, 219-221), from registers
@@ -1854,7 +1865,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
   __syncthreads();
   IOU_STAMP(9);
   if (!S.is_last) return;
-  if (t.G <= 64 && t.G * nsp <= 2 * kTgtThreads && t.num_classes <= 63 && tail_gt_fast(t, smem, t.G * nsp)) {
+  if (t.G <= 64 && t.G * nsp <= 4 * kTgtThreads && t.num_classes <= 63 && tail_gt_fast(t, smem, t.G * nsp)) {
     IOU_STAMP(10);
     return;
   }
