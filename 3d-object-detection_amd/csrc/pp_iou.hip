@@ -1360,7 +1360,7 @@ static_assert(sizeof(PosLds) <= kTgtLdsBytes, "the positives' stage reuses the w
 
 __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
   PosLds &W = *reinterpret_cast<PosLds *>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x;
   const unsigned n_raw = __hip_atomic_load(t.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned cap = (unsigned)t.G * t.pos_per_gt;
   const unsigned n = min(n_raw, cap);
@@ -1435,8 +1435,6 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
     for (int k = 0; k < kPer; ++k)
       if (slot[k] >= 0) __hip_atomic_store(&t.best[e_i[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    (void)lane;
-    (void)wv;
   } else {
     // more pairs above the threshold than the table holds: the per-anchor words in global memory
     for (unsigned e0 = 0; e0 < n; e0 += kTgtThreads) {
