@@ -61,6 +61,36 @@ __global__ __launch_bounds__(256) void k_pattern(float *out, int P, int N, int d
   }
 }
 
+// k_emit's pattern from a PERSISTENT grid: workgroup w writes the slabs of pillar groups w, w + nwg, ... (a wave = 4
+// pillars x 9 planes per trip): fewer concurrent writers, a narrower write window per plane
+__global__ __launch_bounds__(256) void k_pattern_persistent(float *out, int P, int N, int B) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int groups = (P + 15) / 16;
+  const v4u z = {0, 0, 0, 0};
+  for (int g = blockIdx.x; g < groups * B; g += gridDim.x) {
+    const int b = g / groups, p0 = ((g - b * groups) * 4 + w) * 4;
+    if (p0 >= P) continue;
+    const int n4 = 4 * N / 4;
+    for (int d = 0; d < 9; ++d) {
+      float *dst = out + (((size_t)b * 9 + d) * P + p0) * N;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, n4 * 16, 0x00020000);
+      for (int i = lane; i < n4; i += 64) __builtin_amdgcn_raw_buffer_store_b128(z, rs, i * 16, 0, 0);
+    }
+  }
+}
+// plane-major persistent: the grid walks plane 0 of all pillars, then plane 1, ...: ONE write window
+__global__ __launch_bounds__(256) void k_plane_major(float *out, int P, int N, int B, int chunk_pillars) {
+  const int chunks = (P + chunk_pillars - 1) / chunk_pillars;
+  const long total = (long)B * 9 * chunks;
+  for (long c = blockIdx.x; c < total; c += gridDim.x) {
+    const int ch = (int)(c % chunks), d = (int)((c / chunks) % 9), b = (int)(c / ((long)chunks * 9));
+    const int p0 = ch * chunk_pillars, np = min(chunk_pillars, P - p0);
+    float4 *dst = reinterpret_cast<float4 *>(out + (((size_t)b * 9 + d) * P + p0) * N);
+    const int n4 = np * N / 4;
+    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = make_float4(0, 0, 0, 0);
+  }
+}
+
 int main(int argc, char **argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 4, P = argc > 2 ? atoi(argv[2]) : 30000, N = 100;
   const size_t n = (size_t)B * 9 * P * N;
@@ -122,6 +152,18 @@ int main(int argc, char **argv) {
   run("pattern KW=4 buffer sc0 nt", [&] { hipLaunchKernelGGL(k_pattern_aux<3>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
   run("pattern KW=4 buffer sc1 nt", [&] { hipLaunchKernelGGL(k_pattern_aux<18>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
   run("pattern KW=4 buffer sc0 sc1", [&] { hipLaunchKernelGGL(k_pattern_aux<17>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N); });
+  for (int wg : {256, 512, 1024, 1280, 2048}) {
+    char nm[64];
+    snprintf(nm, sizeof nm, "pattern persistent, %d WGs", wg);
+    run(nm, [&] { hipLaunchKernelGGL(k_pattern_persistent, dim3(wg), dim3(256), 0, 0, out, P, N, B); });
+  }
+  for (int wg : {256, 512, 1024}) {
+    for (int cp : {64, 256, 1024}) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "plane-major %d WGs x %d pillars", wg, cp);
+      run(nm, [&] { hipLaunchKernelGGL(k_plane_major, dim3(wg), dim3(256), 0, 0, out, P, N, B, cp); });
+    }
+  }
   run("hipMemsetAsync", [&] { CK(hipMemsetAsync(out, 0, n * 4, 0)); });
   run("pattern KW=8", [&] { hipLaunchKernelGGL(k_pattern<8>, dim3((P + 31) / 32, B), dim3(256), 0, 0, out, P, N, 0); });
   run("pattern KW=16", [&] { hipLaunchKernelGGL(k_pattern<16>, dim3((P + 63) / 64, B), dim3(256), 0, 0, out, P, N, 0); });
