@@ -464,6 +464,17 @@ __device__ __forceinline__ void tile_body(
   const Rec *kp = kpts + (int64_t)b * ncap;
   const unsigned qmask = (unsigned)TS - 1u;
   // pass 1
+  // A sweep of at most kWin chunks (262 144 points) is ONE window, and the first kP2 rounds of pass 2 then
+  // read the same sources pass 1 has just found: their records are fetched HERE, beside the slot loads, and
+  // ride through the scan in registers -- one dependent memory round trip less per tile (under k_step's
+  // store load every round trip is microseconds).
+  static_assert(kP2 <= kP1, "pass 2's first rounds are a prefix of pass 1's first trip");
+  const bool one_win = nwin == 1;
+  static_assert(kP2 == 3, "rec_e0..2 below (named values handed to run_rounds: captured by reference they stay in scratch)");
+  Rec rec_e0, rec_e1, rec_e2;
+  rec_e0.x = rec_e0.y = rec_e0.z = rec_e0.w = 0;
+  rec_e1 = rec_e0;
+  rec_e2 = rec_e0;
   int ntile = 0;  // positions walked so far = points of the tile
   for (int win = 0; win < nwin; ++win) {
     __syncthreads();  // window arrays free (and cur/hist zeroed)
@@ -486,6 +497,11 @@ __device__ __forceinline__ void tile_body(
       }
 #pragma unroll
       for (int u = 0; u < kP1; ++u) sl[u] = (src[u] >= 0) ? ks[src[u]] : 0;
+      if (one_win && J == 0) {
+        if (src[0] >= 0) rec_e0 = kp[src[0]];
+        if (src[1] >= 0) rec_e1 = kp[src[1]];
+        if (src[2] >= 0) rec_e2 = kp[src[2]];
+      }
 #pragma unroll
       for (int u = 0; u < kP1; ++u) {
         if (src[u] >= 0) {
@@ -574,7 +590,7 @@ __device__ __forceinline__ void tile_body(
   };
   // rounds over a list of `count` positions; fetch(j, q, rec) reads position j.
   // kP2 rounds are fetched ahead of the one being placed.
-  auto run_rounds = [&](int count, auto &&fetch) {
+  auto run_rounds = [&](int count, bool early, const Rec e0, const Rec e1, const Rec e2, auto &&fetch) {
     bool v[kP2];
     unsigned q[kP2];
     Rec rec[kP2];
@@ -584,7 +600,12 @@ __device__ __forceinline__ void tile_body(
       v[d] = j < count;
       q[d] = 0;
       rec[d].x = rec[d].y = rec[d].z = rec[d].w = 0;
-      if (v[d]) fetch(j, q[d], rec[d]);
+      if (early) {  // (uniform) position j's record came in during pass 1
+        if (v[d]) q[d] = L.cq[j];
+        rec[d] = d == 0 ? e0 : d == 1 ? e1 : e2;
+      } else if (v[d]) {
+        fetch(j, q[d], rec[d]);
+      }
     }
     for (int J = 0; J < count; J += kP2 * THREADS) {
 #pragma unroll
@@ -599,7 +620,7 @@ __device__ __forceinline__ void tile_body(
   };
   if (ntile <= kCapT) {
     __syncthreads();  // cursors written
-    run_rounds(ntile, [&](int j, unsigned &q, Rec &rec) {
+    run_rounds(ntile, one_win, rec_e0, rec_e1, rec_e2, [&](int j, unsigned &q, Rec &rec) {
       q = L.cq[j];
       rec = kp[L.csrc[j]];
     });
@@ -612,7 +633,7 @@ __device__ __forceinline__ void tile_body(
         if (lane == 0) s_G = G0;
       }
       __syncthreads();
-      run_rounds(s_G, [&](int j, unsigned &q, Rec &rec) {
+      run_rounds(s_G, false, rec_e0, rec_e1, rec_e2, [&](int j, unsigned &q, Rec &rec) {
         const int src = tile_find(L, j);
         q = (unsigned)ks[src] & qmask;
         rec = kp[src];
@@ -1115,10 +1136,14 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
   //     ORDER role already wrote the descriptors in pillar order -- one load instead of that chain.)
   int4 m = make_int4(-1, 0, 0, 0);
   if constexpr (ORDERED) {
+    // the sweep's totals and the descriptors are loaded side by side (a descriptor beyond the pillar count is
+    // whatever an earlier batch left there -- readable, and dropped below): one round trip, not two
     const int2 tt = a.ordered_totals[b];
+    int4 mo = m;
+    if (lane < KW && p0 + lane < P) mo = a.ordered_meta[(int64_t)b * P + p0 + lane];
     if (bx == 0 && w == 0 && lane == 0) a.totals[b] = tt;
     const int npil_o = min(tt.x, P);
-    if (lane < KW && p0 + lane < npil_o) m = a.ordered_meta[(int64_t)b * P + p0 + lane];
+    if (lane < KW && p0 + lane < npil_o) m = mo;
   } else {
   const int ntiles = a.g.ntiles;
   const int nv = (ntiles + kWave - 1) / kWave;  // tiles per lane, <= 64
@@ -1576,6 +1601,7 @@ struct StepArgs {
   SplitRole s;
   EmitArgs e;
 };
+constexpr int kStepChipSlots = 5 * 256;  // k_step workgroups the chip holds at once (LDS and VGPRs: 5 per CU)
 constexpr int kStepWaves = 4;
 constexpr int kStepThreads = kStepWaves * kWave;
 static_assert(kStepWaves == kEmitWaves, "the emit role is k_emit's workgroup");
@@ -1629,9 +1655,10 @@ __global__ __launch_bounds__(kStepThreads, step_minwaves(MODE)) void k_step(Step
   }
   // Block order.  Workgroups are dispatched in id order.  The binning roles' (tile, order, split) are few and
   // latency-bound, the emit role's many and store-bound; a binning chain that starts late is the launch's
-  // tail.  mix_groups = 0 (the default, host side): all binning blocks first, then the emit blocks.
-  // mix_groups > 0 (PP_STEP_MIX = m >= 2): the grid starts with groups of one binning block and m-1 emit
-  // blocks, so that the stores also flow from the first microsecond; what is left of either kind follows.
+  // tail.  mix_groups = 0 (host side: the binning blocks fit the chip at once): all binning blocks first,
+  // then the emit blocks.  mix_groups > 0 (more binning blocks than that, or PP_STEP_MIX = m >= 2): the grid
+  // starts with groups of one binning block and m-1 emit blocks, so that the stores also flow from the first
+  // microsecond; what is left of either kind follows.
   {
     const int nbin = a.n_tile_blocks + a.n_order_blocks + a.n_split_blocks;
     const int head = a.mix_groups * a.mix;
@@ -2431,7 +2458,11 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
     a.emit_b0 = eb;
 #ifdef PP_STEP_SKIP_KNOB  // tools/lab timing builds only (results are garbage): PP_STEP_SKIP = bit mask of roles left out
     {
-      static const int skip = [] { const char *e = getenv("PP_STEP_SKIP"); return e ? atoi(e) : 0; }();
+      static const int skip_all = [] { const char *e = getenv("PP_STEP_SKIP"); return e ? atoi(e) : 0; }();
+      // PP_STEP_SKIP_AFTER=n: the first n launches run every role (the slots then hold real lists of the SAME cloud)
+      static const int skip_after = [] { const char *e = getenv("PP_STEP_SKIP_AFTER"); return e ? atoi(e) : 0; }();
+      static int launches = 0;
+      const int skip = ++launches > skip_after ? skip_all : 0;
       if (skip & 1) a.n_tile_blocks = 0;
       if (skip & 2) a.n_order_blocks = 0;
       if (skip & 4) a.n_split_blocks = 0;
@@ -2453,26 +2484,36 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
         ++r;
       };
       std::memset(&a.pf, 0, sizeof a.pf);
-      if (pref_blocks > 0 && en > 0) {   // what the emit role reads
+      // Only the EMIT role's arrays are worth it (tools/lab/prefetch_sets.sh, round 4): its blocks start after the
+      // binning blocks, so the lines are there when they ask.  The binning roles' own inputs (the order role's
+      // lists, the tile role's split arrays, the split role's points) were in this list while binning and emit
+      // blocks alternated; with the binning blocks FIRST they start in the same microsecond as the prefetch
+      // blocks and fetch for themselves -- the prefetch only doubled that traffic (headline 34.9 -> 33.7 us
+      // without, C5 B=4 111-118 -> 104-109 us).
+      static const int pref_sets = [] {  // development knob: PP_STEP_PREFETCH_SETS = mask {1 emit, 2 order, 4 tile} arrays
+        const char *e = getenv("PP_STEP_PREFETCH_SETS");
+        return e ? atoi(e) : 1;
+      }();
+      if (pref_blocks > 0 && en > 0 && (pref_sets & 1)) {   // what the emit role reads
         add(a.e.ordered_meta, (size_t)a.e.P * 16, eb, en);
         add(a.e.sorted_pts, (size_t)a.e.ncap * 16, eb, en);
       }
-      if (pref_blocks > 0 && on > 0) {  // ... the order role: the occupied heads of the tiles' lists
+      if (pref_blocks > 0 && on > 0 && (pref_sets & 2)) {  // ... the order role: the occupied heads of the tiles' lists
         a.pf.tile_agg = a.o.tile_agg + (size_t)ob * nt_o;
         a.pf.tile_meta = a.o.tile_meta + ((size_t)ob * nt_o << a.o.g.tile_shift);
         a.pf.nlists = on * nt_o;
         a.pf.list_stride = 1 << a.o.g.tile_shift;
       }
-      if (pref_blocks > 0 && tn > 0) {   // what the tile role reads
+      if (pref_blocks > 0 && tn > 0 && (pref_sets & 4)) {   // what the tile role reads
         add(a.t.mat, (size_t)nt_t * a.t.nchunks_cap * 8, tb, tn);
         add(a.t.kslot, (size_t)a.t.ncap * 4, tb, tn);
         add(a.t.kpts, (size_t)a.t.ncap * 16, tb, tn);
       }
       static const int pref_points = [] {  // development knob: PP_STEP_PREFETCH_POINTS=0/1
         const char *e = getenv("PP_STEP_PREFETCH_POINTS");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 0;
       }();
-      if (pref_blocks > 0 && sn > 0 && pref_points)   // ... and the split role: the caller's points, cold after a network pass
+      if (pref_blocks > 0 && sn > 0 && pref_points)   // ... and the split role: the caller's points
         add(a.s.pts, (size_t)a.s.sweep_stride * 16, sb, sn);
       a.n_pref_blocks = r > 0 || a.pf.nlists > 0 ? pref_blocks : 0;
     }
@@ -2485,7 +2526,11 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
       // activations between two launches) the binning roles' chains run on cold lines and are the launch's
       // tail unless they start first: 39 -> 35 us in bench.py's end-to-end loop; in a voxelizer-only loop, where
       // their inputs are still cached, the 1:1 interleave (mix 2) was 2 us better (42.4 vs 40.6 us, round 4).
-      a.mix = mix_env ? mix_env : 1;
+      // More binning blocks than the chip holds at once (5 workgroups per CU): "first" would mean rounds of
+      // binning with no store in flight -- they are spread evenly over the launch instead, one per
+      // n_emit / nbin emit blocks (C5 B=4, 3 400 binning blocks: 117-121 -> 104-109 us; 1:1 and 1:3 are both worse).
+      const int mix_auto = nbin > kStepChipSlots && n_emit > 0 ? std::max(2, n_emit / nbin + 1) : 1;
+      a.mix = mix_env ? mix_env : mix_auto;
       a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit / (a.mix - 1)) : 0;
       if (a.mix < 2) a.mix = 2, a.mix_groups = 0;
     }
