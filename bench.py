@@ -267,6 +267,50 @@ def static_traffic(key):
         return None, None
 
 
+def live_traffic(batch, kernel, timeout_s=180):
+    """HBM bytes per launch of the headline's k_step measured IN THIS RUN: two child runs of this script's
+    headline loop under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes with --kernel-trace only,
+    from /tmp, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- median over the launches of `kernel`,
+    KiB * 1024 (k_step's reads are narrow gathers and short rows: the guide's x2 correction for wide streaming
+    reads is not applied; the same processing as tools/pmc_summary.py + tools/make_emit_traffic.py).  Children
+    are fresh processes (`-- python3 bench.py ...`, never an exec of this one).  None when rocprofv3 is missing,
+    fails or times out: the caller then falls back to the committed constant and says so."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None                                   # no profiler here, or this run is itself being profiled
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="pp_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "t", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--headline-only", "--steps", "8", "--warmup", "4",
+                   "--batch", str(batch)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name") or row.get("Kernel-Name") or ""
+                    if kernel.replace("pp::", "") in name and row.get("Counter_Name") == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 4:
+                return None
+            got[ctr] = (statistics.median(vals) * 1024.0, len(vals))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]
+    return total, {"FETCH_SIZE_bytes": got["FETCH_SIZE"][0], "WRITE_SIZE_bytes": got["WRITE_SIZE"][0],
+                   "launches": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
+
+
 def self_launch(n_ranks):
     """Start `n_ranks` rank processes of this script (one per GPU) under torch.distributed.run and
     wait for them.  Called before anything in this process has touched the GPU."""
@@ -301,6 +345,9 @@ def main():
                     help="only the timed headline loop (no side legs): under rocprofv3 the kernel-stats average of "
                          "k_step then covers exactly the launches `roofline` is computed from")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed constant (profiles/emit_traffic.json) instead of two "
+                         "rocprofv3 --pmc child runs of the headline loop")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-feature-net side measurement")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the train_c3 sub-record")
     ap.add_argument("--no-stress", action="store_true", help="skip the stress_c5 sub-record")
@@ -749,6 +796,10 @@ def main():
     if ctx.rank == 0:
         total_sweeps = a.steps * a.batch * ctx.world_size
         traffic, tsrc = static_traffic(f"step_batch{a.batch}" if pipelined else f"batch{a.batch}")
+        traffic_live = None
+        if pipelined and ctx.world_size == 1 and a.mode == "fwd" and not a.headline_only and not a.no_live_traffic:
+            torch.cuda.synchronize()
+            traffic_live = live_traffic(a.batch, pipe.voxelizer.step_kernel_name(a.batch))
         out = {
             "metric": METRIC, "value": total_sweeps / elapsed, "unit": "sweeps/s",
             "n_gpus": ctx.world_size, "steps": a.steps, "warmup": a.warmup,
@@ -776,6 +827,14 @@ def main():
             "three_launch_value": three_e2e["sweeps_per_s"] if three_e2e else None,
             "distinct_resident_batches": len(point_sets) if a.mode == "fwd" else 1,
         }
+        if traffic_live is not None:
+            out["roofline"]["traffic_static"] = traffic
+            out["roofline"]["traffic"] = traffic_live[0]
+            out["roofline"]["traffic_detail"] = traffic_live[1]
+            out["roofline"]["traffic_source"] = (
+                "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child runs of "
+                "`bench.py --headline-only`, --kernel-trace only), median per launch of the headline's k_step "
+                "instance, KiB * 1024; `traffic_static` = the committed constant of profiles/emit_traffic.json")
         if overlap is not None:
             out["overlapped"] = overlap
         if vox_rec is not None:

@@ -77,6 +77,15 @@ def test_bench_contract_line(gpu):
     # voxelizer's; the three-launch path is measured beside it
     assert rf["kernel"].startswith("pp::k_step") and rf["pipeline_frac"] == rf["frac"]
     assert set(rf["three_launch"]["kernels_us"]) == {"k_split", "k_tile", "k_emit"}
+    # roofline.traffic: measured in the run itself (two rocprofv3 --pmc child runs of the headline loop) where the
+    # profiler is available; the committed constant otherwise, and labelled so
+    if "traffic_detail" in rf:
+        assert rf["traffic_source"].startswith("measured in this run")
+        assert rf["bytes_per_launch"] * 0.95 < rf["traffic"] < rf["bytes_per_launch"] * 1.35
+        assert abs(rf["traffic"] - rf["traffic_static"]) < 0.08 * rf["traffic_static"]
+        assert min(rf["traffic_detail"]["launches"]) >= 4
+    else:
+        assert rf["traffic"] is None or rf["traffic_source"].startswith("static")
     assert 0 < rf["three_launch"]["pipeline_frac"] < rf["three_launch"]["k_emit_frac"] < 1
     vo = j["voxelizer_only"]
     for rec in (vo, vo["row_major_order"], vo["one_sweep_per_launch"], vo["c1_shapes"]):
