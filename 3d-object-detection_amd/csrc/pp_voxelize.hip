@@ -1532,11 +1532,13 @@ struct TileRole {
   int4 *tile_meta;
   u64 *tile_agg;
 };
-// What the prefetch role streams through (k_step): the arrays the tile and emit roles read were written by the
+// What the prefetch role streams through (k_step): the arrays the emit role reads were written by the
 // PREVIOUS launch; when other work ran in between (the network's activations: a GiB per step) they are in HBM
-// again, and both roles are chains of dependent loads -- every hop would pay an HBM miss under a full store
+// again, and the role is a chain of dependent loads -- every hop would pay an HBM miss under a full store
 // load.  A few workgroups at the head of the grid read those arrays once, front to back, with many loads in
-// flight: the lines land in the memory-side Infinity Cache before most of the chains ask for them.
+// flight: the lines land in the memory-side Infinity Cache before most of the chains ask for them.  (The list
+// can also hold the binning roles' inputs -- PP_STEP_PREFETCH_SETS -- which paid while binning and emit blocks
+// alternated; with the binning blocks first they fetch for themselves at the same moment: see step_impl.)
 struct PrefetchRole {
   const void *ptr[7];
   unsigned n16[7];       // 16-byte units
