@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void k_plane_major(float *out, int P, int N, i
 }
 
 int main(int argc, char **argv) {
-  const int B = argc > 1 ? atoi(argv[1]) : 4, P = argc > 2 ? atoi(argv[2]) : 30000, N = 100;
+  const int B = argc > 1 ? atoi(argv[1]) : 4, P = argc > 2 ? atoi(argv[2]) : 30000, N = argc > 4 ? atoi(argv[4]) : 100;
+  const bool brief = argc > 5 && atoi(argv[5]);  // only the linear fill and k_emit's pattern
   const size_t n = (size_t)B * 9 * P * N;
   float *out;
   CK(hipMalloc(&out, n * 4));
@@ -132,6 +133,16 @@ int main(int argc, char **argv) {
     printf("%-28s %7.2f us  %.2f TB/s\n", name, ms * 10, n * 4 / (ms * 1e-5) / 1e12);
   };
   run("linear, 256 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(256), dim3(256), 0, 0, (float4 *)out, n / 4); });
+  if (brief) {
+    run("linear, 1024 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(1024), dim3(256), 0, 0, (float4 *)out, n / 4); });
+    run("pattern KW=4", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 0); });
+    run("pattern KW=4 + 1 load", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 1); });
+    run("pattern KW=4 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 2); });
+    run("pattern KW=4 + 3 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 3); });
+    run("pattern KW=8", [&] { hipLaunchKernelGGL(k_pattern<8>, dim3((P + 31) / 32, B), dim3(256), 0, 0, out, P, N, 0); });
+    run("pattern KW=8 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<8>, dim3((P + 31) / 32, B), dim3(256), 0, 0, out, P, N, 2); });
+    return 0;
+  }
   run("linear, 512 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(512), dim3(256), 0, 0, (float4 *)out, n / 4); });
   run("linear, 1024 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(1024), dim3(256), 0, 0, (float4 *)out, n / 4); });
   run("linear, 2048 WGs", [&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, (float4 *)out, n / 4); });
