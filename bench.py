@@ -53,6 +53,7 @@ from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig  # noqa: E402
 
 METRIC = "lidar sweeps/sec end-to-end fwd (pillarize+backbone), 60k pts, 500×500 BEV"
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md:36
+HBM_COPY_MEASURED = 6.29e12  # B/s, the same line: "6.29 TB/s measured (float4 copy, 79%)"
 N_POINTS, HALF, STEP, P, N = 60000, 50.0, 0.2, 12000, 100
 C5 = dict(n=200000, half=100.0, step=0.2, P=30000, N=100)   # BASELINE configs[4] shapes
 C1 = dict(n=60000, half=50.0, step=1.0, P=12000, N=100)     # BASELINE configs[0]: 100x100 grid
@@ -179,6 +180,9 @@ def roofline_record(kern_us, launches, bytes_per_launch, traffic=None, traffic_s
     achieved = bytes_per_launch / (dur_us * 1e-6) / 1e9
     rec = {"bound": "hbm", "kernel": name, "achieved": achieved,
            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+           # SURVEY 8(d) asks for both: the 8.0 TB/s specification (`peak`, `frac`) and the guide's measured
+           # float4-copy rate (MI355X_MICROARCH.md: 6.29 TB/s, 79 % of the specification)
+           "peak_measured_copy": HBM_COPY_MEASURED / 1e9, "frac_of_measured_copy": achieved * 1e9 / HBM_COPY_MEASURED,
            "traffic": traffic, "traffic_source": traffic_source,
            "bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_us, "launches_timed": launches}
     if "k_step" in kern_us:
