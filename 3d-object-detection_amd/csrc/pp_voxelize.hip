@@ -2530,7 +2530,8 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
       // their inputs are still cached, the 1:1 interleave (mix 2) was 2 us better (42.4 vs 40.6 us, round 4).
       // More binning blocks than the chip holds at once (5 workgroups per CU): "first" would mean rounds of
       // binning with no store in flight -- they are spread evenly over the launch instead, one per
-      // n_emit / nbin emit blocks (C5 B=4, 3 400 binning blocks: 117-121 -> 104-109 us; 1:1 and 1:3 are both worse).
+      // n_emit / nbin emit blocks (C5 B=4, 3 400 binning blocks against 7 500: one per two, 117-121 -> 104-109 us;
+      // one per one and one per three are both worse).
       const int mix_auto = nbin > kStepChipSlots && n_emit > 0 ? std::max(2, n_emit / nbin + 1) : 1;
       a.mix = mix_env ? mix_env : mix_auto;
       a.mix_groups = a.mix > 1 ? std::min(nbin, n_emit / (a.mix - 1)) : 0;
