@@ -271,7 +271,7 @@ def static_traffic(key):
         return None, None
 
 
-def live_traffic(batch, kernel, timeout_s=180):
+def live_traffic(batch, kernel, timeout_s=90):
     """HBM bytes per launch of the headline's k_step measured IN THIS RUN: two child runs of this script's
     headline loop under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes with --kernel-trace only,
     from /tmp, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- median over the launches of `kernel`,
