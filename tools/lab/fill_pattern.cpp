@@ -91,6 +91,57 @@ __global__ __launch_bounds__(256) void k_plane_major(float *out, int P, int N, i
   }
 }
 
+
+// TWO ROLES in one launch: `zwg` workgroups stream zeros linearly over the whole output, skipping every 128-byte
+// line that holds a pillar's head group (nh 16-byte groups at the start of each pillar's row); the other workgroups
+// are k_emit-shaped (a wave = 4 pillars) and write only those live lines, whole, behind `delay` dependent loads.
+// Every line is written exactly once.  Is "a linear fill + a sparse live pass" faster than k_emit's dense pattern?
+__global__ __launch_bounds__(256) void k_two_roles(float *out, int P, int N, int B, int zwg, int nh, int delay) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const v4u z = {0, 0, 0, 0};
+  const unsigned n4row = (unsigned)N / 4u;                 // 16-byte groups per pillar row
+  const size_t gplane = (size_t)P * n4row;                 // groups per plane (a multiple of 8: planes are line-aligned)
+  if ((int)blockIdx.x < zwg) {
+    // 32-bit arithmetic only: plane by plane, the grid striding over the plane's groups
+    const unsigned gp = (unsigned)gplane, magic = 0xFFFFFFFFu / n4row + 1u;
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    for (int pl = 0; pl < B * 9; ++pl) {
+      float4 *op = o4 + (size_t)pl * gplane;
+      for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < gp; g += (unsigned)zwg * 256u) {
+        const unsigned p = __umulhi(g, magic), n4 = g - p * n4row;
+        const bool head = n4 < (unsigned)nh;               // (a real kernel reads the pillar's count here)
+        const unsigned long long m = __ballot(head);
+        const bool live_line = ((m >> (lane & ~7)) & 0xFFull) != 0;   // 8 consecutive lanes = one line
+        if (!live_line) op[g] = make_float4(0, 0, 0, 0);
+      }
+    }
+    return;
+  }
+  if (delay < 0) return;  // zero role alone
+  const int id = (int)blockIdx.x - zwg, groups = (P + 15) / 16;
+  const int b = id / groups, p0 = ((id - b * groups) * 4 + w) * 4;
+  if (p0 >= P || b >= B) return;
+  if (delay) {
+    volatile float *q = out;
+    float s = 0;
+    for (int k = 0; k < delay; ++k) s += q[(size_t)(lane + k * 64 + (int)s) & 1023];
+    if (s == 12345.f) out[0] = s;
+  }
+  // the live lines of the wave's 4 pillars in the 9 planes: lines that hold groups [p*n4row, p*n4row + nh)
+  for (int t = lane; t < 9 * 4 * 8 * 2; t += 64) {         // (plane, pillar, up to 2 lines, 8 groups per line)
+    const int gi = t & 7, li = (t >> 3) & 1, k = (t >> 4) & 3, d = t >> 6;
+    const int p = p0 + k;
+    if (p >= P) continue;
+    const size_t g0 = (size_t)p * n4row, l0 = g0 >> 3, l1 = (g0 + nh - 1) >> 3;
+    const size_t line = l0 + li;
+    if (line > l1) continue;
+    // a line shared with the previous pillar's head is written by that pillar's lanes as well: identical zeros
+    float4 *o4 = reinterpret_cast<float4 *>(out) + ((size_t)b * 9 + d) * gplane;
+    o4[line * 8 + gi] = make_float4(0, 0, 0, 0);
+  }
+  (void)z;
+}
+
 int main(int argc, char **argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 4, P = argc > 2 ? atoi(argv[2]) : 30000, N = argc > 4 ? atoi(argv[4]) : 100;
   const bool brief = argc > 5 && atoi(argv[5]);  // only the linear fill and k_emit's pattern
@@ -139,6 +190,15 @@ int main(int argc, char **argv) {
     run("pattern KW=4 + 1 load", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 1); });
     run("pattern KW=4 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 2); });
     run("pattern KW=4 + 3 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 3); });
+    run("zero role alone, 256 WGs", [&] { hipLaunchKernelGGL(k_two_roles, dim3(256), dim3(256), 0, 0, out, P, N, B, 256, 1, -1); });
+    run("zero role alone, 512 WGs", [&] { hipLaunchKernelGGL(k_two_roles, dim3(512), dim3(256), 0, 0, out, P, N, B, 512, 1, -1); });
+    run("live role alone", [&] { hipLaunchKernelGGL(k_two_roles, dim3((P + 15) / 16 * B), dim3(256), 0, 0, out, P, N, B, 0, 1, 2); });
+    for (int zwg : {192, 256, 320, 384, 512})
+      for (int nh : {1}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "two roles: %d zero WGs, nh=%d", zwg, nh);
+        run(nm, [&] { hipLaunchKernelGGL(k_two_roles, dim3(zwg + (P + 15) / 16 * B), dim3(256), 0, 0, out, P, N, B, zwg, nh, 2); });
+      }
     run("pattern KW=8", [&] { hipLaunchKernelGGL(k_pattern<8>, dim3((P + 31) / 32, B), dim3(256), 0, 0, out, P, N, 0); });
     run("pattern KW=8 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<8>, dim3((P + 31) / 32, B), dim3(256), 0, 0, out, P, N, 2); });
     return 0;
