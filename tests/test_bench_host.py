@@ -1,0 +1,41 @@
+"""bench.py's host-side helpers that need no GPU: the roofline record and the fall-backs of the live PMC traffic
+measurement (the measurement itself runs in tests/test_gpu_pipeline.py::test_bench_contract_line)."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("pp_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_live_traffic_declines_under_a_profiler_and_without_one(monkeypatch):
+    b = _bench()
+    # a run that is itself being profiled does not start profilers of its own
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert b.live_traffic(4, "pp::k_step<0, 0>") is None
+    monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
+    # no rocprofv3 on the PATH: None (the caller then reports the committed constant, labelled static)
+    monkeypatch.setenv("PATH", "/nonexistent")
+    assert b.live_traffic(4, "pp::k_step<0, 0>") is None
+
+
+def test_roofline_record_reports_both_peaks():
+    b = _bench()
+    rec = b.roofline_record({"k_step": 40.0}, 50, 177_792_000, traffic=2.0e8, traffic_source="static: x")
+    assert rec["bound"] == "hbm" and rec["kernel"].startswith("pp::k_step")
+    assert abs(rec["achieved"] - 177_792_000 / 40e-6 / 1e9) < 1e-6
+    assert abs(rec["frac"] - rec["achieved"] / 8000.0) < 1e-12
+    assert abs(rec["frac_of_measured_copy"] - rec["achieved"] / 6290.0) < 1e-12
+    assert rec["pipeline_frac"] == rec["frac"] and rec["traffic"] == 2.0e8
+    three = b.roofline_record({"k_split": 9.0, "k_tile": 9.0, "k_emit": 30.0}, 50, 177_792_000)
+    assert three["kernel"].startswith("pp::k_emit") and three["pipeline"]["sum_us"] == 48.0
+    assert three["pipeline_frac"] < three["frac"] < 1
+    s_key, src = b.static_traffic("step_batch4")
+    assert s_key and 1.0 < s_key / 177_792_000 < 1.35 and src.startswith("static")
