@@ -2103,7 +2103,7 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
     const char *e = getenv("PP_TARGETS_FORM");
     return !e ? 0 : (e[0] == 'a' ? 1 : 2);
   }();
-  const bool boxes_form = an.grid && form_env != 1;
+  bool boxes_form = an.grid && form_env != 1;
   // scratch: [0,8192) error flag + every sample's {list counter, ticket, pair counter} | col_max[Gcap] |
   // col_win[Gcap] | first-level tickets | cand[cand_per_gt * Gcap] | pos[pos_per_gt * Gcap] | best, bestj
   // [batch * A]; sample b owns the rows [g_off[b], g_off[b+1]) of each (Gcap = all samples' G)
@@ -2129,6 +2129,14 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
     }
     if (cpw_env) cand_per_wg = (size_t)cpw_env;
     splits = (size_t)std::min(std::max(std::ceil(cand / (double)cand_per_wg), 1.0), 64.0);
+    // grid.y holds the zero-fill workgroups and every box's PAIR workgroups: a sample with more boxes than that
+    // (eleven thousand at C3's six workgroups per box) goes through the anchor-centric kernel, which walks any
+    // number of boxes in chunks
+    if ((size_t)kZeroWgs + (size_t)g_max * splits > 65535) {
+      boxes_form = false;
+      splits = 1;
+      cand_per_wg = kCandPerWg;
+    }
   }
   const size_t units = boxes_form ? (size_t)kZeroWgs + (size_t)g_max * splits : nwg;  // workgroups per sample
   if (units > 65535) {

@@ -320,6 +320,9 @@ int pp_make_ious_dev(pp_ctx_t *ctx, void *stream, const double *a_corners_dev,
  * Outputs f32 (data/dataset.py:117-118 casts to float):
  *   cls_targets [A,num_classes], reg_targets [A,9]
  * Limits (PP_ERR_VALUE beyond): 1 <= A <= 16 776 960 anchors, 0 <= G <= 65535, 1..1024 classes.
+ * (Anchors on the fly are assigned from the box side while a sample's boxes x workgroups per box fit one grid
+ * dimension -- about eleven thousand boxes at BASELINE configs[2] -- and from the anchor side beyond; the results are
+ * the same either way.)
  */
 typedef struct pp_target_params {
   double pos_thresh;    /* cfg.DATA.IOU_POS_THRESH, config.py:122 */

@@ -547,3 +547,30 @@ def test_box_centric_centre_not_finite(gpu, oracle):
     assert torch.equal(outs[0][0][1], TargetAssigner(cfg, canvas_height=80, device=gpu).assign(
         g["centers"], g["wlh"], g["yaw"], g["classes"])[0])
     assert (outs[0][1][0][:, 0] == 1).sum().item() > 0
+
+
+def test_box_centric_falls_back_beyond_its_grid_limit(gpu, oracle):
+    """Anchors on the fly with more boxes than the box-centric launch can hold in one grid dimension (64 zero-fill
+    workgroups + boxes x workgroups per box <= 65535: about eleven thousand boxes at six per box) go through the
+    anchor-centric kernel instead of being refused; same results, next to an ordinary sample in the same batch."""
+    import torch
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    rng = np.random.default_rng(77)
+    cfg = boxes.AnchorConfig(40, 40)
+    anchors = boxes.make_anchors(cfg)
+    H = 80
+    gts = [_crowded_gt(rng, 11500, H, 64, np.array([36.0, 48.0])), _crowded_gt(rng, 25, H, 8, np.array([30.0, 40.0]))]
+    ta = TargetAssigner(cfg, canvas_height=H, pos_thresh=0.45, device=gpu)
+    for _ in range(2):
+        cls_b, reg_b = ta.assign_batch(gts, check=True)
+    torch.cuda.synchronize()
+    for b, g in enumerate(gts):
+        c_img, k_img = boxes.boxes_to_image_space(g["centers"], g["wlh"], g["yaw"], H)
+        ref_c, ref_r, _ = oracle.create_target(anchors["corners"], k_img, anchors["centers"], c_img, anchors["wlh"],
+                                               anchors["yaw"], g["centers"], g["wlh"], g["yaw"], g["classes"], H,
+                                               pos_thresh=0.45)
+        _check(cls_b[b], reg_b[b], ref_c, ref_r)
+    # ... and the small sample alone afterwards (box-centric again: the scratch is re-armed for the other form)
+    cls_1, reg_1 = ta.assign_batch(gts[1:], check=True)
+    assert torch.equal(cls_1[0], cls_b[1]) and torch.equal(reg_1[0], reg_b[1])
