@@ -81,6 +81,45 @@ def test_random_configuration(gpu, oracle, case):
     assert torch.equal(canvas, sc(feats, idx))
 
 
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_configuration_pipelined(gpu, oracle, case):
+    """The same kind of draws through the software-pipelined form (k_step: ordered descriptors loaded beside the
+    totals, the tile role's records fetched in pass 1, block order by launch size): a sequence of ragged batches
+    whose shapes change from call to call, every result bit-equal to the plain call's and the first sweep of the
+    first batch to the oracle."""
+    import torch
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    rng = np.random.default_rng(5000 + case)
+    half = float(rng.choice([4.0, 6.4, 10.0, 25.0]))
+    step = float(rng.choice([0.2, 0.4, 0.5]))
+    N = int(rng.choice([4, 6, 8, 12, 20, 32, 100, 260]))
+    order = int(rng.integers(0, 2))
+    nmax = int(rng.integers(800, 20000))
+    first = _cloud(rng, nmax, half, int(rng.integers(0, 12)))
+    cc = oracle.cell_counts(first.astype(np.float64), *grid_args(half, step))
+    P = int(max(1, len(cc) * rng.choice([0.3, 0.9, 1.0, 1.5]) + rng.integers(0, 5)))   # P % 4 != 0 in most draws
+    cfg = VoxelConfig.square(half, step, P, N, order=order)
+    plain, piped = PillarVoxelizer(cfg, device=gpu), PillarVoxelizer(cfg, device=gpu)
+    seq = []
+    for i in range(int(rng.integers(3, 7))):
+        B = int(rng.choice([1, 2, 5]))
+        clouds = np.stack([first if (i == 0 and b == 0) else _cloud(rng, nmax, half, int(rng.integers(0, 12)))
+                           for b in range(B)])
+        ns = [nmax if (i == 0 and b == 0) else int(rng.integers(0, nmax + 1)) for b in range(B)]
+        seq.append((torch.from_numpy(clouds).to(gpu), ns))
+    want = [tuple(x.clone() for x in plain(t, n_points=ns, return_counts=True)) for t, ns in seq]
+    got = [piped.submit(t, n_points=ns, return_counts=True) for t, ns in seq]
+    got += [piped.submit(None, return_counts=True) for _ in range(piped.LAG)]
+    got = [g for g in got if g is not None]
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for w_, g_ in zip(want, got):
+        assert all(torch.equal(x, y) for x, y in zip(w_, g_)), (half, step, P, N, order)
+    ref_p, ref_i, m = oracle.dataset_voxel_stage(first.astype(np.float64), P, N, *grid_args(half, step), order=order)
+    assert np.array_equal(got[0][0][0].cpu().numpy(), ref_p) and np.array_equal(got[0][1][0].cpu().numpy(), ref_i)
+    assert int(got[0][2][0, 0]) == m
+
+
 @pytest.mark.parametrize("case", list(range(10)))
 def test_random_target_assignment(gpu, oracle, case):
     """Random anchor grids (1-3 anchor types per cell, random sizes / yaws) and ground-truth sets
