@@ -498,3 +498,32 @@ def test_pipelined_fused_full_size_and_pipeline(gpu):
     assert len(outs) == len(clouds)
     for (c, r), (wc, wr) in zip(outs, want):
         assert (c - wc).abs().max().item() <= 2e-6 and (r - wr).abs().max().item() <= 2e-6
+
+
+def test_pipelined_fused_and_dense_with_more_binning_blocks_than_the_chip_holds(gpu):
+    """Twelve sweeps on a 500x500 grid: 12 x (123 tiles + chunks) + order blocks > the 1 280 workgroups the chip holds,
+    so k_step spreads the binning blocks between the emit blocks instead of dispatching them first -- the fused form
+    (with its clear role in front) and the dense form, both bit-identical to the three-launch calls."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    cfg = VoxelConfig.square(50.0, 0.2, 1500, 8)
+    H = W = cfg.canvas_height
+    tab = _net(gpu).fused_params()
+    a, b, c = (PillarVoxelizer(cfg, device=gpu) for _ in range(3))
+    ts = [torch.from_numpy(np.stack([synth.lidar_like(3000, 50.0, 100 * i + s) for s in range(12)])).to(gpu)
+          for i in range(3)]
+    got_f, got_d = [], []
+    for t in ts + [None] * b.LAG:
+        r = b.submit_pfn_canvas(t, tab, (H, W))
+        if r is not None:
+            got_f.append((r[0].clone(), r[1].clone()))
+        d = c.submit(t)
+        if d is not None:
+            got_d.append((d[0].clone(), d[1].clone()))
+    assert len(got_f) == len(got_d) == 3
+    for t, f, d in zip(ts, got_f, got_d):
+        cv, ix = a.pfn_canvas(t, tab, (H, W))
+        assert torch.equal(cv, f[0]) and torch.equal(ix, f[1])
+        pil, ix2 = a(t)
+        assert torch.equal(pil, d[0]) and torch.equal(ix2, d[1])
