@@ -189,6 +189,12 @@ int main(int argc, char **argv) {
     run("pattern KW=4", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 0); });
     run("pattern KW=4 + 1 load", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 1); });
     run("pattern KW=4 + 2 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 2); });
+    // the same with the workgroups per CU capped by a dynamic LDS allocation (30 KB: 5, like k_step; 40 KB: 4; 53 KB: 3)
+    for (int lds : {20000, 26000, 30720, 40000, 53000}) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "pattern + 2 loads, %d B LDS", lds);
+      run(nm, [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), lds, 0, out, P, N, 2); });
+    }
     run("pattern KW=4 + 3 loads", [&] { hipLaunchKernelGGL(k_pattern<4>, dim3((P + 15) / 16, B), dim3(256), 0, 0, out, P, N, 3); });
     run("zero role alone, 256 WGs", [&] { hipLaunchKernelGGL(k_two_roles, dim3(256), dim3(256), 0, 0, out, P, N, B, 256, 1, -1); });
     run("zero role alone, 512 WGs", [&] { hipLaunchKernelGGL(k_two_roles, dim3(512), dim3(256), 0, 0, out, P, N, B, 512, 1, -1); });
