@@ -120,6 +120,57 @@ def test_random_configuration_pipelined(gpu, oracle, case):
     assert int(got[0][2][0, 0]) == m
 
 
+@pytest.mark.parametrize("case", list(range(12)))
+def test_random_configuration_fused_pipelined(gpu, case):
+    """The fused feature-net form of the software pipeline (k_step<pfn>: emit role = conv1x1 + ReLU + BN + max +
+    scatter, clear role for the other canvas) on random draws: ragged batches whose sizes change from call to call,
+    both canvas layouts, dense submits mixed in -- every canvas bit-equal to the three-launch fused call's."""
+    import torch
+    import pp_amd.model as M
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    rng = np.random.default_rng(9000 + case)
+    half = float(rng.choice([4.0, 6.4, 10.0, 25.0]))
+    step = float(rng.choice([0.2, 0.4, 0.5]))
+    N = int(rng.choice([4, 6, 8, 12, 20, 32, 100]))
+    order = int(rng.integers(0, 2))
+    nmax = int(rng.integers(800, 16000))
+    P = int(rng.integers(50, 3000))
+    cl = bool(rng.integers(0, 2))
+    cfg = VoxelConfig.square(half, step, P, N, order=order)
+    H = W = cfg.canvas_height
+    torch.manual_seed(case)
+    fn = M.PPFeatureNet(9, 64).to(gpu).eval()
+    with torch.no_grad():
+        fn.bn1.running_mean.normal_(0, 0.3)
+        fn.bn1.running_var.uniform_(0.5, 1.5)
+        fn.bn1.weight.normal_(0, 1.0)
+    tab = fn.fused_params()
+    plain, piped = PillarVoxelizer(cfg, device=gpu), PillarVoxelizer(cfg, device=gpu)
+    seq = []
+    for i in range(int(rng.integers(4, 8))):
+        B = int(rng.choice([1, 2, 4]))
+        clouds = np.stack([_cloud(rng, nmax, half, int(rng.integers(0, 12))) for _ in range(B)])
+        ns = [int(rng.integers(0, nmax + 1)) for _ in range(B)]
+        seq.append((torch.from_numpy(clouds).to(gpu), ns, bool(rng.integers(0, 4) == 0)))   # one call in four: dense
+    want = []
+    for t, ns, dense in seq:
+        r = plain(t, n_points=ns) if dense else plain.pfn_canvas(t, tab, (H, W), n_points=ns, channels_last=cl)
+        want.append(tuple(x.clone() for x in r))
+    kinds = [d for _, _, d in seq]
+    got = []
+    calls = [(t, ns) for t, ns, _ in seq] + [(None, None)] * piped.LAG
+    for k, (t, ns) in enumerate(calls):
+        due = k - piped.LAG                                  # the batch this call emits decides the form it comes out in
+        dense = kinds[due] if 0 <= due < len(kinds) else False
+        r = piped.submit(t, n_points=ns) if dense else piped.submit_pfn_canvas(t, tab, (H, W), n_points=ns, channels_last=cl)
+        if r is not None:
+            got.append(tuple(x.clone() for x in r))
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for w_, g_ in zip(want, got):
+        assert all(torch.equal(x, y) for x, y in zip(w_, g_)), (half, step, P, N, order, cl)
+
+
 @pytest.mark.parametrize("case", list(range(10)))
 def test_random_target_assignment(gpu, oracle, case):
     """Random anchor grids (1-3 anchor types per cell, random sizes / yaws) and ground-truth sets
