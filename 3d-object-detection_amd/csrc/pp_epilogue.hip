@@ -67,11 +67,30 @@ __global__ __launch_bounds__(256) void k_bias_relu_bn_nhwc(const float4 *__restr
     s = make_float4(q[1], q[4], q[7], q[10]);
     t = make_float4(q[2], q[5], q[8], q[11]);
   };
-  if (kFixedLane) load_table((int)(i % c4));
+  if (kFixedLane) {
+    // c4 divides the grid stride: the lane keeps its channel group AND its pixel advances by a constant -- ONE
+    // 64-bit division per thread instead of one per 16 bytes (no measurable change end to end: the kernel is a
+    // read-modify-write stream at ~3.8 TB/s of traffic either way)
+    int64_t pix = i / c4;
+    const int g = (int)(i - pix * c4);
+    const int64_t pstep = step / c4;
+    load_table(g);
+    float *yp = y + pix * y_stride + (int64_t)g * 4;
+    const int64_t ystep = pstep * y_stride;
+    for (; i < n4; i += step, yp += ystep) {
+      float4 v = x[i];
+      v.x = fmaxf(v.x + b.x, 0.0f) * s.x + t.x;
+      v.y = fmaxf(v.y + b.y, 0.0f) * s.y + t.y;
+      v.z = fmaxf(v.z + b.z, 0.0f) * s.z + t.z;
+      v.w = fmaxf(v.w + b.w, 0.0f) * s.w + t.w;
+      *reinterpret_cast<float4 *>(yp) = v;
+    }
+    return;
+  }
   for (; i < n4; i += step) {
     const int64_t pix = i / c4;
     const int g = (int)(i - pix * c4);
-    if (!kFixedLane) load_table(g);
+    load_table(g);
     float4 v = x[i];
     v.x = fmaxf(v.x + b.x, 0.0f) * s.x + t.x;
     v.y = fmaxf(v.y + b.y, 0.0f) * s.y + t.y;
