@@ -147,7 +147,9 @@ struct pp_ctx {
   pp::PinBuf pin_in, pin_out, pin_meta;
   // IoU / target scratch
   pp::DevBuf iou_ws;
-  unsigned long long tgt_key = 0;  // shape the target scratch was last armed for
+  // the layout the target scratch was last armed for: {A, gcap, batch, units, form, splits, cand_per_wg, off_best,
+  // ticket groups}, compared field by field (all zero: not armed)
+  unsigned long long tgt_key[9] = {};
   pp::DevBuf decode_ws;            // post-processing: sort keys + rocPRIM temporary storage
   pp::DevBuf pfn_ws;               // training feature net: per-workgroup partial sums
   // emit-kernel timing ring (bench.py)

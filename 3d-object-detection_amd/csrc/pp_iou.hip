@@ -1827,8 +1827,10 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
 #pragma unroll
               for (int d = 0; d < 9; ++d) store_f32_sc1(pe->row + d, S.rstage[lane * 9 + d]);
               store_f32_sc1(pe->pad, __int_as_float(S.gcls[0]));  // the box's class rides along
+              // (only for a STORED entry: the tail resets the words of the entries it sees, so a dropped one
+              // would leave its word raised for every later call on this context)
+              __hip_atomic_fetch_max(&t.best[ai], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __hip_atomic_fetch_max(&t.best[ai], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
@@ -1981,6 +1983,13 @@ extern "C" int pp_iou_check(pp_ctx_t *ctx, void *stream_) {
   if (flag) {
     // the flag is sticky across launches until it has been reported once
     PP_HIP_TRY(hipMemsetAsync(ctx->iou_ws.ptr, 0, 4, static_cast<hipStream_t>(stream_)));
+    if (flag == 2) {
+      // the positive list overflowed (sized from the candidate count, so only reachable through boxes whose centre is
+      // not finite): entries were dropped; re-arm every scratch word before the next call
+      std::memset(ctx->tgt_key, 0, sizeof ctx->tgt_key);
+      set_error("target assignment: more pairs above the threshold than candidate anchors (a box centre that is not finite?)");
+      return PP_ERR_VALUE;
+    }
     set_error("IOU < 0: a box has the wrong corner winding (pillars.cpp:166-169)");
     return PP_ERR_WINDING;
   }
@@ -2143,7 +2152,16 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
     set_error("pp_assign_targets*_dev: %zu workgroups per sample (limit 65535)", units);
     return PP_ERR_VALUE;
   }
-  const size_t cand_per_gt = boxes_form ? splits : nwg, pos_per_gt = boxes_form ? splits * cand_per_wg : 0;
+  // positives per box: at most one entry per candidate.  The PAIR loop strides over ALL of a box's candidates, also
+  // when `splits` was clamped to 64 workgroups (fm_scale ~1 with six anchors per cell: 3174 candidates against
+  // 64 x 32), so the list is sized from the candidate count itself, not from splits x cand_per_wg
+  size_t pos_per_gt = 0;
+  if (boxes_form) {
+    const double per_axis = std::min(std::floor(20.0 * an.fm_scale) + 3.0, 32768.0);
+    const double cand = std::min(per_axis * per_axis * an.per_cell, (double)A);
+    pos_per_gt = std::max(splits * cand_per_wg, (size_t)std::ceil(cand));
+  }
+  const size_t cand_per_gt = boxes_form ? splits : nwg;
   const size_t off_cmax = 8192, off_cwin = off_cmax + gcap * 8;
   // first-level tickets: groups of ~sqrt(workgroups) (a power of two), one 64-byte line per group and sample
   int ticket_shift = 0;
@@ -2215,24 +2233,27 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   t.reg_targets = reg_targets;
   // The scratch words are re-armed by every sample's tail at the end of every call; only a
   // fresh / regrown / re-shaped workspace needs the init.
-  const unsigned long long key = ((unsigned long long)A << 24) ^ (unsigned long long)gcap ^
-                                 ((unsigned long long)batch << 56) ^ ((unsigned long long)units << 40) ^
-                                 (boxes_form ? 1ull << 63 : 0ull);
-  if (grew || ctx->tgt_key != key) {
+  // ... identified by every value that moves a scratch word (no packed bit fields: two assigners with different grids
+  // on one context must never look alike)
+  const unsigned long long key[9] = {(unsigned long long)A, (unsigned long long)gcap, (unsigned long long)batch,
+                                     (unsigned long long)units, boxes_form ? 2ull : 1ull, (unsigned long long)splits,
+                                     (unsigned long long)cand_per_wg, (unsigned long long)off_best,
+                                     (unsigned long long)ngrp};
+  if (grew || std::memcmp(ctx->tgt_key, key, sizeof key) != 0) {
     const unsigned gb = (unsigned)((std::max<size_t>(std::max<size_t>(gcap, PP_MAX_BATCH), n_ticket1) + 255) / 256);
     hipLaunchKernelGGL(k_targets_init, dim3(gb), dim3(256), 0, stream, t.col_max, t.col_win,
                        (int)gcap, t.errflag, t.cand_count, t.ticket, t.ticket1, (int)n_ticket1);
     if (boxes_form)
       hipLaunchKernelGGL(k_targets_gt_init, dim3((unsigned)((std::max<size_t>(n_best, PP_MAX_BATCH) + 255) / 256)),
                          dim3(256), 0, stream, t.best, t.bestj, (int64_t)n_best, t.pos_count);
-    ctx->tgt_key = key;
+    std::memcpy(ctx->tgt_key, key, sizeof key);
   }
   if (boxes_form)
     hipLaunchKernelGGL(k_targets_gt, dim3((unsigned)batch, (unsigned)units), dim3(kTgtThreads), 0, stream, t, bt);
   else
     hipLaunchKernelGGL(k_targets<false>, dim3((unsigned)batch, (unsigned)nwg), dim3(kTgtThreads), 0, stream, t, bt);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) {
-    ctx->tgt_key = 0;  // counters in an unknown state: re-arm on the next call
+    std::memset(ctx->tgt_key, 0, sizeof ctx->tgt_key);  // counters in an unknown state: re-arm on the next call
     set_error("k_targets launch failed: %s", hipGetErrorString(e));
     return PP_ERR_HIP;
   }

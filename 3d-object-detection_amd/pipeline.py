@@ -82,20 +82,29 @@ class PillarPipeline:
         stream (it emits an older batch into one of two output buffers) and, on the caller's stream, runs the network
         on the batch the PREVIOUS call's launch emitted into the other buffer.  The two only meet through events that
         were recorded a whole step earlier, so neither queue waits: the voxelizer leaves the step's critical path.
-        ``points`` must be ready when the call is made (resident, or produced on the caller's stream before an event
-        this method can order against: the side stream waits for the caller's stream as of the PREVIOUS call).
+        ``points`` (and ``n_points`` if it is a tensor) may be produced on the caller's stream right before the call
+        -- a ``non_blocking`` copy, an ingest kernel -- and dropped right after it: the side stream waits for an event
+        recorded on the caller's stream AT ENTRY (between two calls that stream holds only the previous network pass
+        and whatever produced ``points``, so the wait also covers "buffer k was read by the previous call's network"
+        and costs the overlap nothing), and the tensors are ``record_stream``-ed on the side stream, so the caching
+        allocator does not hand their memory to a main-stream allocation while the side-stream launch still reads it.
         Returns ``(cls, reg)`` of the batch handed in ``PillarVoxelizer.LAG + 1`` calls ago, else ``None``;
         ``points=None`` drains."""
         ov = getattr(self, "_ov", None)
         if ov is None:
             ov = self._ov = {"stream": torch.cuda.Stream(device=self.device), "i": 0, "bufs": [None, None],
-                             "vox_done": [torch.cuda.Event(), torch.cuda.Event()], "net_done": torch.cuda.Event(),
-                             "ready": [None, None], "armed": False}
+                             "vox_done": [torch.cuda.Event(), torch.cuda.Event()], "entry": torch.cuda.Event(),
+                             "ready": [None, None]}
         main = torch.cuda.current_stream(self.device)
         i, side = ov["i"], ov["stream"]
         k = i % 2
-        if ov["armed"]:
-            side.wait_event(ov["net_done"])      # buffer k was read by the network of the previous call
+        # everything the caller's stream holds now -- the producer of `points`, the previous call's network pass that
+        # read buffer k -- is ordered before the side stream's launch
+        ov["entry"].record(main)
+        side.wait_event(ov["entry"])
+        for t_ in (points, n_points):
+            if torch.is_tensor(t_) and t_.is_cuda:
+                t_.record_stream(side)
         B = self.voxelizer._inflight[-1] if getattr(self.voxelizer, "_inflight", None) else None
         with torch.cuda.stream(side):
             if B and (ov["bufs"][k] is None or ov["bufs"][k][0].shape[0] != B):
@@ -113,8 +122,6 @@ class PillarPipeline:
         if prev is not None:
             main.wait_event(ov["vox_done"][1 - k])
             out = self.model(prev[0], prev[1])
-        ov["net_done"].record(main)
-        ov["armed"] = True
         return out
 
     @torch.no_grad()
@@ -166,7 +173,9 @@ class PillarPipeline:
         if self.model.training:
             raise RuntimeError("forward_fused_pipelined is inference only: call model.eval() first")
         if self.voxelizer.data_mean is not None:
-            raise RuntimeError("the fused feature net has no data_mean form: use forward_pipelined")
+            # as forward_fused: a data mean makes the zero-padded slots non-zero, nothing to skip -- the dense
+            # pipelined path (same pipeline, same lag: the batches in flight are shared between the two forms)
+            return self.forward_pipelined(points, n_points)
         pfn_params = self.model.feature_net.fused_table(self.device)
         H, W = self.model.scatter.h, self.model.scatter.w
         r = self.voxelizer.submit_pfn_canvas(points, pfn_params, (H, W), n_points=n_points, channels_last=True)

@@ -223,7 +223,8 @@ class PillarVoxelizer:
         Returns the ``(pillars, indices[, counts])`` of the batch submitted three calls ago
         (bit-identical to ``__call__`` on that batch), or ``None`` while the pipeline fills.
         ``points=None`` drains (``LAG`` such calls flush everything).  ``out`` buffers (optional)
-        receive that older batch.  Everything runs on the current stream."""
+        receive that older batch.  Everything runs on the current stream.  A refused call (``ValueError``: wrong
+        stream, bad argument) leaves the pipeline as it was; a failed launch resets it (``_submit_failed``)."""
         cfg = self.cfg
         P, N = cfg.max_pillars, cfg.max_points_per_pillar
         inflight = getattr(self, "_inflight", None)
@@ -254,14 +255,7 @@ class PillarVoxelizer:
             vp(indices.data_ptr()) if indices is not None else None,
             vp(counts.data_ptr()) if counts is not None else None, ctypes.byref(emitted))
         if rc != _lib.PP_OK:
-            # One rule for both sides: a failed submit abandons the batches in flight (their results are never
-            # returned) and the next submit starts a fresh pipeline.  (The C side alone keeps its batches when it
-            # rejects a call before the launch and drops them when the launch fails; without the reset here the
-            # two could disagree about what is due.)
-            msg = _lib.lib().pp_last_error()
-            _lib.lib().pp_voxelize_step_reset(self._ctx.handle)
-            self._inflight = [None, None, None]
-            _lib.check(rc, "pp_voxelize_step_dev (pipeline reset)", msg)
+            self._submit_failed(rc, "pp_voxelize_step_dev")
         self._inflight = [nxt[1] if nxt else None, inflight[0], inflight[1]]
         if due is None:
             return None
@@ -329,12 +323,10 @@ class PillarVoxelizer:
             vp(counts.data_ptr()) if counts is not None else None,
             vp(clear_c.data_ptr()) if clear_c is not None else None,
             vp(clear_i.data_ptr()) if clear_i is not None else None, clear_b, ctypes.byref(emitted))
-        if rc != _lib.PP_OK:                        # same rule as submit(): a failed call abandons the pipeline
-            msg = _lib.lib().pp_last_error()
-            _lib.lib().pp_voxelize_step_reset(self._ctx.handle)
-            self._inflight = [None, None, None]
-            self._pc = None                          # the canvases' state is unknown: start from zeroed ones
-            _lib.check(rc, "pp_voxelize_step_pfn_canvas_dev (pipeline reset)", msg)
+        if rc != _lib.PP_OK:                        # same rule as submit()
+            if rc != _lib.PP_ERR_VALUE:
+                self._pc = None                      # the canvases' state is unknown: start from zeroed ones
+            self._submit_failed(rc, "pp_voxelize_step_pfn_canvas_dev")
         self._inflight = [nxt[1] if nxt else None, inflight[0], inflight[1]]
         if due is None:
             return None
@@ -344,6 +336,20 @@ class PillarVoxelizer:
             st["filled"][1 - k] = 0
         st["turn"] = 1 - k
         return (canvas, indices, counts) if return_counts else (canvas, indices)
+
+    def _submit_failed(self, rc, what):
+        """The contract of include/pp_hip.h, on both sides alike.  A call REFUSED before anything was launched
+        (``PP_ERR_VALUE``: another stream while batches are in flight, a bad argument, missing output buffers for
+        the batch that is due) changes nothing: the batches in flight stay in flight, here and in the library, and
+        the next valid call carries on (a stray call does not cost three good batches).  Any other failure (a
+        failed launch or allocation) abandons the batches in flight on both sides -- their results are never
+        returned and the next submit starts an empty pipeline."""
+        msg = _lib.lib().pp_last_error()
+        if rc != _lib.PP_ERR_VALUE:
+            _lib.lib().pp_voxelize_step_reset(self._ctx.handle)
+            self._inflight = [None, None, None]
+            what += " (pipeline reset)"
+        _lib.check(rc, what, msg)
 
     def step_kernel_name(self, batch):
         """The k_step instance ``submit`` emits a batch of ``batch`` sweeps with, as a kernel trace prints it."""

@@ -145,6 +145,88 @@ def cpu_baseline(seconds_budget=10.0, workers=4, worker_budget=5.0, c1_budget=5.
     return out
 
 
+def _median_ms(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, float(np.min(ts)) * 1e3
+
+
+def dropin_record(gpu_ms, cpu_ms, what):
+    """one leg of `dropin_host`: the module call on host arrays (PCIe inclusive) beside the CPU figure"""
+    ratio = cpu_ms / gpu_ms
+    return {"hip_ms": gpu_ms, "cpu_ms": cpu_ms, "speedup": ratio, "meets_50x": bool(ratio >= 50.0), "what": what}
+
+
+def dropin_host(reps=15):
+    """The drop-in surface's OWN speed (north_star: ">= 50x the CPU pybind11 pillarizer ... at matched output", "data/
+    dataset.py calls the same symbols"): the built pybind11 module `pillars` (native/pillars*.so, what
+    install_mods.sh:8-10 would move into data/) called the way data/dataset.py:88-106 and utils/box_utils.py:181-183
+    call it -- float64 NumPy arrays on the HOST, outputs mutated in place, PCIe transfers and the host-side scatter
+    included -- beside the CPU oracle's reference-style functions on the same arrays (1 core; a C port through
+    ctypes, faster per call than the reference's bounds-checked pybind11 build: conservative for the ratio)."""
+    import importlib.util
+    from oracle import oracle as O
+    from pp_amd import boxes
+    O.build()
+    spec = importlib.util.spec_from_file_location("pillars", _lib.build_pybind_module())
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pts = synth.lidar_like(N_POINTS, HALF, 0).astype(np.float64)          # dataset.py:82 hands over f64
+    agg = np.ascontiguousarray(pts.T)                                      # [4, n]; dataset.py:88 passes its transpose view
+    cp_args = (N, P, STEP, STEP, -HALF, -HALF, -10.0, HALF, HALF, 10.0, int(round(2 * HALF / STEP)))
+    T, I = np.zeros((P, N, 9)), np.zeros((P, 3))
+
+    def call_hip():
+        mod.create_pillars(agg.transpose([1, 0]), T, I, *cp_args)
+
+    def call_cpu():
+        O.create_pillars(agg.transpose([1, 0]), T, I, *cp_args, order=O.ORDER_HASH)
+
+    def glue(create):      # data/dataset.py:88-106 around the call, statement for statement
+        def run():
+            pillar = np.zeros((P, N, 9))
+            indices = np.zeros((P, 3))
+            create(agg.transpose([1, 0]), pillar, indices, *cp_args)
+            pillar = pillar.transpose([2, 0, 1])
+            pillar = torch.from_numpy(pillar).float()
+            indices = torch.from_numpy(indices).long()
+            return pillar, indices
+        return run
+    hip_call, _ = _median_ms(call_hip, reps)
+    cpu_call, _ = _median_ms(call_cpu, max(5, reps // 2))
+    hip_glue, _ = _median_ms(glue(mod.create_pillars), reps)
+    cpu_glue, _ = _median_ms(glue(lambda *a_: O.create_pillars(*a_, order=O.ORDER_HASH)), max(5, reps // 2))
+    anchors = boxes.make_anchors(boxes.AnchorConfig(250, 250))
+    gt = synth.gt_boxes(40, 500, 0)
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 500)
+    ious = np.zeros((anchors["corners"].shape[0], 40))
+    hip_iou, _ = _median_ms(lambda: mod.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious), reps)
+    cpu_iou, _ = _median_ms(lambda: O.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious), 5, warm=1)
+    return {
+        "module": "native/" + os.path.basename(_lib.pybind_module_path()) + " (pybind11, csrc/pillars_module.cpp -> "
+                  "pp_create_pillars_f64 / pp_make_ious_f64)",
+        "create_pillars_call": dropin_record(
+            hip_call, cpu_call, "pillars.create_pillars(points f64 [n,4] strided view, tensor f64 [P,N,9], indices f64 "
+            "[P,3], ...) at configs[1]'s shapes on pre-zeroed arrays, the call alone; median of "
+            f"{reps}; cpu = the oracle's reference-style create_pillars (hash map of heap nodes) on one core"),
+        "create_pillars_in_dataset_glue": dropin_record(
+            hip_glue, cpu_glue, "the same call inside the reference caller's own statements (data/dataset.py:88-106: two "
+            "np.zeros incl. the 86 MB f64 tensor, the call, transpose to [9,P,N], .float(), .long()): the glue is "
+            "reference code and costs the same on both sides"),
+        "make_ious_call": dropin_record(
+            hip_iou, cpu_iou, "pillars.make_ious(a_corners [A,4,2], g_corners, a_centers, g_centers, ious [A,G]) at "
+            "A=125000, G=40 (configs[2]): 11 MB of f64 anchors up, the 40 MB f64 matrix back over PCIe"),
+        "note": "PCIe-inclusive compatibility numbers, never `value`.  The >= 50x target is met on the device-resident "
+                "API (voxelizer_only / cpu_baseline); on THIS surface the reference's own host-side work bounds the ratio: "
+                "the caller's np.zeros + transpose + f32 cast of an 86 MB f64 tensor, and for make_ious the 40 MB matrix "
+                "the signature demands"}
+
+
 def kernel_means_us(vox):
     """mean duration (us) of the voxelizer's kernels over the calls since set_timing: the three kernels of the
     plain calls, or k_step alone (recorded in the k_emit column) after pipelined calls"""
@@ -207,10 +289,12 @@ def rotating_outputs(batch, p, n, dev, total_bytes=512 << 20, most=12):
              torch.empty((batch, p, 3), dtype=torch.int64, device=dev)) for _ in range(k)]
 
 
-def vox_measure(vox, points, out, pipelined, iters=200, warm=20, kernel_iters=64):
+def vox_measure(vox, points, out, pipelined, iters=200, warm=20, kernel_iters=64, ctx=None, dev=None):
     """(seconds per call, kernel means in us, launches timed): wall time with event timing OFF (the event pairs
     cost launch time), the kernels' durations in a pass of their own.  ``out``: one (pillars, indices) pair or a
-    list of them used in turn (rotating_outputs)."""
+    list of them used in turn (rotating_outputs).  With a multi-rank ``ctx`` the wall loop is bracketed by barriers
+    and the time is the maximum over the ranks (every rank runs the same loop on its own sweeps)."""
+    multi = ctx is not None and ctx.distributed
     outs = out if isinstance(out, list) else [out]
     turn = [0]
 
@@ -228,11 +312,19 @@ def vox_measure(vox, points, out, pipelined, iters=200, warm=20, kernel_iters=64
     for _ in range(warm):
         call()
     torch.cuda.synchronize()
+    if multi:
+        shard.barrier(ctx)
+        torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(iters):
         call()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t1) / iters
+    if multi:
+        shard.barrier(ctx)
+        torch.cuda.synchronize()
+        dt = shard.max_over_ranks(ctx, time.perf_counter() - t1, device=dev) / iters
+    else:
+        dt = (time.perf_counter() - t1) / iters
     for _ in range(4):
         call()
     torch.cuda.synchronize()
@@ -247,17 +339,26 @@ def vox_measure(vox, points, out, pipelined, iters=200, warm=20, kernel_iters=64
     return dt, kern_us, n
 
 
-def vox_both(vox, points, out, bytes_per_launch, iters=200, kernel_iters=64):
-    """one voxelizer configuration both ways: software-pipelined (k_step) and as three launches"""
-    dt_p, k_p, _ = vox_measure(vox, points, out, True, iters=iters, kernel_iters=kernel_iters)
-    dt_3, k_3, _ = vox_measure(vox, points, out, False, iters=iters, kernel_iters=kernel_iters)
+def vox_both(vox, points, out, bytes_per_launch, iters=200, kernel_iters=64, ctx=None, dev=None):
+    """one voxelizer configuration both ways: software-pipelined (k_step) and as three launches.  With a multi-rank
+    ``ctx``: every rank runs it on its own sweeps, `sweeps_per_s` is the WHOLE JOB's (all ranks' sweeps over the
+    slowest rank's loop time, `wall_frac` stays per GPU) and `per_rank` carries min / max over the ranks of the
+    kernel's duration and fraction."""
+    dt_p, k_p, _ = vox_measure(vox, points, out, True, iters=iters, kernel_iters=kernel_iters, ctx=ctx, dev=dev)
+    dt_3, k_3, _ = vox_measure(vox, points, out, False, iters=iters, kernel_iters=kernel_iters, ctx=ctx, dev=dev)
     B = points.shape[0]
-    return {"output_buffers": len(out) if isinstance(out, list) else 1,
-            "sweeps_per_s": B / dt_p, "us_per_step": dt_p * 1e6,
-            "pipeline_GBps": bytes_per_launch / dt_p / 1e9, "wall_frac": bytes_per_launch / dt_p / HBM_PEAK,
-            "k_step_us": k_p["k_step"], "kernel_frac": bytes_per_launch / (k_p["k_step"] * 1e-6) / HBM_PEAK,
-            "three_launch": dict(three_launch_record(k_3, bytes_per_launch), sweeps_per_s=B / dt_3,
-                                 us_per_step=dt_3 * 1e6, wall_frac=bytes_per_launch / dt_3 / HBM_PEAK)}
+    W = ctx.world_size if ctx is not None else 1
+    rec = {"output_buffers": len(out) if isinstance(out, list) else 1,
+           "sweeps_per_s": W * B / dt_p, "us_per_step": dt_p * 1e6,
+           "pipeline_GBps": bytes_per_launch / dt_p / 1e9, "wall_frac": bytes_per_launch / dt_p / HBM_PEAK,
+           "k_step_us": k_p["k_step"], "kernel_frac": bytes_per_launch / (k_p["k_step"] * 1e-6) / HBM_PEAK,
+           "three_launch": dict(three_launch_record(k_3, bytes_per_launch), sweeps_per_s=W * B / dt_3,
+                                us_per_step=dt_3 * 1e6, wall_frac=bytes_per_launch / dt_3 / HBM_PEAK)}
+    if W > 1:
+        rec["n_gpus"] = W
+        rec["per_rank"] = ranks_min_max(ctx, k_p["k_step"], bytes_per_launch, dev)
+        rec["per_rank"]["kernel_frac"] = rec["per_rank"].pop("frac")
+    return rec
 
 
 def static_traffic(key):
@@ -271,17 +372,21 @@ def static_traffic(key):
         return None, None
 
 
-def live_traffic(batch, kernel, timeout_s=90):
-    """HBM bytes per launch of the headline's k_step measured IN THIS RUN: two child runs of this script's
-    headline loop under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes with --kernel-trace only,
-    from /tmp, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- median over the launches of `kernel`,
-    KiB * 1024 (k_step's reads are narrow gathers and short rows: the guide's x2 correction for wide streaming
-    reads is not applied; the same processing as tools/pmc_summary.py + tools/make_emit_traffic.py).  Children
-    are fresh processes (`-- python3 bench.py ...`, never an exec of this one).  None when rocprofv3 is missing,
-    fails or times out: the caller then falls back to the committed constant and says so."""
+def live_traffic(batch, kernel, timeout_s=90, child="--headline-only"):
+    """HBM bytes per launch of `kernel` measured IN THIS RUN: two child runs of this script under `rocprofv3 --pmc`
+    -- FETCH_SIZE and WRITE_SIZE in separate passes with --kernel-trace only, from /tmp, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes -- median over the launches of `kernel`, KiB * 1024 (the same
+    processing as tools/pmc_summary.py + tools/make_emit_traffic.py).  `child` selects what the child runs: the
+    headline loop (`--headline-only`) or the batched target assignment alone (`--targets-only`).  On gfx950
+    FETCH_SIZE under-reports 16-byte-per-lane streaming reads by up to 2x (the guide's correction): the caller gets
+    the raw figure AND `FETCH_SIZE_bytes_x2` and reports both.  Children are fresh processes in their own process
+    group (`-- python3 bench.py ...`, never an exec of this one); on a timeout the whole group is killed and
+    reaped, so no profiled child is left holding the GPU.  None when rocprofv3 is missing, fails or times out: the
+    caller then falls back to the committed constant and says so."""
     import csv
     import glob
     import shutil
+    import signal
     import statistics
     import subprocess
     import tempfile
@@ -293,17 +398,26 @@ def live_traffic(batch, kernel, timeout_s=90):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "t", "--output-format", "csv", "--",
-                   sys.executable, os.path.abspath(__file__), "--headline-only", "--steps", "8", "--warmup", "4",
+                   sys.executable, os.path.abspath(__file__), child, "--steps", "8", "--warmup", "4",
                    "--batch", str(batch)]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=timeout_s)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)     # the launcher AND the profiled python child
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return None
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row.get("Kernel_Name") or row.get("Kernel-Name") or ""
                     if kernel.replace("pp::", "") in name and row.get("Counter_Name") == ctr:
                         vals.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or len(vals) < 4:
+            if rc != 0 or len(vals) < 4:
                 return None
             got[ctr] = (statistics.median(vals) * 1024.0, len(vals))
     except Exception:
@@ -312,7 +426,30 @@ def live_traffic(batch, kernel, timeout_s=90):
         shutil.rmtree(tmp, ignore_errors=True)
     total = got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]
     return total, {"FETCH_SIZE_bytes": got["FETCH_SIZE"][0], "WRITE_SIZE_bytes": got["WRITE_SIZE"][0],
+                   "FETCH_SIZE_bytes_x2": 2.0 * got["FETCH_SIZE"][0],
                    "launches": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
+
+
+def per_rank(ctx, values, device=None):
+    """`values` (this rank's floats) from EVERY rank: a list, rank by rank, of lists -- one all-reduce(SUM) of a
+    [world, k] tensor in which only this rank's row is non-zero (works over RCCL and over gloo alike; called after a
+    timed loop, never inside one)."""
+    k = len(values)
+    t = torch.zeros((ctx.world_size, k), dtype=torch.float64, device=device)
+    t[ctx.rank] = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if ctx.distributed:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+    return t.cpu().tolist()
+
+
+def ranks_min_max(ctx, us, bytes_per_launch, device=None, name="k_step_us"):
+    """min / max over the ranks of one kernel's mean duration and of its roofline fraction (every rank times its
+    own kernel with its own HIP events; north_star asks for the fraction at 1/2/4/8 GPUs)"""
+    rows = [r[0] for r in per_rank(ctx, [us], device)]
+    fr = [bytes_per_launch / (u * 1e-6) / HBM_PEAK if u > 0 else float("nan") for u in rows]
+    return {name: [min(rows), max(rows)], "frac": [min(fr), max(fr)], "per_rank_" + name: rows,
+            "what": "this kernel's mean duration on every rank (its own HIP event pairs) and algorithmic bytes / "
+                    "duration / 8 TB/s: [min, max] over the ranks"}
 
 
 def self_launch(n_ranks):
@@ -323,8 +460,9 @@ def self_launch(n_ranks):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # The ranks inherit this process's environment unchanged (this image and the GPU boxes export
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 themselves -- `env | grep HSA_` -- and nothing here sets or overrides it).
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -348,7 +486,12 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed headline loop (no side legs): under rocprofv3 the kernel-stats average of "
                          "k_step then covers exactly the launches `roofline` is computed from")
+    ap.add_argument("--targets-only", action="store_true",
+                    help="only the batched target assignment of configs[2] (--steps + --warmup launches, no output): "
+                         "the child run `train_c3.targets.moved_bytes` is measured from under rocprofv3 --pmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the dropin_host record (the pybind11 module's "
+                                                             "own speed on host arrays)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed constant (profiles/emit_traffic.json) instead of two "
                          "rocprofv3 --pmc child runs of the headline loop")
@@ -361,7 +504,7 @@ def main():
                          "code path on a box with fewer GPUs than ranks (all ranks share device 0)")
     a = ap.parse_args()
     if a.headline_only:
-        a.no_cpu_baseline = a.no_fused = a.no_train_leg = a.no_stress = True
+        a.no_cpu_baseline = a.no_fused = a.no_train_leg = a.no_stress = a.no_dropin = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has
@@ -391,6 +534,20 @@ def main():
     torch.backends.cudnn.benchmark = (a.mode == "fwd")
 
     cfg = VoxelConfig.square(HALF, STEP, P, N)          # default pillar order (scrambled)
+    if a.targets_only:
+        # the PMC child of train_c3.targets: the step's boxes in one launch, nothing else on the device
+        from pp_amd import boxes
+        from pp_amd.targets import TargetAssigner
+        ta_ = TargetAssigner(boxes.AnchorConfig(fm_height=(cfg.canvas_height + 1) // 2,
+                                                fm_width=(cfg.canvas_width + 1) // 2),
+                             canvas_height=cfg.canvas_height, device=dev)
+        g_ = ta_.upload_batch([synth.gt_boxes(40, cfg.canvas_height, s) for s in range(a.batch)])
+        o_ = ta_.assign_batch_device(*g_)
+        for _ in range(a.warmup + a.steps):
+            ta_.assign_batch_device(*g_, out=o_)
+        torch.cuda.synchronize()
+        shard.shutdown(ctx)
+        return
     pipe = PillarPipeline(cfg, device=dev, seed=0, with_targets=(a.mode == "train"))
     pipe.model.eval() if a.mode == "fwd" else pipe.model.train()
     sweep_ids = [ctx.rank * a.batch + i for i in range(a.batch)]
@@ -444,6 +601,8 @@ def main():
     kern_us, launches = kernel_means_us(pipe.voxelizer)
     pipe.voxelizer.set_timing(0)
     bytes_per_launch = cfg.algorithmic_bytes(N_POINTS) * a.batch
+    head_ranks = ranks_min_max(ctx, kern_us["k_step"] if "k_step" in kern_us else kern_us["k_emit"], bytes_per_launch,
+                               dev, name="avg_launch_us")
     three_e2e = None
     if pipelined and a.headline_only:
         for _ in range(PillarVoxelizer.LAG):
@@ -452,10 +611,13 @@ def main():
         for _ in range(PillarVoxelizer.LAG):
             pipe.forward_pipelined(None)                                # drain
         # the same forward with the voxelizer as three dependent launches per step, for comparison
+        def three_step():      # the same four resident batches in turn as the pipelined leg
+            step_no[0] += 1
+            return pipe.forward(point_sets[step_no[0] % len(point_sets)])
         for _ in range(3):
-            pipe.forward(points)
+            three_step()
         pipe.voxelizer.set_timing(min(a.steps, 4096))
-        el3 = timed_loop(lambda: pipe.forward(points), a.steps)
+        el3 = timed_loop(three_step, a.steps)
         k3, _ = kernel_means_us(pipe.voxelizer)
         pipe.voxelizer.set_timing(0)
         three_e2e = dict(three_launch_record(k3, bytes_per_launch), ms_per_step=el3 / a.steps * 1e3,
@@ -664,7 +826,14 @@ def main():
                        "us_per_call": assign_call_us, "achieved": t_bytes / (assign_call_us * 1e-6) / 1e9,
                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": t_bytes / (assign_call_us * 1e-6) / HBM_PEAK,
                        "one_sample_per_launch_us": assign1_us,
-                       "one_sample_per_launch_frac": 112 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK}
+                       "one_sample_per_launch_frac": 112 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK,
+                       # what the box-centric kernel MOVES: it evaluates the anchors arithmetically and reads none of
+                       # SURVEY's 40 B per anchor of input -- the two target arrays (72 B per anchor) and the boxes
+                       "moved_bytes": 72 * tp.assigner.A * a.batch,
+                       "moved_bytes_source": "computed: 72 * A * batch (the two f32 target arrays; the boxes stay in L2); "
+                                             "profiles/r04/pmc_targets_c3_b4_*: 36.4 MB written + 0.24 MB fetched at B=4",
+                       "frac_of_moved_bytes": 72 * tp.assigner.A * a.batch / (assign_call_us * 1e-6) / HBM_PEAK,
+                       "one_sample_frac_of_moved_bytes": 72 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK}
         del tg1, t_out
         e0.record()
         for _ in range(10):
@@ -692,9 +861,32 @@ def main():
             one, g_one = points[:1], tp.upload_ground_truth_batch(gts_host[:1])
             for _ in range(3 + PillarVoxelizer.LAG):
                 pipe.forward_pipelined(one)
+            pipe.voxelizer.set_timing(min(a.steps, 4096))
             el1 = timed_loop(lambda: pipe.forward_pipelined(one), a.steps)
+            k1, n1 = kernel_means_us(pipe.voxelizer)
+            pipe.voxelizer.set_timing(0)
             for _ in range(PillarVoxelizer.LAG):
                 pipe.forward_pipelined(None)
+            b1 = bytes_per_launch // a.batch
+            c3_roof = dict(roofline_record(k1, n1, b1, step_kernel=pipe.voxelizer.step_kernel_name(1)),
+                           ranks_min_max=ranks_min_max(ctx, k1["k_step"], b1, dev, name="avg_launch_us"))
+            c3_roof["what"] = ("k_step at ONE sweep per launch inside the one-sweep-per-GPU forward loop (HIP event pairs, "
+                               "every rank its own)")
+            to1 = tp.assigner.assign_batch_device(*g_one)
+            for _ in range(10):
+                tp.assigner.assign_batch_device(*g_one, out=to1)
+            e0.record()
+            for _ in range(100):
+                tp.assigner.assign_batch_device(*g_one, out=to1)
+            e1.record()
+            torch.cuda.synchronize()
+            tg1_us = e0.elapsed_time(e1) * 1e3 / 100
+            c3_tgt = {"kernel": "pp::k_targets_gt, one sample per launch", "us_per_call": tg1_us,
+                      "bytes_per_launch": 112 * tp.assigner.A, "moved_bytes": 72 * tp.assigner.A,
+                      "frac": 112 * tp.assigner.A / (tg1_us * 1e-6) / HBM_PEAK,
+                      "frac_of_moved_bytes": 72 * tp.assigner.A / (tg1_us * 1e-6) / HBM_PEAK,
+                      "ranks_min_max": ranks_min_max(ctx, tg1_us, 112 * tp.assigner.A, dev, name="us_per_call")}
+            del to1
 
             def train_one():
                 tp.model.zero_grad(set_to_none=True)
@@ -711,6 +903,7 @@ def main():
                 "train": {"value": a.train_steps * ctx.world_size / elt, "unit": "sweeps/s",
                           "ms_per_step": elt / a.train_steps * 1e3, "steps": a.train_steps},
                 "allreduce_ms": ar_ms,
+                "roofline": c3_roof, "targets": c3_tgt,
                 "collectives": {"backend": ctx.backend, "world_size": torch.distributed.get_world_size(),
                                 "in_forward": "none (sweeps shard; no data-path collective)",
                                 "in_train_step": "positive-count all-reduce (4 B), flat gradient all-reduce "
@@ -724,29 +917,70 @@ def main():
     # BASELINE configs[4] shapes (stress): voxelizer only, one GPU's share -- B sweeps per launch and the
     # configs[4] per-GPU shape (ONE 200k-point sweep per launch), both ways
     stress = None
-    if not a.no_stress and ctx.world_size == 1:
+    if not a.no_stress:
+        # every rank: its own sweeps (seed = global sweep id), its own rotating outputs; at N > 1 the wall loops are
+        # bracketed by barriers (sweeps_per_s = all ranks' sweeps over the slowest rank's time) and `per_rank` carries
+        # min / max over the ranks of the kernel's duration and fraction -- no collective inside a loop
         c5 = VoxelConfig.square(C5["half"], C5["step"], C5["P"], C5["N"])
         v5 = PillarVoxelizer(c5, device=dev)
         pts5 = torch.from_numpy(np.stack([synth.lidar_like(C5["n"], C5["half"], s) for s in sweep_ids])).to(dev)
         out5 = rotating_outputs(a.batch, C5["P"], C5["N"], dev)
         b5 = c5.algorithmic_bytes(C5["n"]) * a.batch
-        r5 = vox_both(v5, pts5, out5, b5, iters=100)
+        r5 = vox_both(v5, pts5, out5, b5, iters=100, ctx=ctx, dev=dev)
         dt3, k3 = r5["three_launch"]["us_per_step"] * 1e-6, r5["three_launch"]["kernels_us"]
         best = min(dt3, r5["us_per_step"] * 1e-6)
-        stress = {"workload": f"configs[4] shapes on one GPU: {a.batch} x {C5['n']}-pt clouds, 1000x1000 grid, "
+        on = "one GPU" if ctx.world_size == 1 else f"each of {ctx.world_size} GPUs"
+        stress = {"workload": f"configs[4] shapes on {on}: {a.batch} x {C5['n']}-pt clouds, 1000x1000 grid, "
                               f"P={C5['P']} N={C5['N']}, voxelizer only",
                   # beyond the Infinity Cache the three-launch path can be the faster one at this batch (the
                   # binning stages are issue-bound at 800k points and k_step's roles share the workgroup slots)
-                  "sweeps_per_s": a.batch / best, "us_per_step": best * 1e6, "wall_frac": b5 / best / HBM_PEAK,
+                  "sweeps_per_s": ctx.world_size * a.batch / best, "us_per_step": best * 1e6,
+                  "wall_frac": b5 / best / HBM_PEAK,
                   "roofline": roofline_record(k3, 64, b5, *static_traffic(f"c5_batch{a.batch}")),
                   "pipelined": {k: r5[k] for k in ("sweeps_per_s", "us_per_step", "wall_frac", "k_step_us",
                                                    "kernel_frac")},
                   "three_launch_us_per_step": dt3 * 1e6,
                   "output_buffers": len(out5),
                   "one_sweep_per_launch": vox_both(v5, pts5[:1], rotating_outputs(1, C5["P"], C5["N"], dev),
-                                                   b5 // a.batch, iters=100)}
+                                                   b5 // a.batch, iters=100, ctx=ctx, dev=dev)}
+        if ctx.world_size > 1:
+            stress["n_gpus"] = ctx.world_size
+            stress["per_rank"] = r5["per_rank"]
         del v5, pts5, out5
         torch.cuda.empty_cache()
+        # ... and configs[4]'s canvas END TO END (SURVEY section 7 hard part 8: up3's output_padding is 3 at 1000x1000):
+        # the pipelined forward, voxelizer + network, on the 200k-point sweeps
+        if a.mode == "fwd":
+            torch.backends.cudnn.benchmark = True
+            p5 = PillarPipeline(c5, device=dev, seed=0)
+            p5.model.eval()
+            b_e = min(a.batch, 2)
+            pts_e = [torch.from_numpy(np.stack([synth.lidar_like(C5["n"], C5["half"], 2000 * r + s)
+                                                for s in sweep_ids[:b_e]])).to(dev) for r in range(2)]
+            turn5 = [0]
+
+            def step5():
+                turn5[0] += 1
+                return p5.forward_pipelined(pts_e[turn5[0] % 2])
+            for _ in range(3 + PillarVoxelizer.LAG):
+                step5()
+            n5 = max(4, a.steps // 2)
+            p5.voxelizer.set_timing(n5)
+            el5 = timed_loop(step5, n5)
+            k5, _ = kernel_means_us(p5.voxelizer)
+            p5.voxelizer.set_timing(0)
+            for _ in range(PillarVoxelizer.LAG):
+                p5.forward_pipelined(None)
+            b5e = c5.algorithmic_bytes(C5["n"]) * b_e
+            stress["end_to_end"] = {
+                "value": n5 * b_e * ctx.world_size / el5, "unit": "sweeps/s", "ms_per_step": el5 / n5 * 1e3, "steps": n5,
+                "sweeps_per_gpu_per_step": b_e, "k_step_us": k5.get("k_step"),
+                "k_step_frac": b5e / (k5["k_step"] * 1e-6) / HBM_PEAK,
+                "up3_output_padding": int(p5.model.backbone.up3.conv2d_t.output_padding[0]),
+                "what": "configs[4]'s sizes end to end: HIP voxelizer (k_step) + PPFeatureNet + scatter + backbone + head "
+                        "forward at the 1000x1000 canvas, f32, inference, software-pipelined like the headline"}
+            del p5, pts_e
+            torch.cuda.empty_cache()
 
     # the reference's SHIPPED configuration (config.py:46-61,109-123): 600x600 grid, P=24000, N=200 (every
     # bucket cap above the 128-point LDS pool, 172.8 MB per sweep), 6 anchors per cell = 540 000 anchors
@@ -823,8 +1057,9 @@ def main():
                             "world_size": torch.distributed.get_world_size() if ctx.distributed else 1,
                             "in_timed_step": "none (sweeps shard; no data-path collective)" if a.mode == "fwd"
                             else "positive-count, gradient and loss-scalar all-reduces"},
-            "roofline": roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc, three=three_e2e,
-                                        step_kernel=pipe.voxelizer.step_kernel_name(a.batch)),
+            "roofline": dict(roofline_record(kern_us, launches, bytes_per_launch, traffic, tsrc, three=three_e2e,
+                                             step_kernel=pipe.voxelizer.step_kernel_name(a.batch)),
+                             ranks_min_max=head_ranks),
             # the headline's definition, for comparisons across rounds: a software pipeline whose outputs lag
             # `latency_calls` calls; `three_launch_value` is the same forward with three dependent launches per step
             "pipelined": bool(pipelined), "latency_calls": PillarVoxelizer.LAG if pipelined else 0,
@@ -835,6 +1070,9 @@ def main():
             out["roofline"]["traffic_static"] = traffic
             out["roofline"]["traffic"] = traffic_live[0]
             out["roofline"]["traffic_detail"] = traffic_live[1]
+            # MI355X_MICROARCH.md's gfx950 correction: FETCH_SIZE under-reports 16-byte-per-lane streaming reads (the
+            # split and prefetch roles' float4 streams) by up to 2x -- the reading with FETCH doubled, beside the raw one
+            out["roofline"]["traffic_fetch_x2"] = traffic_live[1]["FETCH_SIZE_bytes_x2"] + traffic_live[1]["WRITE_SIZE_bytes"]
             out["roofline"]["traffic_source"] = (
                 "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child runs of "
                 "`bench.py --headline-only`, --kernel-trace only), median per launch of the headline's k_step "
@@ -857,6 +1095,10 @@ def main():
             out["stress_c5"] = stress
         if refdef is not None:
             out["reference_default"] = refdef
+        if not a.no_dropin and not a.headline_only and ctx.world_size == 1:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            out["dropin_host"] = dropin_host()
         if not a.no_cpu_baseline and ctx.world_size == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -39,3 +39,23 @@ def test_roofline_record_reports_both_peaks():
     assert three["pipeline_frac"] < three["frac"] < 1
     s_key, src = b.static_traffic("step_batch4")
     assert s_key and 1.0 < s_key / 177_792_000 < 1.35 and src.startswith("static")
+
+
+def test_dropin_record_arithmetic():
+    b = _bench()
+    r = b.dropin_record(0.4, 10.0, "x")
+    assert abs(r["speedup"] - 25.0) < 1e-12 and r["meets_50x"] is False and r["hip_ms"] == 0.4 and r["cpu_ms"] == 10.0
+    assert b.dropin_record(0.1, 5.0, "x")["meets_50x"] is True          # exactly 50x counts
+    assert b.dropin_record(0.1, 4.99, "x")["meets_50x"] is False
+
+
+def test_per_rank_and_min_max_single_process():
+    """the N = 1 forms of the per-rank helpers (the 2-rank forms run in tests/test_shard_gloo.py and, on the GPU, in
+    tests/test_gpu_bench_ranks.py)"""
+    from pp_amd import shard
+    b = _bench()
+    ctx = shard.ShardContext()
+    assert b.per_rank(ctx, [1.5, 2.5]) == [[1.5, 2.5]]
+    mm = b.ranks_min_max(ctx, 40.0, 177_792_000)
+    assert mm["k_step_us"] == [40.0, 40.0] and mm["per_rank_k_step_us"] == [40.0]
+    assert abs(mm["frac"][0] - 177_792_000 / 40e-6 / 8e12) < 1e-12 and mm["frac"][0] == mm["frac"][1]

@@ -28,7 +28,9 @@ def _free_port():
 @pytest.mark.parametrize("mode", ["fwd", "train"])
 def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
     args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-            "--train-steps", "2", "--backend", "gloo", "--mode", mode, "--no-cpu-baseline", "--no-stress"]
+            "--train-steps", "2", "--backend", "gloo", "--mode", mode, "--no-cpu-baseline"]
+    if mode == "train":
+        args.append("--no-stress")
     if mode == "fwd":
         # the way the driver starts it: plain `python bench.py --gpus N`, no launcher, no WORLD_SIZE --
         # bench.py starts the N rank processes itself (before any GPU call in the parent)
@@ -36,7 +38,7 @@ def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
-    env = dict(os.environ, TMPDIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TMPDIR=str(tmp_path))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -72,9 +74,36 @@ def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
             assert c3[leg]["value"] > 0 and abs(c3[leg]["value"] - 2 * c3[leg]["steps"] /
                                                (c3[leg]["ms_per_step"] * c3[leg]["steps"] * 1e-3)) < 1e-6 * c3[leg]["value"]
         assert c3["allreduce_ms"] > 0
+        # ... with the roofline records of the two kernels every rank runs at one sweep per step, min / max over ranks
+        r3 = c3["roofline"]
+        assert r3["kernel"].startswith("pp::k_step") and r3["bytes_per_launch"] == 44_448_000
+        mm = r3["ranks_min_max"]
+        assert len(mm["per_rank_avg_launch_us"]) == 2 and mm["avg_launch_us"][0] <= mm["avg_launch_us"][1]
+        assert 0 < mm["frac"][0] <= mm["frac"][1] <= 1
+        assert abs(mm["per_rank_avg_launch_us"][0] - r3["avg_launch_us"]) < 1e-6     # rank 0 prints its own
+        t3 = c3["targets"]
+        assert t3["bytes_per_launch"] == 112 * 125000 and t3["moved_bytes"] == 72 * 125000
+        assert len(t3["ranks_min_max"]["per_rank_us_per_call"]) == 2 and t3["us_per_call"] > 0
+        # the headline's own spread over the ranks
+        hm = rf["ranks_min_max"]
+        assert len(hm["per_rank_avg_launch_us"]) == 2 and abs(hm["per_rank_avg_launch_us"][0] - rf["avg_launch_us"]) < 1e-6
+        assert hm["frac"][0] <= rf["frac"] + 1e-9 <= hm["frac"][1] + 2e-9
+        # BASELINE configs[4] ("8xMI355X stress") at N > 1: every rank its own 200k-point sweeps, whole-job rate,
+        # per-rank kernel fractions; and the 1000x1000 canvas end to end
+        s5 = out["stress_c5"]
+        assert s5["n_gpus"] == 2 and "each of 2 GPUs" in s5["workload"]
+        pr = s5["per_rank"]
+        assert len(pr["per_rank_k_step_us"]) == 2 and pr["k_step_us"][0] <= pr["k_step_us"][1]
+        assert 0 < pr["kernel_frac"][0] <= pr["kernel_frac"][1] <= 1
+        assert abs(s5["pipelined"]["sweeps_per_s"] - 2 * out["config"]["sweeps_per_gpu_per_step"] /
+                   (s5["pipelined"]["us_per_step"] * 1e-6)) < 1e-6 * s5["pipelined"]["sweeps_per_s"]
+        assert s5["one_sweep_per_launch"]["n_gpus"] == 2 and len(
+            s5["one_sweep_per_launch"]["per_rank"]["per_rank_k_step_us"]) == 2
+        e5 = s5["end_to_end"]
+        assert e5["value"] > 0 and e5["up3_output_padding"] == 3 and 0 < e5["k_step_frac"] <= 1
         assert out["pipelined"] is True and out["latency_calls"] == 3 and out["three_launch_value"] > 0
         assert out["overlapped"]["value"] > 0 and out["overlapped"]["latency_calls"] == 4
-        assert "cpu_baseline" not in out and "stress_c5" not in out     # N = 1 legs only
+        assert "cpu_baseline" not in out and "dropin_host" not in out and "reference_default" not in out   # N = 1 legs only
     # every rank used its own MIOpen directories under TMPDIR
     roots = [d for d in os.listdir(tmp_path) if d.startswith("pp_miopen_")]
     assert roots and sorted(os.listdir(os.path.join(tmp_path, roots[0]))) == ["rank0", "rank1"]

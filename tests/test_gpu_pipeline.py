@@ -407,3 +407,100 @@ def test_forward_overlapped_equals_forward(gpu):
     for (c, r), (wc, wr) in zip(outs, want):
         assert c.shape == wc.shape
         assert (c - wc).abs().max().item() <= 2e-6 and (r - wr).abs().max().item() <= 2e-6
+
+
+def test_forward_overlapped_orders_fresh_non_blocking_clouds(gpu):
+    """clouds produced on the caller's stream right before the call (a non_blocking copy from pinned memory
+    behind a long-running kernel) and dropped right after it.  The side stream must wait for the producer (an event
+    recorded at entry) and hold the tensor's memory (record_stream) -- otherwise k_step voxelizes whatever the block
+    held before, or what the next main-stream allocation writes into it."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    pipe = PillarPipeline(VoxelConfig.square(16.0, 0.2, 4000, 32), feature_channels=16, device=gpu, seed=0)
+    pipe.model.eval()
+    host = [torch.from_numpy(np.stack([synth.lidar_like(15000, 16.0, 10 * k + s) for s in range(2)])).pin_memory()
+            for k in range(6)]
+    want = [tuple(x.clone() for x in pipe.forward(h.to(gpu))) for h in host]
+    torch.cuda.synchronize()
+    busy = torch.empty(512 << 20, dtype=torch.uint8, device=gpu)
+    outs, lag = [], pipe.voxelizer.LAG + 1
+    for k in range(len(host) + lag):
+        if k < len(host):
+            for _ in range(4):
+                busy.add_(1)                                    # the copy below queues behind ~1 ms of work
+            c = host[k].to(gpu, non_blocking=True)
+            r = pipe.forward_overlapped(c)
+            del c                                               # the caller drops the cloud at once ...
+            junk = torch.full((2, 15000, 4), float("nan"), device=gpu)   # ... and the same block size is asked for again
+            del junk
+        else:
+            r = pipe.forward_overlapped(None)
+        assert (r is None) == (k < lag)
+        if r is not None:
+            outs.append(tuple(x.clone() for x in r))
+    torch.cuda.synchronize()
+    assert len(outs) == len(host)
+    for (c, r), (wc, wr) in zip(outs, want):
+        assert torch.isfinite(c).all() and (c - wc).abs().max().item() <= 2e-6 and (r - wr).abs().max().item() <= 2e-6
+
+
+def test_fused_forms_fall_back_to_the_dense_path_with_a_data_mean(gpu):
+    """One behaviour for one condition: with a dataset mean both fused forms run the dense path --
+    forward_fused like forward, forward_fused_pipelined like forward_pipelined (same lag)."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    cfg = VoxelConfig.square(16.0, 0.2, 3000, 16)
+    mean = np.random.default_rng(0).normal(0, 0.1, 9 * 3000 * 16).astype(np.float32)
+    pipe = PillarPipeline(cfg, feature_channels=16, device=gpu, seed=0, data_mean=mean)
+    pipe.model.eval()
+    clouds = [torch.from_numpy(synth.lidar_like(9000, 16.0, s)).to(gpu) for s in range(3)]
+    want = [tuple(x.clone() for x in pipe.forward(c)) for c in clouds]
+    got = [tuple(x.clone() for x in pipe.forward_fused(c)) for c in clouds]
+    outs = []
+    for c in clouds + [None] * pipe.voxelizer.LAG:
+        r = pipe.forward_fused_pipelined(c)
+        if r is not None:
+            outs.append(tuple(x.clone() for x in r))
+    assert len(outs) == 3
+    for w, g, o in zip(want, got, outs):
+        assert torch.equal(w[0], g[0]) and torch.equal(w[1], g[1]) and torch.equal(w[0], o[0]) and torch.equal(w[1], o[1])
+
+
+def test_configs4_canvas_end_to_end(gpu, oracle):
+    """BASELINE configs[4]'s sizes through the whole forward on the GPU (SURVEY section 7 hard part 8: at a 1000x1000 canvas
+    the stride-4 up block needs output_padding 3, model/model.py:122-129): 200k-point sweep, P=30000, B=1.  forward ==
+    the model on the oracle's pillars; the fused one-launch form agrees within 1e-4."""
+    import torch
+    from pp_amd import synth
+    from pp_amd.pipeline import PillarPipeline
+    from pp_amd.voxelizer import VoxelConfig
+    from util import oracle_stage
+    cfg = VoxelConfig.square(100.0, 0.2, 30000, 100)
+    pipe = PillarPipeline(cfg, device=gpu, seed=0)
+    pipe.model.eval()
+    assert pipe.model.backbone.up3.conv2d_t.output_padding == (3, 3)
+    pts = synth.lidar_like(200000, 100.0, 5)
+    dpts = torch.from_numpy(pts).to(gpu)
+    cl, rg = pipe.forward(dpts)
+    assert cl.shape == (1, 18, 500, 500) and rg.shape == (1, 16, 500, 500)
+    ref_p, ref_i, m = oracle_stage(oracle, pts, 30000, 100, 100.0, 0.2, order=cfg.order)
+    assert m > 30000                                            # the overflow regime, as in the bench
+    with torch.no_grad():
+        cl2, rg2 = pipe.model(torch.from_numpy(ref_p)[None].to(gpu), torch.from_numpy(ref_i)[None].to(gpu))
+    assert torch.equal(cl, cl2) and torch.equal(rg, rg2)
+    cl, rg = cl.clone(), rg.clone()
+    outs = []
+    for c in [dpts, dpts] + [None] * pipe.voxelizer.LAG:
+        r = pipe.forward_fused_pipelined(c)
+        if r is not None:
+            outs.append((r[0].clone(), r[1].clone()))
+    assert len(outs) == 2
+    for c, r in outs:
+        assert (c - cl).abs().max().item() <= 1e-4 and (r - rg).abs().max().item() <= 1e-4
+    # the dense pipelined form: bit-identical to forward
+    outs = [pipe.forward_pipelined(c) for c in [dpts] + [None] * pipe.voxelizer.LAG]
+    assert torch.equal(outs[-1][0], cl) and torch.equal(outs[-1][1], rg)

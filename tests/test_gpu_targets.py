@@ -507,6 +507,35 @@ def test_box_centric_many_positives(gpu, oracle, thresh, lo, hi):
     assert lo <= n_pos[0] <= hi, n_pos                  # the sample really takes the path this case is about
 
 
+def test_box_centric_more_candidates_than_64_workgroups_hold(gpu, oracle):
+    """at fm_scale = 1 with six anchors per cell a box has 23 x 23 x 6 = 3174 candidate anchors -- more than
+    the 64 PAIR workgroups per box x 32 candidates the launch is clamped to, so every workgroup strides over several
+    windows and, with a low threshold, one box has more pairs above it than 64 x 32.  The positive list is sized from
+    the candidate count (nothing dropped, no error flag), and a second assigner with another grid on the SAME context
+    kind re-arms its scratch (the layout key is compared field by field)."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    ref = boxes.AnchorConfig.reference_default()
+    cfg = boxes.AnchorConfig(80, 80, 1.0, ref.dims, ref.yaws_deg, ref.zs)
+    gts = [synth.gt_boxes(3, 80, 41, margin=25.0), synth.gt_boxes(2, 80, 42, margin=25.0)]
+    n_pos = _both_forms_and_oracle(gpu, oracle, cfg, 80, gts, 0.05, classes=9)
+    assert max(n_pos) > 700, n_pos
+    # the same assigner object (one context) asked for another grid shape in between: results stay right
+    ta = TargetAssigner(cfg, canvas_height=80, pos_thresh=0.05, device=gpu)
+    c0, r0 = ta.assign_batch(gts, check=True)
+    small = boxes.AnchorConfig(40, 40)
+    tb = TargetAssigner(small, canvas_height=80, device=gpu)
+    tb._ctx = ta._ctx                                   # two grids, ONE context
+    g2 = synth.gt_boxes(6, 80, 5, margin=15.0)
+    want = TargetAssigner(small, canvas_height=80, device=gpu).assign(g2["centers"], g2["wlh"], g2["yaw"], g2["classes"])
+    got = tb.assign(g2["centers"], g2["wlh"], g2["yaw"], g2["classes"], check=True)
+    c1, r1 = ta.assign_batch(gts, check=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+
+
 def test_box_centric_odd_sizes_misaligned_samples_and_boxes_off_the_map(gpu, oracle):
     """A = 81 anchors x 3 classes: the second and third sample's rows start off 16 bytes (the zero fill's head / tail
     paths); more list slots per box than the anchor-centric form has workgroups; boxes whose gate window lies

@@ -540,12 +540,12 @@ def test_pipelined_mode_soak(gpu):
     assert not bad, bad[:10]
 
 
-def test_pipelined_mode_stream_is_enforced_and_failed_submit_resets(gpu):
+def test_pipelined_mode_stream_is_enforced_and_refused_submit_changes_nothing(gpu):
     """pp_voxelize_step_dev carries a batch from role to role by STREAM ORDER: a submit on another stream while
     batches are in flight is refused (PP_ERR_VALUE, "another stream") instead of racing; once drained, any stream
-    may start the next pipeline.  And a submit that is rejected in the middle of a full pipeline (here: more
-    sweeps than PP_MAX_BATCH) abandons the batches in flight on BOTH sides -- the next submits start an empty
-    pipeline instead of failing with 'a batch is due'."""
+    may start the next pipeline.  A refusal -- that one, or a bad argument in the middle of a full pipeline (here:
+    more sweeps than PP_MAX_BATCH) -- changes NOTHING on either side (include/pp_hip.h): the batches in
+    flight come out, in order, on their own stream."""
     import torch
     from pp_amd import synth
     half, step, P, N = 20.0, 0.25, 2000, 16
@@ -558,7 +558,11 @@ def test_pipelined_mode_stream_is_enforced_and_failed_submit_resets(gpu):
     with torch.cuda.stream(other):
         with pytest.raises(ValueError, match="another stream"):
             b.submit(ts[2])
-    # the refusal reset the pipeline (one rule for every failed submit): start again, on the other stream
+    # the two batches are still in flight: they come out on their own stream, then the pipeline is empty
+    got = [b.submit(None) for _ in range(b.LAG)]
+    torch.cuda.synchronize()
+    assert got[0] is None and all(torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) for g, w in zip(got[1:], want))
+    # drained: the other stream may start the next pipeline
     with torch.cuda.stream(other):
         outs = list(b.stream(ts))
     other.synchronize()
@@ -584,7 +588,11 @@ def test_pipelined_mode_stream_is_enforced_and_failed_submit_resets(gpu):
     too_many = torch.zeros((33, 16, 4), device=gpu)                 # PP_MAX_BATCH is 32
     with pytest.raises(ValueError):
         d.submit(too_many)
-    assert d.submit(None) is None                                    # nothing is due any more, on either side
+    # the three good batches are still in flight, on both sides: they drain in order
+    outs = [d.submit(None) for _ in range(d.LAG)]
+    torch.cuda.synchronize()
+    assert all(o is not None and torch.equal(o[0], w[0]) and torch.equal(o[1], w[1]) for o, w in zip(outs, want))
+    assert d.submit(None) is None                                    # ... and the pipeline is empty
     outs = list(d.stream(ts[:2]))
     torch.cuda.synchronize()
     assert len(outs) == 2 and torch.equal(outs[0][0], want[0][0]) and torch.equal(outs[1][1], want[1][1])

@@ -152,3 +152,42 @@ def test_sharded_gradients_equal_the_gathered_batch_loss():
 
 def test_rank_without_positives_contributes_zero_not_nan():
     _run_dp(1)
+
+
+def _bench_ranks_worker(rank, world, port, q):
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from pp_amd import shard
+    spec = importlib.util.spec_from_file_location("pp_bench_ranks", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = b
+    spec.loader.exec_module(b)
+    ctx = shard.init_from_env("gloo")
+    rows = b.per_rank(ctx, [10.0 + rank, 100.0 * (rank + 1)])
+    mm = b.ranks_min_max(ctx, 30.0 + 10.0 * rank, 8.0e12 * 30e-6 * 0.5)     # rank 0: 0.5 of the peak, rank 1: 0.375
+    q.put((rank, rows, mm))
+    shard.barrier(ctx)
+    shard.shutdown(ctx)
+
+
+def test_bench_per_rank_records_over_two_ranks():
+    """bench.py's per-rank roofline spread (roofline.ranks_min_max, stress_c5.per_rank, configs3 records): every rank
+    ends up with every rank's kernel time, min / max and the fractions, through ONE all-reduce after the loop."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_ranks_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, rows, mm in res:
+        assert rows == [[10.0, 100.0], [11.0, 200.0]]
+        assert mm["k_step_us"] == [30.0, 40.0] and mm["per_rank_k_step_us"] == [30.0, 40.0]
+        assert abs(mm["frac"][0] - 0.375) < 1e-12 and abs(mm["frac"][1] - 0.5) < 1e-12
