@@ -85,7 +85,8 @@ struct TargetArgs {
   int fm_h, gt_splits;       // feature-map rows; workgroups per ground truth
   int cand_per_wg;           // candidate anchors per PAIR workgroup (<= kCandPerWg)
   unsigned cand_per_gt;      // list entries reserved per ground truth (anchor-centric form: its workgroups)
-  struct PosEntry *pos;      // [boxes][pos_per_gt] pairs above the threshold {anchor, box, IoU}
+  struct PosKey *pos;        // [boxes][pos_per_gt] pairs above the threshold {anchor, box, IoU} ...
+  struct PosRow *pos_rows;   // ... and, index for index, their regression rows + the box's class
   unsigned pos_per_gt;
   unsigned *pos_count;       // per sample
   float *cand_rows;          // [boxes][gt_splits][kRowPitch]: the regression row of each column-list slot's pair
@@ -95,14 +96,22 @@ struct TargetArgs {
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
 };
-struct PosEntry {
+// A pair above the threshold is two records in two arrays, index for index: the 16-byte key the tail's threads read
+// side by side (lane e <-> key e: one wave-level load is 1024 consecutive bytes) and the 48-byte row.  (One 64-byte
+// record per pair, read field by field with the lanes 64 bytes apart, made every wave-level load of the tail touch
+// 64 lines and ask for every line a dozen times: 2 us between the last ticket and the first LDS phase.)
+struct PosKey {
   unsigned anchor, gt;
   u64 bits;
-  float row[9];  // the regression row of (anchor, box), worked out where the pair was clipped
-  float pad[3];
 };
-static_assert(sizeof(PosEntry) == 64, "pair entry layout");
-constexpr int kRowPitch = 12;  // floats between two rows of cand_rows (48 B)
+struct PosRow {
+  float row[9];  // the regression row of (anchor, box), worked out where the pair was clipped
+  int cls;       // the box's class
+  float pad[2];
+};
+static_assert(sizeof(PosKey) == 16 && sizeof(PosRow) == 48, "pair entry layout");
+constexpr int kRowPitch = 12;  // floats between two rows of cand_rows (48 B = three 16-byte groups)
+__device__ __forceinline__ ColEntry *cand_at(const TargetArgs &t, size_t e) { return t.cand + e; }
 
 constexpr int kTypeCols = 13;
 
@@ -136,6 +145,7 @@ __device__ __forceinline__ void sample_view(TargetArgs &t, const TargetBatch &bt
   t.col_win += o;
   t.cand += (size_t)t.cand_per_gt * (size_t)o;  // sample b appends at most cand_per_gt * G_b entries
   t.pos += (size_t)t.pos_per_gt * (size_t)o;
+  if (t.pos_rows) t.pos_rows += (size_t)t.pos_per_gt * (size_t)o;
   if (t.cand_rows) t.cand_rows += (size_t)t.cand_per_gt * (size_t)o * kRowPitch;
   t.pos_count += b * kCounterStride;
   if (t.best) {
@@ -266,6 +276,14 @@ __device__ __forceinline__ float target_quotient(double g_c, double a_c, double 
   const double den = c < 2 ? ad : a_h;
   return (float)((gq - a_c) / den);  // dx, dy, dz
 }
+// the same with the anchor's diagonal handed in (ad = sqrt(a_w * a_w + a_l * a_l), the expression above, evaluated once
+// per anchor TYPE instead of once per pair): same operands, same operations, same bits
+__device__ __forceinline__ float target_quotient_ad(double g_c, double a_c, double ad, double a_h, double canvas_height,
+                                                    int c) {
+  const double gq = c == 1 ? (canvas_height - 1) - g_c : g_c;  // box_utils.py:83
+  const double den = c < 2 ? ad : a_h;
+  return (float)((gq - a_c) / den);  // dx, dy, dz
+}
 __device__ __forceinline__ float target_logratio(double g_s, double a_s) {
   return (float)log(g_s / a_s);  // dw, dl, dh
 }
@@ -335,6 +353,9 @@ struct TgtLds {
   float rstage[kTgtThreads * 9];          // the regression rows on their way out
   int gcls[kGtChunk];                     // classes of the chunk's ground truths
   double gv7[8];                          // box-centric form: x, y, z, w, l, h, yaw of the workgroup's box
+  double rc_ad[kLdsTypes];                // ... per anchor type of the cell: sqrt(w^2 + l^2) (box_utils.py:79)
+  float rc_lg[kLdsTypes][3];              // ... log(gw/aw), log(gl/al), log(gh/ah) (:88-90)
+  float rc_dt[kLdsTypes], rc_ort[kLdsTypes];  // ... sin(gt - at), the orientation bit (:92-102)
   float colrow[12];                       // ... the regression row of its column maximum's pair
   u64 need;                               // ... which lanes' pairs need a row
   u64 cmax[kGtChunk], cseen[kGtChunk];    // column maximum of this workgroup / as of the last window
@@ -603,8 +624,8 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T, int n_fixed = -1) 
     const unsigned e = (unsigned)(k * kTgtThreads + tid);
     e_key[k] = e_bits[k] = 0ull;  // an entry's maximum is never 0
     if (e < n) {
-      e_key[k] = ld_agent(&t.cand[e].key);
-      e_bits[k] = ld_agent(&t.cand[e].bits);
+      e_key[k] = ld_agent(&cand_at(t, e)->key);
+      e_bits[k] = ld_agent(&cand_at(t, e)->bits);
     }
   }
   IOU_STAMP(11);
@@ -620,7 +641,7 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T, int n_fixed = -1) 
   for (int k = 0; k < kTailBatch; ++k)
     if (e_bits[k]) atomicMax(cmax_at((int)(e_key[k] & 0xFFFFFFFFull)), e_bits[k]);
   for (unsigned e = kTailBatch * kTgtThreads + tid; e < n; e += kTgtThreads)
-    atomicMax(cmax_at((int)(ld_agent(&t.cand[e].key) & 0xFFFFFFFFull)), ld_agent(&t.cand[e].bits));
+    atomicMax(cmax_at((int)(ld_agent(&cand_at(t, e)->key) & 0xFFFFFFFFull)), ld_agent(&cand_at(t, e)->bits));
   sync();
   // the first anchor that reaches the maximum, and the entry it came in
 #pragma unroll
@@ -630,9 +651,9 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T, int n_fixed = -1) 
       atomicMin(cwin_at(j), (e_key[k] & 0xFFFFFFFF00000000ull) | (unsigned)(k * kTgtThreads + tid));
   }
   for (unsigned e = kTailBatch * kTgtThreads + tid; e < n; e += kTgtThreads) {
-    const u64 key = ld_agent(&t.cand[e].key);
+    const u64 key = ld_agent(&cand_at(t, e)->key);
     const int j = (int)(key & 0xFFFFFFFFull);
-    const u64 b = ld_agent(&t.cand[e].bits);
+    const u64 b = ld_agent(&cand_at(t, e)->bits);
     if (b != 0ull && b == cmax_ld(j)) atomicMin(cwin_at(j), (key & 0xFFFFFFFF00000000ull) | e);
   }
   sync();
@@ -868,6 +889,7 @@ __device__ void targets_tail(const TargetArgs &t, TailLds &T, int n_fixed = -1) 
   if (tid == 0) {
     *t.cand_count = 0u;
     *t.ticket = 0u;
+    t.ticket[1] = 0u;  // (the box-centric form counts in 64 bits: groups done | pairs above the threshold)
   }
 }
 
@@ -1009,7 +1031,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     if ((tb >> lane) & 1ull) {
       const unsigned pos = base + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
-      ColEntry *ce = t.cand + pos;
+      ColEntry *ce = cand_at(t, pos);
       __hip_atomic_store(&ce->key, (u64)(unsigned)(j0 + lane) | ((u64)(unsigned)S.carg[lane] << 32), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&ce->bits, S.cmax[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1422,7 +1444,7 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
         const int c = t.g_class[e_j[k]];
         if ((unsigned)c < (unsigned)t.num_classes) t.cls_targets[(int64_t)e_i[k] * t.num_classes + c] = 1.0f;
         // regression row (box_utils.py:219-221): the PAIR workgroup that clipped the pair worked it out
-        const float *src = t.pos[k * kTgtThreads + tid].row;
+        const float *src = t.pos_rows[k * kTgtThreads + tid].row;
         float *reg = t.reg_targets + (int64_t)e_i[k] * 9;
         float rv[9];
 #pragma unroll
@@ -1459,7 +1481,7 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
           float *reg = t.reg_targets + (int64_t)i * 9;
 #pragma unroll
           for (int d = 0; d < 9; ++d)
-            reg[d] = __hip_atomic_load(t.pos[e].row + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            reg[d] = __hip_atomic_load(t.pos_rows[e].row + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -1477,195 +1499,149 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
 }
 
 // The box-centric tail in its usual shape -- at most 64 boxes, 1024 list slots, 256 pairs above the threshold,
-// 63 classes -- as ONE pass: every global load it needs (the pair counter, the pair entries with their rows and
-// classes, the column slots, the boxes' classes) is issued up front and in flight together, the positives' hash
-// and the column argmax share their two LDS phases, and the only dependent round trip left is the forced rows'
-// fetch.  (positives_tail + targets_tail, one after the other: 6.6 us of the launch's 16; this: see NOTES.)
-// Returns false -- workgroup-uniformly, before it has written anything -- when the sample does not fit.
-constexpr int kFastPos = 256, kFastHash = 512;
+// 63 classes -- which the caller knows BEFORE anything is loaded: the number of pairs above the threshold arrives with
+// the last ticket (the tickets count in 64 bits: workgroups done | the pairs they stored).
+// Round 5, what the stamps said about round 4's form at one sample per launch (tools/lab/gt_stamps.py): last ticket ->
+// entries in registers 2.0 us (18 dword loads per thread with the lanes 64 bytes apart: a wave-level load touched 64
+// lines and every line was asked for a dozen times), LDS phases 0.8, the forced rows' fetch and the drain in front of
+// it 1.2, end 0.4.  And what a first rebuild showed (every record's row kept in the registers of the lanes that
+// loaded it, twelve unrolled 16-byte groups per lane: SLOWER, 7 us in its last phase): the tail is code that ONE
+// workgroup executes ONCE per launch, on a CU that has never run it -- it runs at the speed its instructions arrive,
+// so it has to be short.  Hence
+//   * keys and rows live in separate arrays (PosKey / PosRow, ColEntry / cand_rows), thread e <-> record e: one
+//     16-byte load per key (a wave-level load is 1024 consecutive bytes), three per row of a pair; every load of the
+//     first round trip is issued before anything is waited for;
+//   * the two LDS phases (row maximum per anchor through a hash table + the first box reaching it; column maximum per
+//     box + the first anchor reaching it and its slot);
+//   * then wave 0, lane = box, fetches the forced rows from the winning slots (the one dependent round trip left;
+//     loading ALL slots' rows with the first round trip instead was measured: +0.6 us there, nothing gained here) and,
+//     while they are on their way, lets the boxes that force the same anchor meet in the SAME hash table (class mask by
+//     atomicOr, the last box by atomicMax: round 4's ballot-per-index-bit search was 1.3 us of once-executed code) --
+//     which also tells the positives that this anchor's rows are the forced ones: a positive's row is simply not
+//     written where a forced row goes, so no store has to be down before another one;
+//   * winners' rows go out from registers; nothing is evaluated here.
+constexpr int kFastPos = 256, kFastHash = 512, kFastSlots = 4;  // slots per thread
 struct FastTailLds {
-  unsigned key[kFastHash];   // anchor + 1 (0 = empty)
-  u64 bits[kFastHash];       // the anchor's highest IoU
-  unsigned minj[kFastHash];  // the first box reaching it
+  unsigned key[kFastHash];     // anchor + 1 (0 = empty): anchors with a pair above the threshold, and forced anchors
+  u64 bits[kFastHash];         // the anchor's highest IoU
+  unsigned minj[kFastHash];    // the first box reaching it
+  u64 fmask[kFastHash];        // classes of ALL boxes forcing this anchor (0: no box forces it)
+  int flast[kFastHash];        // the last box forcing it
   u64 colmax[64], colwin[64];
-  int cls[64];
-  unsigned later[64];
 };
 static_assert(sizeof(FastTailLds) <= kTgtLdsBytes, "the fast tail reuses the workgroup's LDS");
 
-__device__ bool tail_gt_fast(const TargetArgs &t, unsigned char *smem, int nslots) {
+__device__ __forceinline__ unsigned fast_hash_slot(FastTailLds &F, unsigned anchor) {  // find or insert
+  unsigned h = (anchor * 2654435761u) >> (32 - 9);
+  static_assert(kFastHash == 512, "hash width");
+  for (;;) {  // at most 256 + 64 of the 512 slots are ever taken
+    const unsigned old = atomicCAS(&F.key[h], 0u, anchor + 1u);
+    if (old == 0u || old == anchor + 1u) return h;
+    h = (h + 1u) & (kFastHash - 1);
+  }
+}
+
+__device__ void tail_gt_fast(const TargetArgs &t, unsigned char *smem, int nslots, unsigned n) {
   FastTailLds &F = *reinterpret_cast<FastTailLds *>(smem);
   const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, G = t.G;
-  constexpr int kPer = kFastPos / kTgtThreads;
-  const unsigned cap = min((unsigned)G * t.pos_per_gt, (unsigned)kFastPos);
-  auto ldf = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  // ---- every load, speculatively (an entry beyond the counter is stale and ignored)
-  const unsigned n_raw = __hip_atomic_load(t.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned e_i[kPer], e_j[kPer];
-  u64 e_b[kPer];
-  int e_c[kPer];
-  float e_row[kPer][9];
+  // ---- the first round trip: every load (a record beyond its array reads zeros)
+  __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void *)t.pos, 0, (int)(n * 16u), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)t.pos_rows, 0, (int)(n * 48u), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)t.cand, 0, nslots * 16, 0x00020000);
+  const v4u pk = __builtin_amdgcn_raw_buffer_load_b128(rs_k, tid * 16, 0, kAuxSc1);  // {anchor, box, IoU}
+  v4u ck[kFastSlots];                                                                   // {box, anchor, IoU}
 #pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const unsigned e = (unsigned)(k * kTgtThreads + tid);
-    e_i[k] = e_j[k] = 0u;
-    e_b[k] = 0ull;
-    e_c[k] = -1;
-    if (e < cap) {
-      const PosEntry *pe = t.pos + e;
-      const u64 ij = ld_agent(reinterpret_cast<const u64 *>(pe));
-      e_i[k] = (unsigned)ij;
-      e_j[k] = (unsigned)(ij >> 32);
-      e_b[k] = ld_agent(&pe->bits);
-      e_c[k] = __float_as_int(ldf(pe->pad));
+  for (int k = 0; k < kFastSlots; ++k) ck[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (k * kTgtThreads + tid) * 16, 0, kAuxSc1);
+  v4u pr[3];
 #pragma unroll
-      for (int d = 0; d < 9; ++d) e_row[k][d] = ldf(pe->row + d);
-    }
-  }
-  u64 c_key[2], c_bits[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int e = k * kTgtThreads + tid;
-    c_key[k] = c_bits[k] = 0ull;
-    if (e < nslots) {
-      c_key[k] = ld_agent(&t.cand[e].key);
-      c_bits[k] = ld_agent(&t.cand[e].bits);
-    }
-  }
-  const int my_cls = tid < G ? t.g_class[tid] : 0;
-  if (n_raw > (unsigned)kFastPos || n_raw > (unsigned)G * t.pos_per_gt) return false;  // uniform: one word, every thread
-  const unsigned n = n_raw;
+  for (int c = 0; c < 3; ++c) pr[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, tid * 48 + c * 16, 0, kAuxSc1);
+  unsigned gc = (tid < G) ? (unsigned)t.g_class[tid] : 63u;  // wave 0, lane = box: its class
+  gc = gc < 63u ? gc : 63u;                                  // (63: a class outside the row, never written)
   // ---- LDS phase 0
   for (int h = tid; h < kFastHash; h += kTgtThreads) {
     F.key[h] = 0u;
     F.bits[h] = 0ull;
     F.minj[h] = ~0u;
+    F.fmask[h] = 0ull;
+    F.flast[h] = -1;
   }
   if (tid < 64) {
     F.colmax[tid] = 0ull;
     F.colwin[tid] = ~0ull;
-    F.cls[tid] = my_cls;
   }
   __syncthreads();
+  IOU_STAMP(11);
   // ---- phase 1: maxima (rows: per anchor through the hash table; columns: per box)
-  int slot[kPer];
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    slot[k] = -1;
-    if ((unsigned)(k * kTgtThreads + tid) < n) {
-      unsigned h = (e_i[k] * 2654435761u) >> (32 - 9);
-      static_assert(kFastHash == 512, "hash width");
-      for (;;) {  // the table is at most half full
-        const unsigned old = atomicCAS(&F.key[h], 0u, e_i[k] + 1u);
-        if (old == 0u || old == e_i[k] + 1u) break;
-        h = (h + 1u) & (kFastHash - 1);
-      }
-      slot[k] = (int)h;
-      atomicMax(&F.bits[h], e_b[k]);
-    }
+  const u64 pbits = (u64)pk[2] | ((u64)pk[3] << 32);
+  int slot = -1;
+  if ((unsigned)tid < n) {
+    slot = (int)fast_hash_slot(F, pk[0]);
+    atomicMax(&F.bits[slot], pbits);
   }
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
-    if (c_bits[k]) atomicMax(&F.colmax[(int)(c_key[k] & 0xFFFFFFFFull)], c_bits[k]);
-  // slots 512..1023 (the reference's six anchors per cell: 19 slots per box) are not kept in registers: loaded
-  // here, and once more in phase 2
-  for (int e = 2 * kTgtThreads + tid; e < nslots; e += kTgtThreads) {
-    const u64 b2 = ld_agent(&t.cand[e].bits);
-    if (b2) atomicMax(&F.colmax[(int)(ld_agent(&t.cand[e].key) & 0xFFFFFFFFull)], b2);
+  for (int k = 0; k < kFastSlots; ++k) {
+    const u64 b = (u64)ck[k][2] | ((u64)ck[k][3] << 32);
+    if (b != 0ull) atomicMax(&F.colmax[(int)ck[k][0]], b);
   }
   __syncthreads();
+  IOU_STAMP(12);
   // ---- phase 2: first box reaching a row's maximum; first anchor reaching a column's, and its list slot
+  if (slot >= 0 && pbits == F.bits[slot]) atomicMin(&F.minj[slot], pk[1]);
 #pragma unroll
-  for (int k = 0; k < kPer; ++k)
-    if (slot[k] >= 0 && e_b[k] == F.bits[slot[k]]) atomicMin(&F.minj[slot[k]], e_j[k]);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int j = (int)(c_key[k] & 0xFFFFFFFFull);
-    if (c_bits[k] && c_bits[k] == F.colmax[j])
-      atomicMin(&F.colwin[j], (c_key[k] & 0xFFFFFFFF00000000ull) | (unsigned)(k * kTgtThreads + tid));
-  }
-  for (int e = 2 * kTgtThreads + tid; e < nslots; e += kTgtThreads) {
-    const u64 b2 = ld_agent(&t.cand[e].bits), k2 = ld_agent(&t.cand[e].key);
-    const int j = (int)(k2 & 0xFFFFFFFFull);
-    if (b2 && b2 == F.colmax[j]) atomicMin(&F.colwin[j], (k2 & 0xFFFFFFFF00000000ull) | (unsigned)e);
+  for (int k = 0; k < kFastSlots; ++k) {
+    const u64 b = (u64)ck[k][2] | ((u64)ck[k][3] << 32);
+    const int j = (int)ck[k][0];
+    if (b != 0ull && b == F.colmax[j]) atomicMin(&F.colwin[j], ((u64)ck[k][1] << 32) | (unsigned)(k * kTgtThreads + tid));
   }
   __syncthreads();
-  // ---- the positives' rows (box_utils.py:211, 219-221), from registers
+  IOU_STAMP(13);
+  // ---- forced rows (box_utils.py:199-205, 212-213, 223-228), wave 0, lane = box: the row is fetched from the slot the
+  // column's argmax came in, and while it is on its way the boxes that force the same anchor meet in the hash table
+  // (the classes of all of them, the last of them: its regression row wins) -- which also tells the positives
+  // below that this anchor's rows are the forced ones
+  int i = 0, fslot = 0;
+  v4u fr[3] = {v4u{0u, 0u, 0u, 0u}, v4u{0u, 0u, 0u, 0u}, v4u{0u, 0u, 0u, 0u}};
+  if (wv == 0) {
+    const u64 w = (ln < G && F.colmax[ln] != 0ull) ? F.colwin[ln] : 0ull;
+    i = (int)(w >> 32);  // the anchor box ln forces; 0: none (an argmax of 0 is dropped, :204-205)
+    if (i != 0) {
+      __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc((void *)t.cand_rows, 0, nslots * kRowPitch * 4, 0x00020000);
+      const int off = (int)(unsigned)(w & 0xFFFFFFFFull) * (kRowPitch * 4);
 #pragma unroll
-  for (int k = 0; k < kPer; ++k)
-    if (slot[k] >= 0) {
-      if (e_b[k] == F.bits[slot[k]] && e_j[k] == F.minj[slot[k]]) {
-        if ((unsigned)e_c[k] < (unsigned)t.num_classes) t.cls_targets[(int64_t)e_i[k] * t.num_classes + e_c[k]] = 1.0f;
-        float *reg = t.reg_targets + (int64_t)e_i[k] * 9;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) reg[d] = e_row[k][d];
-      }
-      __hip_atomic_store(&t.best[e_i[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slow path's word
-    }
-  // ---- forced rows (box_utils.py:199-205, 212-213, 223-228): lane = box
-  const u64 w = (ln < G && F.colmax[ln] != 0ull) ? F.colwin[ln] : 0ull;
-  const int i = (int)(w >> 32);  // the anchor box ln forces; 0: none (an argmax of 0 is dropped, :204-205)
-  float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
-  u64 mask = 0ull;
-  if (wv == 3) {
-    // lanes forcing the same anchor find each other bit by bit: one ballot per bit of the anchor index
-    unsigned gc = (unsigned)F.cls[ln];
-    gc = gc < 63u ? gc : 63u;  // (63: a class outside the row, never written)
-    u64 same = G == 64 ? ~0ull : (1ull << G) - 1ull;
-    const int nbits = 32 - __clz((int)t.A);  // i < A
-    for (int b = 0; b < nbits; ++b) {
-      const bool bit = ((unsigned)i >> b) & 1u;
-      const u64 bal = __ballot(bit);
-      same &= bit ? bal : ~bal;
-    }
-    const bool later = ((same >> ln) >> 1) != 0ull;
-    u64 rest = i != 0 ? same : 0ull;
-    while (__ballot(rest != 0ull)) {  // as many turns as the largest group has members: one, as a rule
-      const int src = rest ? __ffsll((long long)rest) - 1 : ln;
-      const int c2 = __shfl((int)gc, src);
-      mask |= rest ? (1ull << c2) : 0ull;
-      rest &= rest - 1ull;
-    }
-    F.later[ln] = later ? 1u : 0u;
-  } else if (i != 0) {
-    const float *src = t.cand_rows + (size_t)(unsigned)(w & 0xFFFFFFFFull) * kRowPitch;  // the slot the argmax came in
-    if (wv == 0) {
-      r0 = ldf(src + 7), r1 = ldf(src + 8);
-    } else if (wv == 1) {
-      r0 = ldf(src + 4), r1 = ldf(src + 5);
-    } else {
-      r0 = ldf(src + 6), r1 = ldf(src + 1), r2 = ldf(src + 2), r3 = ldf(src + 3);
+      for (int c = 0; c < 3; ++c) fr[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_f, off + c * 16, 0, kAuxSc1);
+      fslot = (int)fast_hash_slot(F, (unsigned)i);
+      atomicOr(&F.fmask[fslot], 1ull << gc);
+      atomicMax(&F.flast[fslot], ln);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the positives' rows are down before a forced row overwrites one
   __syncthreads();
-  if (i != 0) {
-    if (wv == 3) {
-      float *cls = t.cls_targets + (int64_t)i * t.num_classes;
-      for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;
-    } else if (F.later[ln] == 0u) {
+  IOU_STAMP(14);
+  // ---- the positives' rows (box_utils.py:211, 219-221), from registers -- unless a box forces the anchor
+  if (slot >= 0) {
+    if (pbits == F.bits[slot] && pk[1] == F.minj[slot] && F.fmask[slot] == 0ull) {
+      const unsigned cl = pr[2][1];
+      if (cl < (unsigned)t.num_classes) t.cls_targets[(int64_t)pk[0] * t.num_classes + cl] = 1.0f;
+      float *reg = t.reg_targets + (int64_t)pk[0] * 9;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) reg[d] = __uint_as_float(pr[d >> 2][d & 3]);
+    }
+    __hip_atomic_store(&t.best[pk[0]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slow path's word
+  }
+  if (i != 0) {  // (wave 0)
+    const u64 mask = F.fmask[fslot];
+    float *cls = t.cls_targets + (int64_t)i * t.num_classes;
+    for (int c = 0; c < t.num_classes; ++c) cls[c] = ((mask >> c) & 1ull) ? 1.0f : 0.0f;  // every duplicate: the same row
+    if (F.flast[fslot] == ln) {
       float *reg = t.reg_targets + (int64_t)i * 9;
-      if (wv == 0) {
-        reg[0] = 1.0f;
-        reg[7] = r0;
-        reg[8] = r1;
-      } else if (wv == 1) {
-        reg[4] = r0;
-        reg[5] = r1;
-      } else {
-        reg[6] = r0;
-        reg[1] = r1;
-        reg[2] = r2;
-        reg[3] = r3;
-      }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) reg[d] = __uint_as_float(fr[d >> 2][d & 3]);
     }
   }
   if (tid == 0) {  // re-armed for the next call on this context
     *t.pos_count = 0u;
     *t.cand_count = 0u;
-    *t.ticket = 0u;
+    *reinterpret_cast<u64 *>(t.ticket) = 0ull;
   }
-  return true;
 }
 
 __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArgs t, TargetBatch bt) {
@@ -1677,6 +1653,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
   const int G = t.G, nsp = t.gt_splits;
   const unsigned u = blockIdx.y, n_units = (unsigned)kZeroWgs + (unsigned)G * (unsigned)nsp;
   if (u >= n_units) return;
+  unsigned npos_wg = 0u;
   IOU_STAMP(0);
   if (u < (unsigned)kZeroWgs) {
     zero_share(t.cls_targets, t.A * t.num_classes, (int)u, kZeroWgs, tid);
@@ -1685,29 +1662,38 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
   } else {
     const int pu = (int)u - kZeroWgs, j = pu / nsp, split = pu - j * nsp;
     const bool lds_types = t.per_cell <= kLdsTypes;
-    // the box: centre (every thread holds it), corners and area in LDS slot 0
-    const double gcx = t.g_centers_img[(int64_t)j * t.g_center_cols], gcy = t.g_centers_img[(int64_t)j * t.g_center_cols + 1];
-    if (tid < 4) {
-      const double *gp = t.g_corners + ((int64_t)j * 4 + tid) * 2;
-      S.gk[0][tid] = make_double2(gp[0], gp[1]);
-    }
-    if (lds_types && tid < t.per_cell * kTypeCols) S.types[0][tid] = t.types[tid];
-    if (tid >= 64 && tid < 71) {  // the box's values for the rows: x, y, z, w, l, h, yaw
-      const int c = tid - 64;
-      S.gv7[c] = c < 3 ? t.g_centers[j * 3 + c] : c < 6 ? t.g_wlh[j * 3 + c - 3] : t.g_yaw[j];
-    }
-    if (tid == 71) S.gcls[0] = t.g_class[j];
-    __syncthreads();
-    if (tid == 0) {
-      double g8[8];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        g8[2 * k] = S.gk[0][k].x;
-        g8[2 * k + 1] = S.gk[0][k].y;
+    // The prologue's global loads, ALL issued before any is waited for.  (A launch starts on cold caches: a load is
+    // ~1 us, and a wave that branches by lane role with a load inside each branch pays that once per branch -- the
+    // first version of this prologue spent 2.2 us there.)  Wave 1: the box (lane = value), wave 2 / 3: the anchor
+    // type table, and the operands of the logarithms (wave 2) / the sine (wave 3); every lane straight from global
+    // memory, no lane waits for another one's LDS store.
+    double ld0 = 0.0, ld1 = 0.0, rc_g = 0.0, rc_a = 1.0;
+    int ldi = 0;
+    if (wv == 1) {
+      const double *p0 = nullptr;
+      if (lane < 8) p0 = t.g_corners + (int64_t)j * 8 + lane;          // corners x0, y0 .. x3, y3
+      else if (lane < 11) p0 = t.g_centers + j * 3 + (lane - 8);       // the box's values for the rows: x, y, z,
+      else if (lane < 14) p0 = t.g_wlh + j * 3 + (lane - 11);          // w, l, h,
+      else if (lane == 14) p0 = t.g_yaw + j;                            // yaw
+      else if (lane >= 32 && lane < 32 + t.per_cell) p0 = t.types + (lane - 32) * kTypeCols + 8;  // a type's w ...
+      if (p0) ld0 = *p0;
+      if (lane >= 32 && lane < 32 + t.per_cell) ld1 = t.types[(lane - 32) * kTypeCols + 9];       // ... and l
+      if (lane == 15) ldi = t.g_class[j];
+    } else if (wv >= 2) {
+      const int k2 = tid - 2 * 64;  // 0..127
+      if (k2 < t.per_cell * kTypeCols) ld0 = t.types[k2];
+      if (wv == 2 && lane < t.per_cell * 3) {
+        const int d = lane / 3, k = lane - d * 3;
+        rc_g = t.g_wlh[j * 3 + k], rc_a = t.types[d * kTypeCols + 8 + k];
+      } else if (wv == 3 && lane < t.per_cell) {
+        rc_g = t.g_yaw[j], rc_a = t.types[lane * kTypeCols + 11];
       }
-      S.garea[0] = -shoelace_dev(g8, 4);
     }
-    IOU_STAMP(1);
+    // The box's image-space centre: every thread holds it (the candidate window, the gate).  Everything else the
+    // workgroup needs of the box is loaded by waves 1-3 WHILE wave 0 gates the first window (round 5; the box's
+    // loads and the gate used to be two phases with a barrier and a serial area in between: 2.2 us of the
+    // workgroup's 6.4), each lane straight from global memory -- no lane waits for another one's LDS store.
+    const double gcx = t.g_centers_img[(int64_t)j * t.g_center_cols], gcy = t.g_centers_img[(int64_t)j * t.g_center_cols + 1];
     // candidate cells: cell_centre(x) = (x + .5) / fm_scale within 10 of the box centre <=> x in [a, a + 20 * fm_scale]
     // with a = (gcx - 10) * fm_scale - .5; the window is that range in exact arithmetic plus ONE cell either side
     // (the gate below decides on the centre values themselves); a centre that is not finite passes the gate
@@ -1724,11 +1710,46 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
     const int ncx = max(x1 - x0 + 1, 0), ncy = max(y1 - y0 + 1, 0);
     const unsigned ncand = (unsigned)ncx * (unsigned)ncy * (unsigned)t.per_cell;  // <= A < 2^24
     u64 col_bits = 0ull;          // wave 0: this workgroup's column maximum for box j ...
+    // (npos_wg, below: the pairs above the threshold this workgroup stored; rides on its ticket)
     unsigned col_anchor = ~0u;    // ... and the first anchor reaching it
     bool bad = false;
     const unsigned cpw = (unsigned)t.cand_per_wg;
-    for (unsigned q0 = (unsigned)split * cpw; q0 < ncand; q0 += (unsigned)nsp * cpw) {
-      __syncthreads();  // the previous trip's LDS is read
+    IOU_STAMP(1);
+    if (wv == 1) {  // the box into LDS slot 0 (the loads were issued at the top)
+      if (lane < 8) reinterpret_cast<double *>(S.gk[0])[lane] = ld0;
+      else if (lane < 15) S.gv7[lane - 8] = ld0;
+      else if (lane == 15) S.gcls[0] = ldi;
+      else if (lane >= 32 && lane < 32 + t.per_cell) S.rc_ad[lane - 32] = sqrt(ld0 * ld0 + ld1 * ld1);  // box_utils.py:79
+      iou_wave_sync();
+      if (lane == 0) {
+        double g8[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          g8[2 * k] = S.gk[0][k].x;
+          g8[2 * k + 1] = S.gk[0][k].y;
+        }
+        S.garea[0] = -shoelace_dev(g8, 4);
+      }
+    } else if (wv >= 2) {
+      const int k2 = tid - 2 * 64;
+      if (k2 < t.per_cell * kTypeCols) S.types[0][k2] = ld0;
+      // What the regression rows need per anchor TYPE: the logarithms and the sine of a row depend on (box, type)
+      // only (box_utils.py:88-102) -- f64 library chains of ~1 us, evaluated once per type here, side by side with
+      // wave 0's gate, instead of once per pair after the clip; a pair's row then costs three subtractions and
+      // divisions.  (Behind the gate's barrier, side by side with the clip, was measured too: 0.5 us slower -- waves 2
+      // and 3 clip as well.)
+      if (wv == 2 && lane < t.per_cell * 3) {
+        S.rc_lg[lane / 3][lane % 3] = target_logratio(rc_g, rc_a);
+      } else if (wv == 3 && lane < t.per_cell) {
+        float dt, ort;
+        target_angle(rc_g, rc_a, &dt, &ort);
+        S.rc_dt[lane] = dt;
+        S.rc_ort[lane] = ort;
+      }
+    }
+    bool first = true;
+    for (unsigned q0 = (unsigned)split * cpw; q0 < ncand || first; q0 += (unsigned)nsp * cpw) {
+      if (!first) __syncthreads();  // the previous trip's LDS is read
       int wn = 0;
       if (wv == 0) {
         const unsigned q = q0 + (unsigned)lane;
@@ -1755,6 +1776,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
       __syncthreads();
       wn = S.woff[0];
       IOU_STAMP(2);
+      first = false;
       for (int r0 = 0; r0 < wn; r0 += kPairsPerRound)
         if (r0 + wv * (64 / kGroup) < wn) clip_round<1>(t, S, r0, wn, 0, tid, v, gbase, lds_types, bad);
       __syncthreads();
@@ -1762,71 +1784,81 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
       // wave 0, lane = pair: the column (maximum, then the lowest anchor index among the pairs that reach it)
       // and the pairs above the threshold
       double val = 0.0;
-      unsigned ai = ~0u;
+      unsigned ai = ~0u, pos_base = 0u;
       bool pos = false, newcol = false;
       int col_lane = -1;
+      u64 pb = 0ull;
       if (wv == 0) {
         val = lane < wn ? S.iou[lane] : 0.0;
         ai = lane < wn ? (unsigned)S.carg[S.pair_lane[lane]] : ~0u;
         const double wmax = wave_minmax_f64<true>(val > 0.0 ? val : 0.0);
         if (wmax > 0.0) {
           const u64 wb = (u64)__double_as_longlong(wmax);
-          const unsigned first = wave_min_u32(val == wmax ? ai : ~0u);
-          if (wb > col_bits || (wb == col_bits && first < col_anchor)) {
+          const unsigned firsta = wave_min_u32(val == wmax ? ai : ~0u);
+          if (wb > col_bits || (wb == col_bits && firsta < col_anchor)) {
             newcol = true;
-            col_lane = __ffsll((long long)__ballot(val == wmax && ai == first)) - 1;
-            col_anchor = first;
+            col_lane = __ffsll((long long)__ballot(val == wmax && ai == firsta)) - 1;
+            col_anchor = firsta;
             col_bits = wb;
           }
         }
         pos = val > t.pos_thresh;
-        const u64 need = __ballot(pos) | (newcol ? 1ull << col_lane : 0ull);
-        if (lane == 0) S.need = need;
+        pb = __ballot(pos);
+        const u64 need = pb | (newcol ? 1ull << col_lane : 0ull);
+        if (lane == 0) {
+          S.need = need;
+          // the pairs' places in the sample's list: asked for NOW, the answer is needed after the rows
+          if (pb) pos_base = atomicAdd(t.pos_count, (unsigned)__popcll(pb));
+        }
+        npos_wg += (unsigned)__popcll(pb);
       }
       __syncthreads();
-      // The regression rows of those pairs (box_utils.py:70-109), one KIND of value per wave, lane = pair: the
-      // tail then only copies rows -- it used to evaluate them, three or four f64 library chains of ~1 us at the very
-      // end of the launch, for a hundred-odd rows on 256 lanes.
+      // The regression rows of those pairs (box_utils.py:70-109), lane = pair.  With the per-type values in LDS:
+      // wave c < 3 the quotient of coordinate c (one division chain per wave, all three side by side) and its share
+      // of the constants.  (More than kLdsTypes anchor types per cell never get here: the host sends them through the
+      // anchor-centric kernel -- the per-pair library chains inside this loop cost every launch 46 VGPRs.)
       const u64 need = S.need;
       if (need && wv < 3 && ((need >> lane) & 1ull)) {
         const int pl = S.pair_lane[lane];
-        const double *ty = lds_types ? S.types[S.atype[pl]] : t.types + (int)S.atype[pl] * kTypeCols;
         float *row = S.rstage + lane * 9;
-        if (wv == 0) {
-          float dt, ort;
-          target_angle(S.gv7[6], ty[11], &dt, &ort);
-          row[0] = 1.0f;
-          row[7] = dt;
-          row[8] = ort;
-        } else if (wv == 1) {
-          row[4] = target_logratio(S.gv7[3], ty[8]);
-          row[5] = target_logratio(S.gv7[4], ty[9]);
-        } else {
-          row[6] = target_logratio(S.gv7[5], ty[10]);
-          row[1] = target_quotient(S.gv7[0], S.acen[pl].x, ty[8], ty[9], ty[10], t.canvas_height, 0);
-          row[2] = target_quotient(S.gv7[1], S.acen[pl].y, ty[8], ty[9], ty[10], t.canvas_height, 1);
-          row[3] = target_quotient(S.gv7[2], ty[12], ty[8], ty[9], ty[10], t.canvas_height, 2);
+        {
+          const int d = S.atype[pl];
+          const double *ty = S.types[d];
+          const double a_c = wv == 0 ? S.acen[pl].x : wv == 1 ? S.acen[pl].y : ty[12];
+          row[1 + wv] = target_quotient_ad(S.gv7[wv], a_c, S.rc_ad[d], ty[10], t.canvas_height, wv);
+          if (wv == 0) {
+            row[0] = 1.0f;
+            row[7] = S.rc_dt[d];
+            row[8] = S.rc_ort[d];
+          } else if (wv == 1) {
+            row[4] = S.rc_lg[d][0];
+            row[5] = S.rc_lg[d][1];
+          } else {
+            row[6] = S.rc_lg[d][2];
+          }
         }
       }
       if (need) __syncthreads();  // (workgroup-uniform)
       if (wv == 0) {
         if (newcol && lane < 9) S.colrow[lane] = S.rstage[col_lane * 9 + lane];
-        const u64 pb = __ballot(pos);
         if (pb) {
-          unsigned base = 0;
-          if (lane == 0) base = atomicAdd(t.pos_count, (unsigned)__popcll(pb));
-          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pos_base);
           if (pos) {
             const unsigned at = base + (unsigned)__popcll(pb & ((1ull << lane) - 1ull));
             const u64 bits = (u64)__double_as_longlong(val);
             if (at < (unsigned)G * t.pos_per_gt) {
-              PosEntry *pe = t.pos + at;
-              __hip_atomic_store(reinterpret_cast<u64 *>(pe), (u64)ai | ((u64)(unsigned)j << 32), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(&pe->bits, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-              for (int d = 0; d < 9; ++d) store_f32_sc1(pe->row + d, S.rstage[lane * 9 + d]);
-              store_f32_sc1(pe->pad, __int_as_float(S.gcls[0]));  // the box's class rides along
+              // the pair's key {anchor, box, IoU} and its row {row[0..8], class}: four 16-byte write-through stores
+              __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)t.pos, 0, 0x7FFFFFFF, 0x00020000);
+              __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)t.pos_rows, 0, 0x7FFFFFFF, 0x00020000);
+              const float *r9 = S.rstage + lane * 9;
+              const v4u c0 = {ai, (unsigned)j, (unsigned)bits, (unsigned)(bits >> 32)};
+              const v4u c1 = {__float_as_uint(r9[0]), __float_as_uint(r9[1]), __float_as_uint(r9[2]), __float_as_uint(r9[3])};
+              const v4u c2 = {__float_as_uint(r9[4]), __float_as_uint(r9[5]), __float_as_uint(r9[6]), __float_as_uint(r9[7])};
+              const v4u c3 = {__float_as_uint(r9[8]), (unsigned)S.gcls[0], 0u, 0u};  // the box's class rides along
+              __builtin_amdgcn_raw_buffer_store_b128(c0, rk, (int)at * 16, 0, kAuxSc1);
+              __builtin_amdgcn_raw_buffer_store_b128(c1, rr, (int)at * 48, 0, kAuxSc1);
+              __builtin_amdgcn_raw_buffer_store_b128(c2, rr, (int)at * 48 + 16, 0, kAuxSc1);
+              __builtin_amdgcn_raw_buffer_store_b128(c3, rr, (int)at * 48 + 32, 0, kAuxSc1);
               // (only for a STORED entry: the tail resets the words of the entries it sees, so a dropped one
               // would leave its word raised for every later call on this context)
               __hip_atomic_fetch_max(&t.best[ai], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1836,15 +1868,21 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
       }
     }
     if (bad) atomicExch(t.errflag, 1);
-    if (wv == 0 && lane == 0) {
-      // this workgroup's slot of the column list, written whether or not a pair overlapped (bits 0 = none): no
-      // counter, nothing stale, and the tail knows the list's length without a load
-      ColEntry *ce = t.cand + pu;
-      __hip_atomic_store(&ce->key, (u64)(unsigned)j | ((u64)(col_bits ? col_anchor : 0u) << 32), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&ce->bits, col_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wv == 0 && lane < 4) {
+      // this workgroup's slot of the column list {box, anchor, IoU} and the pair's row, written whether or not a pair
+      // overlapped (bits 0 = none): no counter, nothing stale, and the tail knows the list's length without a load.
+      // Lane 0 the entry, lanes 1-3 one 16-byte group of the row each: ONE write-through store per lane.
+      if (lane == 0) {
+        const v4u ch = {(unsigned)j, col_bits ? col_anchor : 0u, (unsigned)col_bits, (unsigned)(col_bits >> 32)};
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)t.cand, 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(ch, rs, pu * 16, 0, kAuxSc1);
+      } else if (col_bits != 0ull) {
+        const float *cr = S.colrow + 4 * (lane - 1);
+        const v4u ch = {__float_as_uint(cr[0]), __float_as_uint(cr[1]), __float_as_uint(cr[2]), __float_as_uint(cr[3])};
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)t.cand_rows, 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(ch, rs, pu * (kRowPitch * 4) + (lane - 1) * 16, 0, kAuxSc1);
+      }
     }
-    if (wv == 0 && lane < 9 && col_bits != 0ull) store_f32_sc1(t.cand_rows + (size_t)pu * kRowPitch + lane, S.colrow[lane]);
   }
   // every store and atomic above is down before the ticket; the sample's last workgroup finishes the job
   IOU_STAMP(6);
@@ -1852,24 +1890,37 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
   __syncthreads();
   IOU_STAMP(8);
   if (tid == 0) {
-    unsigned *my_ticket1 = t.ticket1 + (size_t)(u >> t.ticket_shift) * kTicketPad;
+    // two-level ticket, 64 bits a word: low half = workgroups (groups) done, high half = the pairs above the threshold
+    // they stored -- the sample's last workgroup gets the length of the pair list with its ticket, not from a load
+    u64 *my_ticket1 = reinterpret_cast<u64 *>(t.ticket1 + (size_t)(u >> t.ticket_shift) * kTicketPad);
     const unsigned grp = u >> t.ticket_shift, ngrp = ((n_units - 1u) >> t.ticket_shift) + 1u;
     const unsigned gsize = min(1u << t.ticket_shift, n_units - (grp << t.ticket_shift));
+    const u64 mine = 1ull | ((u64)min(npos_wg, 65535u) << 32);  // (<= 65535 workgroups x 65535: no carry out of the word)
     int last = 0;
-    if (atomicAdd(my_ticket1, 1u) == gsize - 1u) {
-      __hip_atomic_store(my_ticket1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = (atomicAdd(t.ticket, 1u) == ngrp - 1u) ? 1 : 0;
+    unsigned ntot = ~0u;
+    const u64 old1 = atomicAdd(my_ticket1, mine);
+    if ((unsigned)old1 == gsize - 1u) {
+      __hip_atomic_store(my_ticket1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 grp_pos = (old1 + mine) & 0xFFFFFFFF00000000ull;
+      const u64 old2 = atomicAdd(reinterpret_cast<u64 *>(t.ticket), 1ull | grp_pos);
+      if ((unsigned)old2 == ngrp - 1u) {
+        last = 1;
+        ntot = (unsigned)((old2 + grp_pos) >> 32);
+      }
     }
     S.is_last = last;
+    S.contrib = (int)ntot;
   }
   __syncthreads();
   IOU_STAMP(9);
   if (!S.is_last) return;
-  if (t.G <= 64 && t.G * nsp <= 4 * kTgtThreads && t.num_classes <= 63 && tail_gt_fast(t, smem, t.G * nsp)) {
+  const unsigned n_pairs = (unsigned)S.contrib;  // pairs above the threshold in the sample's list
+  if (t.G <= 64 && t.G * nsp <= kFastSlots * kTgtThreads && t.num_classes <= 63 && n_pairs <= (unsigned)kFastPos &&
+      n_pairs <= (unsigned)t.G * t.pos_per_gt) {
+    tail_gt_fast(t, smem, t.G * nsp, n_pairs);
     IOU_STAMP(10);
     return;
   }
-  __syncthreads();  // (the fast tail may have touched the LDS before it declined)
   positives_tail(t, smem);
   IOU_STAMP(15);
   if (t.G <= kForcedLds)
@@ -1891,6 +1942,7 @@ __global__ void k_targets_init(u64 *col_max, u64 *col_win, int G, int *errflag,
   if (j < PP_MAX_BATCH) {  // every sample's counter and ticket
     cand_count[j * kCounterStride] = 0u;
     ticket[j * kCounterStride] = 0u;
+    ticket[j * kCounterStride + 1] = 0u;  // (k_targets_gt counts in 64 bits)
   }
   if (j == 0) *errflag = 0;
 }
@@ -2112,7 +2164,7 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
     const char *e = getenv("PP_TARGETS_FORM");
     return !e ? 0 : (e[0] == 'a' ? 1 : 2);
   }();
-  bool boxes_form = an.grid && form_env != 1;
+  bool boxes_form = an.grid && form_env != 1 && an.per_cell <= kLdsTypes;  // (the box-centric kernel keeps the type table in LDS)
   // scratch: [0,8192) error flag + every sample's {list counter, ticket, pair counter} | col_max[Gcap] |
   // col_win[Gcap] | first-level tickets | cand[cand_per_gt * Gcap] | pos[pos_per_gt * Gcap] | best, bestj
   // [batch * A]; sample b owns the rows [g_off[b], g_off[b+1]) of each (Gcap = all samples' G)
@@ -2147,11 +2199,6 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
       cand_per_wg = kCandPerWg;
     }
   }
-  const size_t units = boxes_form ? (size_t)kZeroWgs + (size_t)g_max * splits : nwg;  // workgroups per sample
-  if (units > 65535) {
-    set_error("pp_assign_targets*_dev: %zu workgroups per sample (limit 65535)", units);
-    return PP_ERR_VALUE;
-  }
   // positives per box: at most one entry per candidate.  The PAIR loop strides over ALL of a box's candidates, also
   // when `splits` was clamped to 64 workgroups (fm_scale ~1 with six anchors per cell: 3174 candidates against
   // 64 x 32), so the list is sized from the candidate count itself, not from splits x cand_per_wg
@@ -2160,6 +2207,18 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
     const double per_axis = std::min(std::floor(20.0 * an.fm_scale) + 3.0, 32768.0);
     const double cand = std::min(per_axis * per_axis * an.per_cell, (double)A);
     pos_per_gt = std::max(splits * cand_per_wg, (size_t)std::ceil(cand));
+    // the PAIR role addresses a sample's pair entries through one buffer resource with 32-bit byte offsets
+    if ((double)g_max * (double)pos_per_gt * sizeof(PosRow) >= 2147483648.0) {
+      boxes_form = false;
+      splits = 1;
+      cand_per_wg = kCandPerWg;
+      pos_per_gt = 0;
+    }
+  }
+  const size_t units = boxes_form ? (size_t)kZeroWgs + (size_t)g_max * splits : nwg;  // workgroups per sample
+  if (units > 65535) {
+    set_error("pp_assign_targets*_dev: %zu workgroups per sample (limit 65535)", units);
+    return PP_ERR_VALUE;
   }
   const size_t cand_per_gt = boxes_form ? splits : nwg;
   const size_t off_cmax = 8192, off_cwin = off_cmax + gcap * 8;
@@ -2171,7 +2230,8 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   const size_t off_tk1 = (off_cwin + gcap * 8 + 255) / 256 * 256;
   const size_t off_cand = (off_tk1 + n_ticket1 * 4 + 255) / 256 * 256;
   const size_t off_pos = (off_cand + cand_per_gt * gcap * sizeof(ColEntry) + 255) / 256 * 256;
-  const size_t off_crow = (off_pos + pos_per_gt * gcap * sizeof(PosEntry) + 255) / 256 * 256;
+  const size_t off_prow = (off_pos + pos_per_gt * gcap * sizeof(PosKey) + 255) / 256 * 256;
+  const size_t off_crow = (off_prow + pos_per_gt * gcap * sizeof(PosRow) + 255) / 256 * 256;
   const size_t off_best = (off_crow + (boxes_form ? cand_per_gt * gcap * kRowPitch * 4 : 0) + 255) / 256 * 256;
   const size_t n_best = boxes_form ? (size_t)batch * (size_t)A : 0;
   const size_t off_bestj = off_best + n_best * 8;
@@ -2224,7 +2284,8 @@ static int assign_targets_impl(pp_ctx_t *ctx, void *stream_, int batch, const in
   t.ticket_groups = (int)ngrp;
   t.gt_splits = (int)splits;
   t.cand_per_wg = (int)cand_per_wg;
-  t.pos = reinterpret_cast<PosEntry *>(ws + off_pos);
+  t.pos = reinterpret_cast<PosKey *>(ws + off_pos);
+  t.pos_rows = boxes_form ? reinterpret_cast<PosRow *>(ws + off_prow) : nullptr;
   t.pos_per_gt = (unsigned)pos_per_gt;
   t.cand_rows = boxes_form ? reinterpret_cast<float *>(ws + off_crow) : nullptr;
   t.best = boxes_form ? reinterpret_cast<u64 *>(ws + off_best) : nullptr;

@@ -1,6 +1,6 @@
 """Target-assignment micro benchmark (development aid; tools/collect_profiles.sh runs it under rocprofv3):
 BASELINE config 3 by default.
-usage: bench_targets.py [fm] [G] [batch] [per_cell: 2 | 6 (the reference's shipped anchor set)] [what: all | batch | single]"""
+usage: bench_targets.py [fm] [G] [batch] [per_cell: 2 | 6 (the reference's shipped anchor set)] [what: all | batch | single | grid (both, anchors on the fly only)]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,7 @@ for name, src in (("arrays", boxes.make_anchors(cfg)), ("grid", cfg)):
         continue
     ta = TargetAssigner(src, canvas_height=2 * fm)
     A = ta.A
-    if what in ("all", "single"):
+    if what in ("all", "single", "grid"):
         g = [ta._gt_to_device(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"]) for gt in gts]
         for _ in range(10):
             ta.assign_device(*g[0])
@@ -33,7 +33,7 @@ for name, src in (("arrays", boxes.make_anchors(cfg)), ("grid", cfg)):
         dt = (time.perf_counter() - t0) / it
         print(f"A={A} G={G} anchors={name}: one sample per launch {dt*1e6:.1f} us per sample; algorithmic 112*A = "
               f"{112*A/1e6:.1f} MB -> {112*A/dt/1e9:.0f} GB/s")
-    if what in ("all", "batch"):
+    if what in ("all", "batch", "grid"):
         counts, packed = ta.upload_batch(gts)
         out = None
         for _ in range(10):

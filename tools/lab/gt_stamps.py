@@ -22,7 +22,8 @@ ok = st[:, 0] > 0
 st = st[ok]
 t0 = st[:, 0].min()
 zero = st[:, 1] < t0          # ZERO-role workgroups never stamp slot 1 in this launch
-names = {0: "start", 1: "box loaded", 2: "gated", 4: "clipped", 6: "reduced", 8: "drained", 9: "ticket", 15: "positives done", 10: "end"}
+names = {0: "start", 1: "box loaded", 2: "gated", 4: "clipped", 6: "reduced", 8: "drained", 9: "ticket", 11: "tail: loads in, LDS armed",
+         12: "tail: maxima", 13: "tail: winners", 14: "tail: positives down, forced rows fetched", 15: "positives done", 10: "end"}
 print(f"{len(st)} workgroups stamped ({zero.sum()} ZERO role); us relative to the first start: min / median / max")
 for k, nm in names.items():
     col = st[:, k]
@@ -37,3 +38,10 @@ for a, b in ((0, 1), (1, 2), (2, 4), (4, 6), (6, 8), (8, 9)):
     print(f"  PAIR role {names[a]:>11s} -> {names[b]:11s} n={m.sum():4d} median {np.median(d):5.2f} max {d.max():5.2f}")
 z = zero & (st[:, 9] >= t0)
 print("  ZERO role lifetime median %.2f max %.2f" % (np.median((st[z, 9] - st[z, 0]) / 100.0), ((st[z, 9] - st[z, 0]) / 100.0).max()))
+last = st[st[:, 10] >= t0]
+for row in last:
+    print("  tail workgroup: " + ", ".join(f"{names[k].split(':')[-1].strip()} {(row[k] - t0) / 100.0:.2f}" for k in (0, 9, 11, 12, 13, 14, 10) if row[k] >= t0))
+ends = np.sort((st[p, 9] - t0) / 100.0)
+print("  PAIR tickets (us): deciles", np.round(np.percentile(ends, [0, 10, 25, 50, 75, 90, 95, 99, 100]), 2))
+starts = np.sort((st[p, 0] - t0) / 100.0)
+print("  PAIR starts (us): deciles", np.round(np.percentile(starts, [0, 10, 25, 50, 75, 90, 95, 99, 100]), 2))
