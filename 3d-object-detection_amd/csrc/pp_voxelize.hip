@@ -717,6 +717,7 @@ struct alignas(32) WaveLds {
   double mean[KW][3];
   double cx[KW], cy[KW];  // canvas_x / canvas_y (pillars.cpp:278-280), once per pillar
   int cnt[KW], live[KW], slot[KW], start[KW];
+  int pix[KW];            // fused feature-net mode: the pillar's canvas pixel row * W + col, -1: none / off the canvas
 };
 
 struct EmitArgs {
@@ -1256,6 +1257,16 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
     if (m.z > 0) pillar_canvas(m.x, a.g, cx, cy);
     L.cx[lane] = cx;
     L.cy[lane] = cy;
+    if constexpr (MODE == kModePfn) {
+      // the pillar's canvas pixel, once, on the lane that holds its descriptor (the f64 -> int64 conversions, the bounds
+      // test and the 64-bit index arithmetic per pillar on EVERY lane were most of pfn_finish's 1.1 us)
+      int pix = -1;
+      if (m.z > 0 && a.canvas) {
+        const int64_t col = (int64_t)cx, row = (int64_t)cy;
+        if (row >= 0 && row < a.canvas_h && col >= 0 && col < a.canvas_w) pix = (int)(row * a.canvas_w + col);
+      }
+      L.pix[lane] = pix;
+    }
   }
   wave_sync();
   PP_STAMP_E(2);
@@ -1374,17 +1385,17 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
     if (a.canvas) {
       // out[b, :, row, col] = x[b, :, p] for the flagged pillars only (model/model.py:56-61);
       // channels last: the 64 lanes write one 256-byte pixel
+      const int64_t hw = (int64_t)a.canvas_h * a.canvas_w;
+      float *cb = a.canvas_nhwc ? a.canvas + (int64_t)b * hw * kPfnChannels + lane
+                                : a.canvas + ((int64_t)b * kPfnChannels + lane) * hw;
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
-        if (k >= kw_eff || cnts[k] == 0) continue;
-        double cx, cy;
-        pillar_canvas(L.slot[k], a.g, cx, cy);
-        const int64_t col = (int64_t)cx, row = (int64_t)cy;
-        if (row < 0 || row >= a.canvas_h || col < 0 || col >= a.canvas_w) continue;
+        const int pix = L.pix[k];   // (-1 for an empty row: rows beyond kw_eff hold no descriptor and are empty)
+        if (pix < 0) continue;
         if (a.canvas_nhwc)
-          a.canvas[((((int64_t)b * a.canvas_h + row) * a.canvas_w) + col) * kPfnChannels + lane] = yv[k];
+          cb[(int64_t)pix * kPfnChannels] = yv[k];
         else
-          a.canvas[((((int64_t)b * kPfnChannels + lane) * a.canvas_h) + row) * a.canvas_w + col] = yv[k];
+          cb[pix] = yv[k];
       }
     }
   };
@@ -2468,6 +2479,8 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
       if (skip & 1) a.n_tile_blocks = 0;
       if (skip & 2) a.n_order_blocks = 0;
       if (skip & 4) a.n_split_blocks = 0;
+      if (skip & 8) a.n_unscatter_blocks = 0;   // the fused form's clear role
+      if (skip & 16) en = 0;                    // the emit role: what the binning (and clear) roles take by themselves
     }
 #endif
     const int n_emit = whole.emit_nbx * en;
