@@ -1660,7 +1660,14 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
     zero_share(t.reg_targets, t.A * 9, (int)u, kZeroWgs, tid);
     if (G == 0) return;  // no box: nothing else runs for this sample, no tail
   } else {
-    const int pu = (int)u - kZeroWgs, j = pu / nsp, split = pu - j * nsp;
+    // Dispatch order (workgroups start in block-id order): the windows' MIDDLE bands first, for all boxes, then outwards.
+    // The candidates are enumerated row-major over the box's window, so the middle splits hold the pairs above the
+    // threshold -- the workgroups with the longest chain (list atomics, entries) -- and the sample's tail waits for
+    // the last of them.  The slot of the column list stays j * nsp + split.
+    const int rank = ((int)u - kZeroWgs) / G, j = ((int)u - kZeroWgs) - rank * G;
+    const int mid = (nsp - 1) >> 1, dst = (rank + 1) >> 1;
+    const int split = (rank & 1) ? mid + dst : mid - dst;
+    const int pu = j * nsp + split;
     const bool lds_types = t.per_cell <= kLdsTypes;
     // The prologue's global loads, ALL issued before any is waited for.  (A launch starts on cold caches: a load is
     // ~1 us, and a wave that branches by lane role with a load inside each branch pays that once per branch -- the
