@@ -1791,8 +1791,12 @@ int make_grid(const pp_voxel_params_t *prm, GridGeom *g, int step_mode) {
   // at most 2048 slots (30.7 KB with 4 waves) keep the emit role at 5 workgroups per CU.  Fewer, fatter
   // tile workgroups hold fewer of the chip's workgroup slots while they wait out their latency chains:
   // 123 tiles of 2048 slots beat 245 of 1024 (C2: 13.1 / 33.6 us per step against 14.7 / 36.8, B = 1 / 4).
+  // Round 5, k_step with the row-major order: tiles of 512 slots (489 at C2) -- its crowded strips were the launch
+  // (C2: 53.0 -> 41.9 us at 4 sweeps per launch, 26.6 -> 14.0 us at one; tools/lab/sweep_rowmajor.sh); the scrambled
+  // order's uniform tiles stay at 2048 slots (38.5 us; 39.9 with 512).
   const int target_tiles = forced_tiles ? forced_tiles
-                         : (prm->order == PP_ORDER_ROW_MAJOR && !step_mode) ? kTargetTiles : kTargetTiles / 2;
+                         : prm->order == PP_ORDER_ROW_MAJOR ? (step_mode ? 2 * kTargetTiles : kTargetTiles)
+                                                            : kTargetTiles / 2;
   const int soft_cap = ((prm->order == PP_ORDER_ROW_MAJOR && !forced_tiles) || step_mode) ? 2048 : kMaxTileSlots;
   while ((nc + ts - 1) / ts > target_tiles && ts < soft_cap) ts *= 2;
   while ((nc + ts - 1) / ts > kMaxTiles && ts < kMaxTileSlots) ts *= 2;
