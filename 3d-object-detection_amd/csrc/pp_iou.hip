@@ -1788,6 +1788,12 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
         if (r0 + wv * (64 / kGroup) < wn) clip_round<1>(t, S, r0, wn, 0, tid, v, gbase, lds_types, bad);
       __syncthreads();
       IOU_STAMP(4);
+#ifdef PP_IOU_CLIP_TWICE  // tools/lab: the clip once more (same result) -- what the SECOND pass through the same code takes
+      for (int r0 = 0; r0 < wn; r0 += kPairsPerRound)
+        if (r0 + wv * (64 / kGroup) < wn) clip_round<1>(t, S, r0, wn, 0, tid, v, gbase, lds_types, bad);
+      __syncthreads();
+      IOU_STAMP(5);
+#endif
       // wave 0, lane = pair: the column (maximum, then the lowest anchor index among the pairs that reach it)
       // and the pairs above the threshold
       double val = 0.0;

@@ -22,7 +22,7 @@ ok = st[:, 0] > 0
 st = st[ok]
 t0 = st[:, 0].min()
 zero = st[:, 1] < t0          # ZERO-role workgroups never stamp slot 1 in this launch
-names = {0: "start", 1: "box loaded", 2: "gated", 4: "clipped", 6: "reduced", 8: "drained", 9: "ticket", 11: "tail: loads in, LDS armed",
+names = {0: "start", 1: "box loaded", 2: "gated", 4: "clipped", 5: "clipped again (lab)", 6: "reduced", 8: "drained", 9: "ticket", 11: "tail: loads in, LDS armed",
          12: "tail: maxima", 13: "tail: winners", 14: "tail: positives down, forced rows fetched", 15: "positives done", 10: "end"}
 print(f"{len(st)} workgroups stamped ({zero.sum()} ZERO role); us relative to the first start: min / median / max")
 for k, nm in names.items():
@@ -32,8 +32,10 @@ for k, nm in names.items():
         c = (col[m] - t0) / 100.0
         print(f"  {nm:15s} n={m.sum():4d}  {c.min():7.2f} {np.median(c):7.2f} {c.max():7.2f}")
 p = ~zero
-for a, b in ((0, 1), (1, 2), (2, 4), (4, 6), (6, 8), (8, 9)):
+for a, b in ((0, 1), (1, 2), (2, 4), (4, 5), (4, 6), (6, 8), (8, 9)):
     m = p & (st[:, a] >= t0) & (st[:, b] >= st[:, a])
+    if not m.any():
+        continue
     d = (st[m, b] - st[m, a]) / 100.0
     print(f"  PAIR role {names[a]:>11s} -> {names[b]:11s} n={m.sum():4d} median {np.median(d):5.2f} max {d.max():5.2f}")
 z = zero & (st[:, 9] >= t0)
