@@ -821,7 +821,8 @@ def main():
         targets_rec = {"bound": "hbm by its bytes; measured: a chain of latencies (box loads, gate, clip rounds of f64, rows, "
                                 "the last-workgroup tail) beside a zero fill -- see DESIGN.md",
                        "kernel": "pp::k_targets_gt (box-centric: grid = samples x {zero-fill workgroups, workgroups per box}; one "
-                                 "launch per step; anchor ARRAYS go through the anchor-centric pp::k_targets<false>)",
+                                 "launch per step; anchor ARRAYS, and more than 8 anchor types per cell, go through the "
+                                 "anchor-centric pp::k_targets<false>)",
                        "bytes_per_launch": t_bytes, "bytes_what": "112 * A per sample (SURVEY 8d) x the batch",
                        "us_per_call": assign_call_us, "achieved": t_bytes / (assign_call_us * 1e-6) / 1e9,
                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": t_bytes / (assign_call_us * 1e-6) / HBM_PEAK,
@@ -831,7 +832,8 @@ def main():
                        # SURVEY's 40 B per anchor of input -- the two target arrays (72 B per anchor) and the boxes
                        "moved_bytes": 72 * tp.assigner.A * a.batch,
                        "moved_bytes_source": "computed: 72 * A * batch (the two f32 target arrays; the boxes stay in L2); "
-                                             "profiles/r04/pmc_targets_c3_b4_*: 36.4 MB written + 0.24 MB fetched at B=4",
+                                             "profiles/r05/pmc_targets_c3_b4_*: 36.27 MB written + 0.21 MB fetched at B=4, "
+                                             "pmc_targets_c3_b1_*: 9.09 + 0.16 MB for one sample",
                        "frac_of_moved_bytes": 72 * tp.assigner.A * a.batch / (assign_call_us * 1e-6) / HBM_PEAK,
                        "one_sample_frac_of_moved_bytes": 72 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK}
         del tg1, t_out
