@@ -297,7 +297,10 @@ int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
 /* Error flag of the IoU / target-assignment launches on this context since the
  * last check: synchronises `stream`, returns PP_ERR_WINDING (and clears the flag)
  * if a pair that passed the centre gate had a wrongly wound box (the reference's
- * "IOU < 0" exit, pillars.cpp:166-169), else PP_OK.  pp_make_ious_f64 calls it itself. */
+ * "IOU < 0" exit, pillars.cpp:166-169), else PP_OK.  pp_make_ious_f64 calls it itself.
+ * PP_ERR_VALUE: the box-centric target kernel's list of pairs above the threshold overflowed
+ * (it is sized from the candidate anchors per box, so only boxes whose image-space centre is
+ * not finite can get there); entries were dropped, the scratch is re-armed before the next call. */
 int pp_iou_check(pp_ctx_t *ctx, void *stream);
 
 /* Device-resident make_ious: contiguous f64 device arrays, ious_dev [A][G]. */
