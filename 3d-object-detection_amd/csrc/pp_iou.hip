@@ -91,7 +91,8 @@ struct TargetArgs {
   unsigned *pos_count;       // per sample
   float *cand_rows;          // [boxes][gt_splits][kRowPitch]: the regression row of each column-list slot's pair
   u64 *best;                 // [samples][A]: highest IoU above the threshold an anchor has seen (0 = none); and
-  unsigned *bestj;           // [samples][A]: the first box reaching it (~0 = none) -- armed, re-armed by the tail
+  unsigned *bestj;           // [samples][A]: the first box reaching it (~0 = none) -- the two-pass tail's scratch (more
+                             // than 1024 pairs above the threshold): armed, raised and re-armed by that tail alone
   // outputs
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
@@ -1452,13 +1453,18 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
 #pragma unroll
         for (int d = 0; d < 9; ++d) reg[d] = rv[d];
       }
-    // the per-anchor words of the slow path: back to "none" (the PAIR role raised them)
-#pragma unroll
-    for (int k = 0; k < kPer; ++k)
-      if (slot[k] >= 0) __hip_atomic_store(&t.best[e_i[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   } else {
-    // more pairs above the threshold than the table holds: the per-anchor words in global memory
+    // more pairs above the threshold than the table holds: per-anchor words in global memory (armed to "none", only
+    // this workgroup touches them: atomics and agent-scope loads meet in its XCD's L2).  Round 5: this rare path raises
+    // the anchors' maxima itself -- the PAIR role used to, with one more global atomic per pair above the threshold in
+    // every launch, and every tail had to reset them.
+    for (unsigned e = tid; e < n; e += kTgtThreads) {
+      const unsigned i = (unsigned)ld_agent(reinterpret_cast<const u64 *>(&t.pos[e]));
+      __hip_atomic_fetch_max(&t.best[i], ld_agent(&t.pos[e].bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
     for (unsigned e0 = 0; e0 < n; e0 += kTgtThreads) {
       const unsigned e = e0 + tid;
       if (e < n) {
@@ -1625,7 +1631,6 @@ __device__ void tail_gt_fast(const TargetArgs &t, unsigned char *smem, int nslot
 #pragma unroll
       for (int d = 0; d < 9; ++d) reg[d] = __uint_as_float(pr[d >> 2][d & 3]);
     }
-    __hip_atomic_store(&t.best[pk[0]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slow path's word
   }
   if (i != 0) {  // (wave 0)
     const u64 mask = F.fmask[fslot];
@@ -1872,9 +1877,6 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
               __builtin_amdgcn_raw_buffer_store_b128(c1, rr, (int)at * 48, 0, kAuxSc1);
               __builtin_amdgcn_raw_buffer_store_b128(c2, rr, (int)at * 48 + 16, 0, kAuxSc1);
               __builtin_amdgcn_raw_buffer_store_b128(c3, rr, (int)at * 48 + 32, 0, kAuxSc1);
-              // (only for a STORED entry: the tail resets the words of the entries it sees, so a dropped one
-              // would leave its word raised for every later call on this context)
-              __hip_atomic_fetch_max(&t.best[ai], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
