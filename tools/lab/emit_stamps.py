@@ -10,8 +10,9 @@ from pp_amd.pipeline import PillarPipeline
 from pp_amd.voxelizer import VoxelConfig
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 what = sys.argv[2] if len(sys.argv) > 2 else "pfn"
+step = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2      # 1.0: BASELINE configs[0]'s 100x100 grid (crowded cells)
 P = 12000
-pipe = PillarPipeline(VoxelConfig.square(50.0, 0.2, P, 100), seed=0)
+pipe = PillarPipeline(VoxelConfig.square(50.0, step, P, 100), seed=0)
 pipe.model.eval()
 pts = torch.from_numpy(np.stack([synth.lidar_like(60000, 50.0, s) for s in range(B)])).cuda()
 tab = pipe.model.feature_net.fused_table(pipe.device)
@@ -42,6 +43,9 @@ for k, nm in names.items():
     if m.any():
         c = us(st[m, k])
         print(f"  {nm:14s} n={m.sum():6d}  min {c.min():6.2f}  p10 {np.percentile(c,10):6.2f}  median {np.median(c):6.2f}  p90 {np.percentile(c,90):6.2f}  max {c.max():6.2f}")
+life = (st[st[:, 6] >= t0, 6] - st[st[:, 6] >= t0, 0]) / 100.0      # (waves of rows beyond the pillar count leave early, unstamped)
+print("  wave lifetime percentiles (us): p50 %.2f p90 %.2f p99 %.2f max %.2f; waves beyond 2 x median: %d" % (
+    np.percentile(life, 50), np.percentile(life, 90), np.percentile(life, 99), life.max(), (life > 2 * np.median(life)).sum()))
 for a_, b_ in ((0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (0, 6)):
     m = (st[:, a_] >= t0) & (st[:, b_] >= st[:, a_])
     if m.any():
