@@ -68,11 +68,12 @@ from oracle import oracle as O
 n, half, step, P, N, budget = int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7])
 pts = synth.lidar_like(n, half, 0).astype(np.float64)
 args = (P, N, step, step, -half, -half, -10.0, half, half, 10.0, int(2 * half / step))
+cp = O.pybind_module().create_pillars       # the reference-style C loop behind the reference's pybind11 signatures
 for _ in range(2):
-    O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
+    O.dataset_voxel_stage(pts, *args, create=cp)
 t0 = time.perf_counter(); k = 0
 while time.perf_counter() - t0 < budget:
-    O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH); k += 1
+    O.dataset_voxel_stage(pts, *args, create=cp); k += 1
 print(k / (time.perf_counter() - t0))
 """
 
@@ -82,13 +83,14 @@ def _cpu_voxel_stage(n, half, step, p, nn, seconds_budget):
     from oracle import oracle as O
     pts = synth.lidar_like(n, half, 0).astype(np.float64)  # dataset.py:82 hands over f64
     args = (p, nn, step, step, -half, -half, -10.0, half, half, 10.0, int(round(2 * half / step)))
+    cp = O.pybind_module().create_pillars   # "through the same pybind11 signatures"
     for _ in range(2):
-        O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
+        O.dataset_voxel_stage(pts, *args, create=cp)
     times = []
     t_end = time.perf_counter() + seconds_budget
     while time.perf_counter() < t_end or len(times) < 5:
         t0 = time.perf_counter()
-        O.dataset_voxel_stage(pts, *args, order=O.ORDER_HASH)
+        O.dataset_voxel_stage(pts, *args, create=cp)
         times.append(time.perf_counter() - t0)
     return float(np.median(times)), len(times), float(np.min(times)), float(np.max(times))
 
@@ -99,8 +101,11 @@ def cpu_baseline(seconds_budget=10.0, workers=4, worker_budget=5.0, c1_budget=5.
     import subprocess
     from oracle import oracle as O
     O.build()
+    O.build_pybind()
     med, calls, lo, hi = _cpu_voxel_stage(N_POINTS, HALF, STEP, P, N, seconds_budget)
     out = {"value": 1.0 / med, "unit": "sweeps/s", "cores": 1, "kind": "port",
+           "binding": "pybind11 module `pillars_oracle` (oracle/oracle_module.cpp): the reference's positional signatures, "
+                      "array_t<double> arguments, built with the reference's flags (-O3 -fPIC, install_mods.sh:8)",
            "sample": f"{calls} calls of the voxel stage only (np.zeros + create_pillars "
                      f"[reference-style hash map of heap nodes] + transpose + f32 cast, "
                      f"dataset.py:89-106) on one {N_POINTS}-pt cloud, median {med * 1e3:.1f} ms "
@@ -167,8 +172,9 @@ def dropin_host(reps=15):
     dataset.py calls the same symbols"): the built pybind11 module `pillars` (native/pillars*.so, what
     install_mods.sh:8-10 would move into data/) called the way data/dataset.py:88-106 and utils/box_utils.py:181-183
     call it -- float64 NumPy arrays on the HOST, outputs mutated in place, PCIe transfers and the host-side scatter
-    included -- beside the CPU oracle's reference-style functions on the same arrays (1 core; a C port through
-    ctypes, faster per call than the reference's bounds-checked pybind11 build: conservative for the ratio)."""
+    included -- beside the CPU oracle's reference-style functions on the same arrays through the same kind of module
+    (`pillars_oracle`, pybind11; 1 core; a C port without the reference's bounds-checked accessors, faster per call
+    than the reference's Boost build as the survey probed it: conservative for the ratio)."""
     import importlib.util
     from oracle import oracle as O
     from pp_amd import boxes
@@ -184,8 +190,10 @@ def dropin_host(reps=15):
     def call_hip():
         mod.create_pillars(agg.transpose([1, 0]), T, I, *cp_args)
 
+    cpu_mod = O.pybind_module()               # the oracle behind the same pybind11 signatures
+
     def call_cpu():
-        O.create_pillars(agg.transpose([1, 0]), T, I, *cp_args, order=O.ORDER_HASH)
+        cpu_mod.create_pillars(agg.transpose([1, 0]), T, I, *cp_args)
 
     def glue(create):      # data/dataset.py:88-106 around the call, statement for statement
         def run():
@@ -200,13 +208,13 @@ def dropin_host(reps=15):
     hip_call, _ = _median_ms(call_hip, reps)
     cpu_call, _ = _median_ms(call_cpu, max(5, reps // 2))
     hip_glue, _ = _median_ms(glue(mod.create_pillars), reps)
-    cpu_glue, _ = _median_ms(glue(lambda *a_: O.create_pillars(*a_, order=O.ORDER_HASH)), max(5, reps // 2))
+    cpu_glue, _ = _median_ms(glue(cpu_mod.create_pillars), max(5, reps // 2))
     anchors = boxes.make_anchors(boxes.AnchorConfig(250, 250))
     gt = synth.gt_boxes(40, 500, 0)
     c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 500)
     ious = np.zeros((anchors["corners"].shape[0], 40))
     hip_iou, _ = _median_ms(lambda: mod.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious), reps)
-    cpu_iou, _ = _median_ms(lambda: O.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious), 5, warm=1)
+    cpu_iou, _ = _median_ms(lambda: cpu_mod.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ious), 5, warm=1)
     return {
         "module": "native/" + os.path.basename(_lib.pybind_module_path()) + " (pybind11, csrc/pillars_module.cpp -> "
                   "pp_create_pillars_f64 / pp_make_ious_f64)",

@@ -34,6 +34,46 @@ def build(force=False):
     return _LIB_PATH
 
 
+def pybind_module_path():
+    import sysconfig
+    return os.path.join(_HERE, "pillars_oracle" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False):
+    """Compile oracle/oracle_module.cpp (the oracle's two functions behind the reference's pybind11 module surface,
+    data/pillars.cpp:429-435) with the reference's own build line (install_mods.sh:8: g++ -O3 -Wall -shared -std=c++11
+    -fPIC + the pybind11 includes; c++14 because pybind11 3 needs it), linked with the C oracle's object code."""
+    import pybind11
+    import sysconfig
+    src = [os.path.join(_HERE, "oracle_module.cpp"), os.path.join(_HERE, "pp_oracle.c"), os.path.join(_HERE, "pp_oracle.h")]
+    out = pybind_module_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(p) for p in src):
+        return out
+    obj = os.path.join(_HERE, "pp_oracle.o")
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-Wall", "-std=c11", "-fPIC", "-ffp-contract=off", "-c",
+                           src[1], "-o", obj])
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-Wall", "-shared", "-std=c++14", "-fPIC",
+                           "-ffp-contract=off", "-fvisibility=hidden", "-I" + pybind11.get_include(),
+                           "-I" + sysconfig.get_paths()["include"], "-I" + _HERE, src[0], obj, "-o", out + ".tmp", "-lm"])
+    os.replace(out + ".tmp", out)
+    return out
+
+
+_pymod = None
+
+
+def pybind_module():
+    """The module `pillars_oracle`: create_pillars / make_ious with the reference's positional pybind11 signatures,
+    on the oracle's reference-style C loops (what bench.py times as the CPU baseline)."""
+    global _pymod
+    if _pymod is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pillars_oracle", build_pybind())
+        _pymod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_pymod)
+    return _pymod
+
+
 _lib = None
 
 
@@ -178,15 +218,22 @@ def make_ious(a_corners, g_corners, a_centers, g_centers, ious):
 
 def dataset_voxel_stage(lidar_points, max_pillars, max_points, x_step, y_step,
                         x_min, y_min, z_min, x_max, y_max, z_max, canvas_height,
-                        order=ORDER_SCRAMBLED, data_mean=None):
+                        order=ORDER_SCRAMBLED, data_mean=None, create=None):
     """np.zeros + create_pillars + transpose + f32 cast (+ the optional data_mean), exactly
     the work of data/dataset.py:89-106.  Returns
-    (pillar[9,P,N] float32, indices[P,3] int64, num_cells)."""
+    (pillar[9,P,N] float32, indices[P,3] int64, num_cells).  ``create``: a module-style
+    ``create_pillars`` (positional signature of pillars.cpp:236-249, returns None) to call instead
+    of this file's ctypes one -- bench.py's CPU legs pass ``pybind_module().create_pillars``."""
     pillar = np.zeros((max_pillars, max_points, 9))          # dataset.py:89
     indices = np.zeros((max_pillars, 3))                     # dataset.py:90
-    m = create_pillars(lidar_points, pillar, indices, max_points, max_pillars,
-                       x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max,
-                       canvas_height, order)                 # dataset.py:92-97
+    if create is not None:
+        create(lidar_points, pillar, indices, max_points, max_pillars, x_step, y_step, x_min, y_min, z_min,
+               x_max, y_max, z_max, canvas_height)           # dataset.py:92-97
+        m = None
+    else:
+        m = create_pillars(lidar_points, pillar, indices, max_points, max_pillars,
+                           x_step, y_step, x_min, y_min, z_min, x_max, y_max, z_max,
+                           canvas_height, order)             # dataset.py:92-97
     pillar = pillar.transpose([2, 0, 1])                     # dataset.py:99
     pillar = np.ascontiguousarray(pillar, dtype=np.float32)  # dataset.py:101 (.float())
     if data_mean is not None:                                # dataset.py:102-105, f32 - f32

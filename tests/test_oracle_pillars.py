@@ -118,3 +118,30 @@ def test_grid_dims_bound(oracle):
     assert np.floor((np.nextafter(60.0, 0) - -60) / .2) < nx
     with pytest.raises(ValueError):
         oracle.grid_dims(0, .2, -60, -60, 60, 60)
+
+
+def test_pybind11_front_of_the_oracle_equals_the_ctypes_one(oracle):
+    """oracle/oracle_module.cpp: the reference's module surface (pillars.cpp:429-435: two names, positional signatures,
+    None returned, outputs mutated in place) on the oracle's reference-style C loops -- what bench.py times as the CPU
+    baseline "through the same pybind11 signatures" (BASELINE.md section 4).  Same arrays as the ctypes front, bit for bit."""
+    m = oracle.pybind_module()
+    assert sorted(n for n in dir(m) if not n.startswith("_")) == ["create_pillars", "make_ious"]
+    rng = np.random.default_rng(5)
+    agg = rng.uniform(-9, 9, (4, 20000))
+    agg[2] = rng.uniform(-2, 2, 20000)
+    pts = agg.transpose([1, 0])                       # the strided view of data/dataset.py:88
+    P, N = 3000, 16
+    args = (N, P, .25, .25, -8, -8, -3, 8, 8, 3, 64)
+    T, I = np.zeros((P, N, 9)), np.zeros((P, 3))
+    assert m.create_pillars(pts, T, I, *args) is None
+    T2, I2 = np.zeros((P, N, 9)), np.zeros((P, 3))
+    oracle.create_pillars(pts, T2, I2, *args, order=oracle.ORDER_HASH)
+    assert np.array_equal(T, T2) and np.array_equal(I, I2) and I[:, 0].sum() > 100
+    with pytest.raises(IndexError):
+        m.create_pillars(pts, np.zeros((10, N, 9)), np.zeros((10, 3)), *args)      # undersized outputs: like .at()
+    # make_ious: a unit-square anchor against itself (clockwise ground truth) and a far one
+    a = np.array([[[0, 0], [1, 0], [1, 1], [0, 1]]], float)
+    g = np.array([[[0, 0], [0, 1], [1, 1], [1, 0]], [[50, 50], [50, 51], [51, 51], [51, 50]]], float)
+    out = np.full((1, 2), -7.0)
+    assert m.make_ious(a, g, np.array([[.5, .5, 0]]), np.array([[.5, .5, 0], [50.5, 50.5, 0]]), out) is None
+    assert out[0, 0] == 1.0 and out[0, 1] == 0.0
