@@ -536,6 +536,22 @@ def test_box_centric_more_candidates_than_64_workgroups_hold(gpu, oracle):
     assert torch.equal(c0, c1) and torch.equal(r0, r1)
 
 
+def test_more_than_eight_anchor_types_per_cell_take_the_anchor_centric_kernel(gpu, oracle):
+    """The box-centric kernel keeps the anchor type table (and the per-type row constants) in LDS: eight types.  Nine per
+    cell on the fly are routed through the anchor-centric k_targets by the host -- same results as the uploaded arrays
+    and the oracle, next to an eight-type grid on the same context."""
+    rng = np.random.default_rng(91)
+    from pp_amd import boxes, synth
+    for per_cell in (8, 9):
+        dims = tuple((float(rng.uniform(6, 12)), float(rng.uniform(14, 26)), float(rng.uniform(1, 2))) for _ in range(per_cell))
+        yaws = tuple(float(y) for y in rng.choice([0.0, 90.0, 45.0], per_cell))
+        zs = tuple(float(z) for z in rng.uniform(0.4, 1.1, per_cell))
+        cfg = boxes.AnchorConfig(30, 30, 0.5, dims, yaws, zs)
+        gts = [synth.gt_boxes(9, 60, 51, margin=12.0), synth.gt_boxes(0, 60, 52), synth.gt_boxes(4, 60, 53, margin=12.0)]
+        n_pos = _both_forms_and_oracle(gpu, oracle, cfg, 60, gts, 0.5)
+        assert sum(n_pos) > 0
+
+
 def test_box_centric_odd_sizes_misaligned_samples_and_boxes_off_the_map(gpu, oracle):
     """A = 81 anchors x 3 classes: the second and third sample's rows start off 16 bytes (the zero fill's head / tail
     paths); more list slots per box than the anchor-centric form has workgroups; boxes whose gate window lies
