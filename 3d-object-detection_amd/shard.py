@@ -48,6 +48,9 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
+            # (the pool's operating notes: the host driver supports dmabuf IPC only, RCCL needs this where the
+            # environment does not already carry it -- set if absent, never overridden; must precede the first HIP call)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(local)
             # bind the communicator to this rank's GPU up front (no lazy device guess at the
             # first collective, no barrier-on-wrong-device warning)

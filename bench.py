@@ -468,9 +468,12 @@ def self_launch(n_ranks):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    # The ranks inherit this process's environment unchanged (this image and the GPU boxes export
-    # HSA_ENABLE_IPC_MODE_LEGACY=0 themselves -- `env | grep HSA_` -- and nothing here sets or overrides it).
+    # The ranks inherit this process's environment.  HSA_ENABLE_IPC_MODE_LEGACY=0 is exported by this image and by the
+    # GPU boxes (`env | grep HSA_`); where it is ABSENT it is set, never overridden.  Source: the pool's operating notes
+    # (the host driver supports dmabuf IPC only; without the variable RCCL / cross-process tensor sharing fails with
+    # "hipIpcGetMemHandle: invalid argument") -- taken on trust: RCCL has never run on these one-GPU boxes.
     env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
