@@ -525,6 +525,9 @@ def main():
         # (non-zero when any rank failed).
         sys.exit(self_launch(a.gpus))
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # a rank started by a launcher other than self_launch: the same default, before this process's first HIP call
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     world = int(os.environ.get("WORLD_SIZE", "1"))
