@@ -30,6 +30,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   stress_c5     BASELINE configs[4] shapes on one GPU: 200k points, 1000x1000 grid, P=30000,
                 voxelizer only, both paths, B sweeps and one sweep per launch
   reference_default  the reference's shipped config.py sizes (600x600, P=24000, N=200; 540 000 anchors)
+  next_rows     SURVEY 8(f) ranks 3 and 2 in the driver's run: lidar ingest (5 sweeps of a sample in one launch) and the
+                inference post-processing (scores, sort, NMS, decode of a batch), us per call and fraction for their bytes
+  dropin_host   the pybind11 drop-in module's own speed on host arrays beside the CPU loop (PCIe inclusive), with meets_50x
   cpu_baseline  the CPU oracle's reference-style voxel stage (hash map of heap nodes + the
                 caller's np.zeros/transpose/.float() glue, data/dataset.py:89-106) timed on
                 this host, 1 core, at configs[1]'s grid and (`c1`) at configs[0]'s 100x100 grid
@@ -233,6 +236,64 @@ def dropin_host(reps=15):
                 "API (voxelizer_only / cpu_baseline); on THIS surface the reference's own host-side work bounds the ratio: "
                 "the caller's np.zeros + transpose + f32 cast of an 86 MB f64 tensor, and for make_ious the 40 MB matrix "
                 "the signature demands"}
+
+
+def next_rows_record(pipe, points, dev):
+    """SURVEY 8(f) rows either side of the path, measured in the driver's run (their parity tests are tests/test_gpu_ingest.py
+    and tests/test_gpu_postprocess.py): the lidar ingest in front of the voxelizer (rank 3, data/dataset.py:51-88) and the
+    inference post-processing behind the head (rank 2, evaluate.py:231-245).  Both are small launches: the fraction of the
+    HBM roofline for their own bytes is reported for the record, what bounds them is latency."""
+    from pp_amd import boxes
+    from pp_amd.ingest import LidarIngest, transform_matrix
+    from pp_amd.postprocess import Detector
+    rng = np.random.default_rng(0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps):
+        for _ in range(5):
+            fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+    # ingest: one sample = 5 sweeps of 60 000 raw rows (x, y, z, intensity, ring: 20 B) -> [300000, 4] f32 (16 B per point)
+    ns = 5
+    raw = [torch.from_numpy(rng.normal(0, 30, (N_POINTS, 5)).astype(np.float32)).to(dev) for _ in range(ns)]
+    th = 0.3
+    mat = transform_matrix([1.0, 2.0, 0.5], [[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    ing = LidarIngest(device=dev)
+    sweeps = [(r, mat) for r in raw]
+    ing_us = timed(lambda: ing(sweeps), 200)
+    ing_bytes = ns * N_POINTS * (20 + 16)
+    # post-processing: the head's outputs of one forward (B sweeps), logits shifted so that ~1 % of the anchors pass the
+    # score threshold (evaluate.py's regime after training; random weights alone pass none or all)
+    with torch.no_grad():
+        cls, reg = pipe.forward(points)
+        cls, reg = cls.clone(), reg.clone()
+    acfg = pipe.anchor_cfg
+    det = Detector(boxes.make_anchors(acfg), acfg, pipe.vox_cfg.canvas_height, STEP, STEP, -HALF, -HALF,
+                   pos_thresh=0.2, nms_thresh=0.1, device=dev)
+    score = torch.sigmoid(cls.float()).reshape(cls.shape[0], acfg.per_cell, 9, -1).amax(2)
+    q = float(torch.quantile(score.flatten()[::7].float(), 0.99))
+    shift = float(np.log(0.2 / 0.8) - np.log(q / (1.0 - q)))          # moves the 99th percentile score to the threshold
+    cls_s = cls + shift
+    cand = [(torch.sigmoid(cls_s[i].float()).reshape(acfg.per_cell, 9, -1).amax(1) > 0.2).sum().item()
+            for i in range(cls.shape[0])]
+    dec_us = timed(lambda: det(cls_s, reg), 50)
+    kept = [int(c) for c in det(cls_s, reg)[2].tolist()]
+    dec_bytes = (cls.numel() + reg.numel()) * 4
+    return {
+        "ingest": {"kernel": "pp::k_ingest_sweeps (all sweeps of a sample in one launch)", "us_per_sample": ing_us,
+                   "sweeps": ns, "points_per_sweep": N_POINTS, "bytes_per_launch": ing_bytes,
+                   "bytes_what": "20 B raw row in + 16 B point out, per point", "frac": ing_bytes / (ing_us * 1e-6) / HBM_PEAK},
+        "postprocess": {"kernel": "pp::k_score + pp::k_sort_runs + pp::k_nms (three launches per batch)",
+                        "us_per_batch": dec_us, "us_per_sample": dec_us / cls.shape[0], "samples": int(cls.shape[0]),
+                        "candidates_per_sample": [int(c) for c in cand], "kept_per_sample": kept,
+                        "bytes_per_launch": dec_bytes, "bytes_what": "the head's cls + reg maps read once",
+                        "frac": dec_bytes / (dec_us * 1e-6) / HBM_PEAK},
+        "what": "SURVEY 8(f) rank 3 (ingest) and rank 2 (post-processing), timed with events around back-to-back calls"}
 
 
 def kernel_means_us(vox):
@@ -503,6 +564,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the dropin_host record (the pybind11 module's "
                                                              "own speed on host arrays)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the next_rows record (lidar ingest, post-processing)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed constant (profiles/emit_traffic.json) instead of two "
                          "rocprofv3 --pmc child runs of the headline loop")
@@ -515,7 +577,7 @@ def main():
                          "code path on a box with fewer GPUs than ranks (all ranks share device 0)")
     a = ap.parse_args()
     if a.headline_only:
-        a.no_cpu_baseline = a.no_fused = a.no_train_leg = a.no_stress = a.no_dropin = True
+        a.no_cpu_baseline = a.no_fused = a.no_train_leg = a.no_stress = a.no_dropin = a.no_next_rows = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has
@@ -1111,6 +1173,8 @@ def main():
             out["stress_c5"] = stress
         if refdef is not None:
             out["reference_default"] = refdef
+        if not a.no_next_rows and ctx.world_size == 1 and a.mode == "fwd":
+            out["next_rows"] = next_rows_record(pipe, points, dev)
         if not a.no_dropin and not a.headline_only and ctx.world_size == 1:
             torch.cuda.synchronize()
             torch.cuda.empty_cache()

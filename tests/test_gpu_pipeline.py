@@ -92,6 +92,17 @@ def test_bench_contract_line(gpu):
         assert 0 < rec["wall_frac"] < 1 and rec["k_step_us"] > 0 and 0 < rec["three_launch"]["wall_frac"] < 1
     fr = j["fused_feature_net"]["roofline"]
     assert fr["bytes_per_launch"] > 0 and 0 < fr["frac"] < 1 and set(fr["kernels_us"]) == {"k_split", "k_tile", "k_emit"}
+    # the rows either side of the path and the drop-in surface's own speed, in the same line
+    nr = j["next_rows"]
+    assert nr["ingest"]["us_per_sample"] > 0 and nr["ingest"]["bytes_per_launch"] == 5 * 60000 * 36
+    pp_ = nr["postprocess"]
+    assert pp_["samples"] == 4 and pp_["us_per_batch"] > 0 and all(200 < c < 5000 for c in pp_["candidates_per_sample"])
+    assert all(0 < k <= 100 for k in pp_["kept_per_sample"])
+    dh = j["dropin_host"]
+    for leg in ("create_pillars_call", "create_pillars_in_dataset_glue", "make_ious_call"):
+        r = dh[leg]
+        assert r["hip_ms"] > 0 and r["cpu_ms"] > 0 and abs(r["speedup"] - r["cpu_ms"] / r["hip_ms"]) < 1e-9
+        assert r["meets_50x"] == (r["speedup"] >= 50.0)
 
 
 def test_fused_epilogue_equals_relu_batchnorm(gpu):
