@@ -77,6 +77,36 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+VARIANTS = {
+    # test infrastructure (tests/test_gpu_handoff.py): the target kernels' hand-off to a sample's last workgroup in the
+    # architecturally guaranteed release / acquire form, to be compared bit for bit with the shipped write-through form
+    "strict": ["-DPP_STRICT_HANDOFF"],
+}
+
+
+def variant_path(name):
+    return os.path.join(_HERE, "variants", f"libpp_hip_{name}.so")
+
+
+def build_variant(name, force=False, verbose=False):
+    """Compile the whole library with the variant's defines into variants/libpp_hip_<name>.so (in-tree, git-ignored;
+    travels to the GPU box like libpp_hip.so).  Never loaded by the product."""
+    out = variant_path(name)
+    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "--offload-arch=gfx950",
+           "-I" + os.path.join(_ROOT, "include"), "-Wl,-rpath,/opt/rocm/lib", *VARIANTS[name],
+           *SOURCES, "-o", out + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 def pybind_module_path():
     """Where build_pybind_module() puts the reference-style extension module ``pillars``."""
     import sysconfig
@@ -108,6 +138,7 @@ def build_pybind_module(force=False, verbose=False):
 
 _lib = None
 _lock = threading.Lock()
+_variants = {}
 
 
 def lib():
@@ -118,87 +149,101 @@ def lib():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built "
-                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
-                "There is no CPU fallback.")
-        try:  # share torch's HIP runtime (same SONAME) when torch is in the process
-            import torch  # noqa: F401
-        except Exception:  # pragma: no cover - torch is optional for the host drop-in
-            pass
-        L = ctypes.CDLL(LIB_PATH)
-        c_int, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
-        pi64 = ctypes.POINTER(ctypes.c_int64)
-        L.pp_last_error.restype = ctypes.c_char_p
-        L.pp_version.restype = ctypes.c_char_p
-        L.pp_device_count.restype = c_int
-        L.pp_ctx_create.argtypes = [c_int, ctypes.POINTER(vp)]
-        L.pp_ctx_destroy.argtypes = [vp]
-        L.pp_ctx_destroy.restype = None
-        L.pp_voxelize_reserve.argtypes = [vp, c_int, i64, ctypes.POINTER(VoxelParams)]
-        L.pp_voxelize_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
-                                      ctypes.POINTER(VoxelParams), vp, vp, vp]
-        L.pp_voxelize_step_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
-                                           ctypes.POINTER(VoxelParams), vp, vp, vp, ctypes.POINTER(c_int)]
-        L.pp_voxelize_step_pfn_canvas_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
-                                                      ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
-                                                      c_int, vp, vp, vp, vp, c_int, ctypes.POINTER(c_int)]
-        L.pp_voxelize_step_kernel_name.argtypes = [ctypes.POINTER(VoxelParams), c_int, ctypes.c_char_p, c_int]
-        L.pp_voxelize_step_reset.argtypes = [vp]
-        L.pp_subtract_mean_dev.argtypes = [vp, vp, vp, c_int, i64, vp]
-        L.pp_voxelize_pfn_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
-                                          ctypes.POINTER(VoxelParams), vp, c_int, vp, vp, vp]
-        L.pp_voxelize_pfn_canvas_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
-                                                 ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
-                                                 c_int, vp, vp]
-        L.pp_voxelize_pfn_canvas_reuse_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
-                                                       ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
-                                                       c_int, vp, vp, vp]
-        L.pp_pfn_dense_dev.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp]
-        L.pp_scatter_canvas_dev.argtypes = [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_int, c_int, c_int]
-        L.pp_pfn_train_stats_dev.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp]
-        L.pp_pfn_train_backward_dev.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp]
-        L.pp_create_pillars_f64.argtypes = [vp, vp, i64, i64, i64, vp, pi64, pi64, vp, pi64, pi64,
-                                            ctypes.POINTER(VoxelParams), pi64]
-        L.pp_make_ious_f64.argtypes = [vp, vp, i64, pi64, vp, i64, pi64, vp, pi64, vp, pi64, vp, pi64]
-        L.pp_iou_check.argtypes = [vp, vp]
-        L.pp_make_ious_dev.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i64, vp]
-        L.pp_assign_targets_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
-                                            vp, ctypes.POINTER(TargetParams), vp, vp]
-        L.pp_assign_targets_grid_dev.argtypes = [vp, vp, c_int, c_int, ctypes.c_double, c_int, vp, i64, vp, vp,
-                                                 vp, vp, vp, vp, ctypes.POINTER(TargetParams), vp, vp]
-        pi32 = ctypes.POINTER(ctypes.c_int32)
-        L.pp_assign_targets_batch_dev.argtypes = [vp, vp, ctypes.c_int32, pi32, i64, vp, vp, vp, vp, vp, vp, vp,
-                                                  vp, vp, vp, ctypes.POINTER(TargetParams), vp, vp]
-        L.pp_assign_targets_grid_batch_dev.argtypes = [vp, vp, ctypes.c_int32, pi32, c_int, c_int, ctypes.c_double,
-                                                       c_int, vp, vp, vp, vp, vp, vp, vp,
-                                                       ctypes.POINTER(TargetParams), vp, vp]
-        L.pp_ingest_dev.argtypes = [vp, vp, vp, i64, c_int, ctypes.POINTER(ctypes.c_double),
-                                    ctypes.c_double, vp]
-        L.pp_ingest_sweeps_dev.argtypes = [vp, vp, c_int, vp, vp, c_int, vp, ctypes.c_double, vp]
-        L.pp_decode_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(DecodeParams), vp, vp, vp]
-        L.pp_decode_strided_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp,
-                                            ctypes.POINTER(DecodeParams), vp, vp, vp]
-        L.pp_decode_batch_dev.argtypes = [vp, vp, c_int, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp,
-                                          ctypes.POINTER(DecodeParams), vp, vp, vp]
-        L.pp_bias_relu_bn_dev.argtypes = [vp, vp, vp, i64, c_int, i64, vp, vp, i64, i64]
-        L.pp_bias_relu_bn_nhwc_dev.argtypes = [vp, vp, vp, i64, c_int, vp, vp, i64, i64]
-        dbl = ctypes.c_double
-        L.pp_relu_bn_train_fwd_dev.argtypes = [vp, vp, vp, vp, i64, c_int, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp]
-        L.pp_relu_bn_train_bwd_dev.argtypes = [vp, vp, vp, vp, vp, i64, i64, c_int, i64, vp, vp, vp, vp, vp, vp, vp]
-        L.pp_ctx_set_timing.argtypes = [vp, c_int]
-        L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
-                                          ctypes.POINTER(c_int)]
-        L.pp_ctx_read_kernel_ms.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_float), c_int,
-                                            ctypes.POINTER(c_int)]
-        L.pp_voxelize_check.argtypes = [vp, vp]
-        for name in EXPORTS:
-            fn = getattr(L, name)
-            if name not in ("pp_last_error", "pp_version", "pp_ctx_destroy"):
-                fn.restype = c_int
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def variant_lib(name):
+    """A build_variant() library as a second, independent instance in this process (its own code object, its own
+    contexts): ``Context(device, lib=variant_lib("strict"))``.  Tests only."""
+    with _lock:
+        if name not in _variants:
+            _variants[name] = _load(variant_path(name))
+    return _variants[name]
+
+
+def _load(path):
+    """Load one build of the library and declare the C ABI's argument types on it."""
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback.")
+    try:  # share torch's HIP runtime (same SONAME) when torch is in the process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the host drop-in
+        pass
+    L = ctypes.CDLL(path)
+    c_int, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    pi64 = ctypes.POINTER(ctypes.c_int64)
+    L.pp_last_error.restype = ctypes.c_char_p
+    L.pp_version.restype = ctypes.c_char_p
+    L.pp_device_count.restype = c_int
+    L.pp_ctx_create.argtypes = [c_int, ctypes.POINTER(vp)]
+    L.pp_ctx_destroy.argtypes = [vp]
+    L.pp_ctx_destroy.restype = None
+    L.pp_voxelize_reserve.argtypes = [vp, c_int, i64, ctypes.POINTER(VoxelParams)]
+    L.pp_voxelize_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                  ctypes.POINTER(VoxelParams), vp, vp, vp]
+    L.pp_voxelize_step_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                       ctypes.POINTER(VoxelParams), vp, vp, vp, ctypes.POINTER(c_int)]
+    L.pp_voxelize_step_pfn_canvas_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                                  ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
+                                                  c_int, vp, vp, vp, vp, c_int, ctypes.POINTER(c_int)]
+    L.pp_voxelize_step_kernel_name.argtypes = [ctypes.POINTER(VoxelParams), c_int, ctypes.c_char_p, c_int]
+    L.pp_voxelize_step_reset.argtypes = [vp]
+    L.pp_subtract_mean_dev.argtypes = [vp, vp, vp, c_int, i64, vp]
+    L.pp_voxelize_pfn_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                      ctypes.POINTER(VoxelParams), vp, c_int, vp, vp, vp]
+    L.pp_voxelize_pfn_canvas_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                             ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
+                                             c_int, vp, vp]
+    L.pp_voxelize_pfn_canvas_reuse_dev.argtypes = [vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int32), c_int,
+                                                   ctypes.POINTER(VoxelParams), vp, c_int, vp, c_int, c_int,
+                                                   c_int, vp, vp, vp]
+    L.pp_pfn_dense_dev.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp]
+    L.pp_scatter_canvas_dev.argtypes = [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_int, c_int, c_int]
+    L.pp_pfn_train_stats_dev.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp]
+    L.pp_pfn_train_backward_dev.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp]
+    L.pp_create_pillars_f64.argtypes = [vp, vp, i64, i64, i64, vp, pi64, pi64, vp, pi64, pi64,
+                                        ctypes.POINTER(VoxelParams), pi64]
+    L.pp_make_ious_f64.argtypes = [vp, vp, i64, pi64, vp, i64, pi64, vp, pi64, vp, pi64, vp, pi64]
+    L.pp_iou_check.argtypes = [vp, vp]
+    L.pp_make_ious_dev.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i64, vp]
+    L.pp_assign_targets_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
+                                        vp, ctypes.POINTER(TargetParams), vp, vp]
+    L.pp_assign_targets_grid_dev.argtypes = [vp, vp, c_int, c_int, ctypes.c_double, c_int, vp, i64, vp, vp,
+                                             vp, vp, vp, vp, ctypes.POINTER(TargetParams), vp, vp]
+    pi32 = ctypes.POINTER(ctypes.c_int32)
+    L.pp_assign_targets_batch_dev.argtypes = [vp, vp, ctypes.c_int32, pi32, i64, vp, vp, vp, vp, vp, vp, vp,
+                                              vp, vp, vp, ctypes.POINTER(TargetParams), vp, vp]
+    L.pp_assign_targets_grid_batch_dev.argtypes = [vp, vp, ctypes.c_int32, pi32, c_int, c_int, ctypes.c_double,
+                                                   c_int, vp, vp, vp, vp, vp, vp, vp,
+                                                   ctypes.POINTER(TargetParams), vp, vp]
+    L.pp_ingest_dev.argtypes = [vp, vp, vp, i64, c_int, ctypes.POINTER(ctypes.c_double),
+                                ctypes.c_double, vp]
+    L.pp_ingest_sweeps_dev.argtypes = [vp, vp, c_int, vp, vp, c_int, vp, ctypes.c_double, vp]
+    L.pp_decode_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(DecodeParams), vp, vp, vp]
+    L.pp_decode_strided_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp,
+                                        ctypes.POINTER(DecodeParams), vp, vp, vp]
+    L.pp_decode_batch_dev.argtypes = [vp, vp, c_int, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp,
+                                      ctypes.POINTER(DecodeParams), vp, vp, vp]
+    L.pp_bias_relu_bn_dev.argtypes = [vp, vp, vp, i64, c_int, i64, vp, vp, i64, i64]
+    L.pp_bias_relu_bn_nhwc_dev.argtypes = [vp, vp, vp, i64, c_int, vp, vp, i64, i64]
+    dbl = ctypes.c_double
+    L.pp_relu_bn_train_fwd_dev.argtypes = [vp, vp, vp, vp, i64, c_int, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp]
+    L.pp_relu_bn_train_bwd_dev.argtypes = [vp, vp, vp, vp, vp, i64, i64, c_int, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.pp_ctx_set_timing.argtypes = [vp, c_int]
+    L.pp_ctx_read_emit_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), c_int,
+                                      ctypes.POINTER(c_int)]
+    L.pp_ctx_read_kernel_ms.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_float), c_int,
+                                        ctypes.POINTER(c_int)]
+    L.pp_voxelize_check.argtypes = [vp, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("pp_last_error", "pp_version", "pp_ctx_destroy"):
+            fn.restype = c_int
+    return L
 
 
 class PPError(RuntimeError):
@@ -227,9 +272,11 @@ def check(rc, what="", msg=None):
 class Context:
     """Owner of one pp_ctx_t (scratch buffers for one device / one stream)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, lib_=None):
         self._h = ctypes.c_void_p()
-        check(lib().pp_ctx_create(int(device), ctypes.byref(self._h)), "pp_ctx_create")
+        self.lib = lib_ if lib_ is not None else lib()
+        check(self.lib.pp_ctx_create(int(device), ctypes.byref(self._h)), "pp_ctx_create",
+              None if lib_ is None else self.lib.pp_last_error())
         self.device = int(device)
         self._pid = os.getpid()
 
@@ -239,7 +286,7 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value and self._pid == os.getpid():
-            lib().pp_ctx_destroy(self._h)
+            self.lib.pp_ctx_destroy(self._h)
         self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -569,6 +569,34 @@ __device__ __forceinline__ void store_f32_sc1(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The hand-off to a sample's last workgroup (k_targets, k_targets_gt).  Shipped form: every byte the tail reads
+// or overwrites is stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), a workgroup
+// barrier, then ONE lane's agent-scope add on the ticket; the workgroup whose add came last learns so from
+// the value the add returned, joins a barrier, and loads the bytes with sc1 loads only (DESIGN.md section 5
+// maps this onto the guide's table and says where it departs: two-level tickets, several workgroups per CU).
+// -DPP_STRICT_HANDOFF builds the architecturally guaranteed form beside it -- lane 0's agent-scope RELEASE
+// fence (+ drain) in front of every ticket, no early ticket, an agent-scope ACQUIRE (+ drain + barrier) at
+// the head of the tail -- for tests/test_gpu_handoff.py, which asserts that both libraries give the same
+// bits over the fuzz cases and the alternating-input soak.  It is test infrastructure: ~2 us per launch.
+#ifdef PP_STRICT_HANDOFF
+constexpr bool kStrictHandoff = true;
+#else
+constexpr bool kStrictHandoff = false;
+#endif
+__device__ __forceinline__ void handoff_release_lane0() {  // behind the barrier that follows every wave's drain
+  if (kStrictHandoff) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (inline asm: the compiler may drop the fence's own wait)
+  }
+}
+__device__ __forceinline__ void handoff_acquire_tail() {  // every wave of the last workgroup
+  if (kStrictHandoff) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // The last workgroup: column argmax from the workgroups' entries, then the forced rows.  A
 // column whose argmax is anchor 0 -- all-zero columns included -- is dropped, exactly like the
 // reference's np.nonzero filter (box_utils.py:204-205).
@@ -1202,7 +1230,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   // its own to order, so no drain -- and the counter's round trip runs under its row stores.
   unsigned tk = 0u;
   unsigned *my_ticket1 = t.ticket1 + (size_t)(tile >> t.ticket_shift) * kTicketPad;
-  if (!contrib && t.G != 0 && tid == 0) tk = atomicAdd(my_ticket1, 1u);
+  if (!kStrictHandoff && !contrib && t.G != 0 && tid == 0) tk = atomicAdd(my_ticket1, 1u);
   int pbase = 0, npos = 0;
   if (!skip) {
 #pragma unroll
@@ -1282,8 +1310,8 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   }
   IOU_STAMP(6);
   if (t.G == 0) return;
-  if (contrib) {
-    if (wv == 0) write_columns(last_j0, last_tb, last_base);
+  if (contrib || kStrictHandoff) {
+    if (contrib && wv == 0) write_columns(last_j0, last_tb, last_base);
     // The last workgroup to get here finishes the job.  Every store above that the tail depends on
     // is write-through; drained per wave, then one agent-scope add per workgroup: the workgroup
     // whose add comes last reads the others' entries with sc1 loads and may overwrite their rows.
@@ -1291,7 +1319,10 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     IOU_STAMP(8);
-    if (tid == 0) tk = atomicAdd(my_ticket1, 1u);
+    if (tid == 0) {
+      handoff_release_lane0();
+      tk = atomicAdd(my_ticket1, 1u);
+    }
   }
   if (tid == 0) {
     // the last workgroup of its group of 1 << ticket_shift carries the group's ticket on
@@ -1307,6 +1338,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
   __syncthreads();
   IOU_STAMP(9);
   if (!S.is_last) return;
+  handoff_acquire_tail();
   if (t.G <= kForcedLds)
     targets_tail<true>(t, *reinterpret_cast<TailLds *>(smem));
   else
@@ -1905,6 +1937,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
   __syncthreads();
   IOU_STAMP(8);
   if (tid == 0) {
+    handoff_release_lane0();
     // two-level ticket, 64 bits a word: low half = workgroups (groups) done, high half = the pairs above the threshold
     // they stored -- the sample's last workgroup gets the length of the pair list with its ticket, not from a load
     u64 *my_ticket1 = reinterpret_cast<u64 *>(t.ticket1 + (size_t)(u >> t.ticket_shift) * kTicketPad);
@@ -1929,6 +1962,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
   __syncthreads();
   IOU_STAMP(9);
   if (!S.is_last) return;
+  handoff_acquire_tail();
   const unsigned n_pairs = (unsigned)S.contrib;  // pairs above the threshold in the sample's list
   if (t.G <= 64 && t.G * nsp <= kFastSlots * kTgtThreads && t.num_classes <= 63 && n_pairs <= (unsigned)kFastPos &&
       n_pairs <= (unsigned)t.G * t.pos_per_gt) {

@@ -24,7 +24,9 @@ class TargetAssigner:
     ``boxes.AnchorConfig`` -- then the kernels evaluate the anchor grid on the fly from a
     [per_cell,13] table and no per-anchor array exists at all (same results, bit for bit)."""
 
-    def __init__(self, anchors, canvas_height, pos_thresh=0.6, num_classes=9, device=None):
+    def __init__(self, anchors, canvas_height, pos_thresh=0.6, num_classes=9, device=None, lib_=None):
+        """``lib_``: another build of the library (``_lib.variant_lib``), for A/B tests; default the product's."""
+        self._L = lib_ if lib_ is not None else _lib.lib()
         if isinstance(anchors, boxes.AnchorConfig):
             self._init_common(canvas_height, pos_thresh, num_classes, device)
             self.grid = anchors
@@ -50,8 +52,12 @@ class TargetAssigner:
         self.canvas_height = float(canvas_height)
         self.pos_thresh = float(pos_thresh)
         self.num_classes = int(num_classes)
-        self._ctx = _lib.Context(self.device.index)
+        self._ctx = _lib.Context(self.device.index, lib_=self._L)
         self._prm = _lib.TargetParams(self.pos_thresh, self.canvas_height, self.num_classes, 0)
+
+    def _check(self, rc, what):
+        if rc != _lib.PP_OK:
+            _lib.check(rc, what, self._L.pp_last_error())
 
     def _gt_to_device(self, gt_centers, gt_wlh, gt_yaw, gt_classes):
         gt_centers = np.asarray(gt_centers, np.float64).reshape(-1, 3)
@@ -81,20 +87,20 @@ class TargetAssigner:
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self.grid is not None:
             c = self.grid
-            rc = _lib.lib().pp_assign_targets_grid_dev(
+            rc = self._L.pp_assign_targets_grid_dev(
                 self._ctx.handle, stream, c.fm_height, c.fm_width, float(c.fm_scale), c.per_cell,
                 _vp(self.types), G, _vp(g_corners), _vp(g_centers_img), _vp(g_centers), _vp(g_wlh),
                 _vp(g_yaw), _vp(g_class), ctypes.byref(self._prm), _vp(cls_t), _vp(reg_t))
-            _lib.check(rc, "pp_assign_targets_grid_dev")
+            self._check(rc, "pp_assign_targets_grid_dev")
         else:
-            rc = _lib.lib().pp_assign_targets_dev(
+            rc = self._L.pp_assign_targets_dev(
                 self._ctx.handle, stream, self.A, _vp(self.a_corners), _vp(self.a_centers),
                 _vp(self.a_wlh), _vp(self.a_yaw), G, _vp(g_corners), _vp(g_centers_img),
                 _vp(g_centers), _vp(g_wlh), _vp(g_yaw), _vp(g_class), ctypes.byref(self._prm),
                 _vp(cls_t), _vp(reg_t))
-            _lib.check(rc, "pp_assign_targets_dev")
+            self._check(rc, "pp_assign_targets_dev")
         if check:
-            _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_dev")
+            self._check(self._L.pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_dev")
         return cls_t, reg_t
 
     # ------------------------------------------------------------------ a batch of samples per launch
@@ -147,16 +153,16 @@ class TargetAssigner:
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self.grid is not None:
             c = self.grid
-            rc = _lib.lib().pp_assign_targets_grid_batch_dev(
+            rc = self._L.pp_assign_targets_grid_batch_dev(
                 self._ctx.handle, stream, B, counts, c.fm_height, c.fm_width, float(c.fm_scale), c.per_cell,
                 _vp(self.types), *gp, ctypes.byref(self._prm), _vp(cls_t), _vp(reg_t))
         else:
-            rc = _lib.lib().pp_assign_targets_batch_dev(
+            rc = self._L.pp_assign_targets_batch_dev(
                 self._ctx.handle, stream, B, counts, self.A, _vp(self.a_corners), _vp(self.a_centers),
                 _vp(self.a_wlh), _vp(self.a_yaw), *gp, ctypes.byref(self._prm), _vp(cls_t), _vp(reg_t))
-        _lib.check(rc, "pp_assign_targets_batch_dev")
+        self._check(rc, "pp_assign_targets_batch_dev")
         if check:
-            _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_batch_dev")
+            self._check(self._L.pp_iou_check(self._ctx.handle, stream), "pp_assign_targets_batch_dev")
         return cls_t, reg_t
 
     def ious(self, g_corners_img, g_centers_img, check=True):
@@ -170,10 +176,10 @@ class TargetAssigner:
         G = int(gc.shape[0])
         out = torch.empty((self.A, G), **f64)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = _lib.lib().pp_make_ious_dev(self._ctx.handle, stream, _vp(self.a_corners),
+        rc = self._L.pp_make_ious_dev(self._ctx.handle, stream, _vp(self.a_corners),
                                          _vp(self.a_centers), 3, self.A, _vp(gc), _vp(gn),
                                          int(gn.shape[1]) if G else 3, G, _vp(out))
-        _lib.check(rc, "pp_make_ious_dev")
+        self._check(rc, "pp_make_ious_dev")
         if check:
-            _lib.check(_lib.lib().pp_iou_check(self._ctx.handle, stream), "pp_make_ious_dev")
+            self._check(self._L.pp_iou_check(self._ctx.handle, stream), "pp_make_ious_dev")
         return out

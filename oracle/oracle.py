@@ -380,6 +380,10 @@ def create_target(anchor_corners, gt_corners, anchor_centers, gt_centers_img,
     make_ious(anchor_corners, gt_corners, anchor_centers, gt_centers_img, ious)
     cls_targets = np.zeros((A, num_classes))
     reg_targets = np.zeros((A, reg_dims + 1))
+    if G == 0:
+        # the reference cannot get here (np.max over an empty axis raises, box_utils.py:193; its samples always
+        # carry a box): the library's documented extension is "no box -> all-zero targets", in these shapes
+        return cls_targets, reg_targets, ious
     gt_box_classes = np.asarray(gt_classes, np.int32)
     max_ious = np.max(ious, axis=1)
     arg_max_ious = np.argmax(ious, axis=1)

@@ -21,6 +21,7 @@ def _native_built():
     if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) or shutil.which("hipcc"):
         pp_amd._lib.build()
         pp_amd._lib.build_pybind_module()
+        pp_amd._lib.build_variant("strict")
     from oracle import oracle as O
     O.build()
 

@@ -274,28 +274,60 @@ def test_small_and_odd_shapes(gpu, oracle, fm, per_cell, G, classes):
     assert np.array_equal(d, ious)
 
 
-def test_repeated_calls_are_identical(gpu, oracle):
-    """The kernel's tail reads what the other workgroups (other XCDs) published through write-through
-    stores and a ticket -- 300 back-to-back calls, with unrelated traffic on the chip in between, must
-    all give the first call's bits (a stale read would show as a missing forced row or a wrong argmax)."""
+def _stream(gpu):
+    import ctypes
     import torch
-    from pp_amd import boxes, synth
+    return ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+
+
+def _soak_single(ta, sets, refs, gpu, calls):
+    """Alternating inputs on ONE context: call k runs set order[k]; the first call of every set is checked against
+    its OWN oracle result, every later call of the set must reproduce that call's bits (mismatches are counted on the
+    device: nothing synchronises inside the loop, so the launches run back to back with the side traffic)."""
+    import torch
+    from util import SideTraffic, check_targets, soak_order
+    g = [ta._gt_to_device(s["centers"], s["wlh"], s["yaw"], s["classes"]) for s in sets]
+    order = soak_order(len(sets), calls)
+    first, bad = {}, torch.zeros((), dtype=torch.int64, device=gpu)
+    traffic = SideTraffic(gpu)
+    for it, k in enumerate(order):
+        if it % 3 == 0:
+            traffic.flush()
+        if it % 2 == 0:
+            traffic.poke()
+        c, r = ta.assign_device(*g[k])
+        if k not in first:
+            first[k] = (c, r)
+        else:
+            bad += (torch.ne(c, first[k][0]).any() | torch.ne(r, first[k][1]).any()).to(torch.int64)
+    traffic.close()
+    torch.cuda.synchronize()
+    assert ta._L.pp_iou_check(ta._ctx.handle, _stream(gpu)) == 0
+    for k, (c, r) in first.items():
+        check_targets(c, r, *refs[k])
+    assert int(bad.item()) == 0, f"{int(bad.item())} of {len(order)} calls differ from their own set's result"
+    return len(order)
+
+
+def test_repeated_calls_are_identical(gpu, oracle):
+    """The kernels' tail reads what the other workgroups (other XCDs) published through write-through stores and a
+    ticket.  A soak that repeats ONE input cannot see a stale read (the previous call left the same bytes), so the
+    calls ALTERNATE between six box sets on one context -- different numbers of boxes, positives, forced anchors,
+    one empty set, every ordered pair of sets adjacent at least once -- with cache-flushing traffic on the stream and
+    unrelated traffic on a second stream; every call is held against its own set's oracle result.  Both kernels
+    (k_targets_gt: anchors on the fly; k_targets: uploaded arrays), BASELINE config 3 and the reference default."""
+    from pp_amd import boxes
     from pp_amd.targets import TargetAssigner
-    for cfg, H, n_gt in ((boxes.AnchorConfig(250, 250), 500, 40), (boxes.AnchorConfig.reference_default(), 600, 35)):
-        ta = TargetAssigner(cfg, canvas_height=H, device=gpu)
-        gt = synth.gt_boxes(n_gt, H, 13)
-        g = ta._gt_to_device(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"])
-        c0, r0 = ta.assign_device(*g)
-        junk = torch.empty((64 << 20,), dtype=torch.float32, device=gpu)
-        bad = 0
-        for it in range(300):
-            if it % 3 == 0:
-                junk.add_(1.0)                      # 512 MB of traffic: flushes L2 / the Infinity Cache
-            c, r = ta.assign_device(*g)
-            bad += int(not (torch.equal(c, c0) and torch.equal(r, r0)))
-        torch.cuda.synchronize()
-        assert bad == 0
-        assert (r0[:, 0] == 1).sum().item() >= n_gt // 2
+    from util import oracle_targets_for, soak_gt_sets
+    for cfg, H in ((boxes.AnchorConfig(250, 250), 500), (boxes.AnchorConfig.reference_default(), 600)):
+        anchors = boxes.make_anchors(cfg)
+        sets = soak_gt_sets(H)
+        refs = [oracle_targets_for(oracle, anchors, s, H, 0.6) for s in sets]
+        assert sum(int((r[:, 0] == 1).sum()) for _, r in refs) >= 60
+        assert len({int((r[:, 0] == 1).sum()) for _, r in refs}) >= 4       # the sets really differ
+        for src in (cfg, anchors):
+            ta = TargetAssigner(src, canvas_height=H, device=gpu)
+            assert _soak_single(ta, sets, refs, gpu, 300) >= 300
 
 
 # --------------------------------------------------------------------------- a batch of samples per launch
@@ -417,29 +449,74 @@ def test_batch_many_boxes_tail_beyond_lds(gpu, oracle):
         _check(cls_b[b], reg_b[b], ref_c, ref_r)
 
 
-def test_batch_repeated_calls_are_identical(gpu, oracle):
-    """The 300-call soak of the single-sample form, for the batch: four tails run in one launch, each behind its
-    own ticket; cache-flushing traffic in between."""
+def _soak_batches(ta, batches, refs, gpu, calls):
+    """The batch form of _soak_single: call k runs batch order[k] into ONE pair of output tensors (the next call
+    overwrites the rows this one wrote -- forced rows of the previous batch included)."""
     import torch
+    from util import SideTraffic, check_targets, soak_order
+    up = [ta.upload_batch(b) for b in batches]
+    order = soak_order(len(batches), calls)
+    first, bad = {}, torch.zeros((), dtype=torch.int64, device=gpu)
+    out = None
+    traffic = SideTraffic(gpu)
+    for it, k in enumerate(order):
+        if it % 3 == 0:
+            traffic.flush()
+        if it % 2 == 0:
+            traffic.poke()
+        c, r = ta.assign_batch_device(*up[k], out=out)
+        out = (c, r)
+        if k not in first:
+            first[k] = (c.clone(), r.clone())
+        else:
+            bad += (torch.ne(c, first[k][0]).any() | torch.ne(r, first[k][1]).any()).to(torch.int64)
+    traffic.close()
+    torch.cuda.synchronize()
+    assert ta._L.pp_iou_check(ta._ctx.handle, _stream(gpu)) == 0
+    for k, (c, r) in first.items():
+        for b in range(len(batches[k])):
+            check_targets(c[b], r[b], *refs[k][b])
+    assert int(bad.item()) == 0, f"{int(bad.item())} of {len(order)} calls differ from their own batch's result"
+    return len(order)
+
+
+def test_batch_repeated_calls_are_identical(gpu, oracle):
+    """The alternating-input soak for the batch form: four tails run in one launch, each behind its own ticket, and
+    consecutive calls carry DIFFERENT batches (different box counts per sample slot, an empty sample that moves from
+    slot to slot) into the same output tensors -- a tail that read the previous call's list, or a zero fill that
+    landed after a forced row, shows as a difference from the batch's own oracle result."""
     from pp_amd import boxes
     from pp_amd.targets import TargetAssigner
+    from util import oracle_targets_for
     for cfg, H in ((boxes.AnchorConfig(250, 250), 500), (boxes.AnchorConfig.reference_default(), 600)):
-        ta = TargetAssigner(cfg, canvas_height=H, device=gpu)
-        gts = _ragged_batch(H, (13, 14, 15, 16), (40, 35, 0, 22))
-        counts, packed = ta.upload_batch(gts)
-        c0, r0 = ta.assign_batch_device(counts, packed)
-        c0, r0 = c0.clone(), r0.clone()
-        out = (torch.empty_like(c0), torch.empty_like(r0))
-        junk = torch.empty((64 << 20,), dtype=torch.float32, device=gpu)
-        bad = 0
-        for it in range(300):
-            if it % 3 == 0:
-                junk.add_(1.0)
-            c, r = ta.assign_batch_device(counts, packed, out=out)
-            bad += int(not (torch.equal(c, c0) and torch.equal(r, r0)))
-        torch.cuda.synchronize()
-        assert bad == 0
-        assert (r0[0, :, 0] == 1).sum().item() >= 20 and not r0[2].any()
+        anchors = boxes.make_anchors(cfg)
+        batches = [_ragged_batch(H, (13, 14, 15, 16), (40, 35, 0, 22)), _ragged_batch(H, (21, 22, 23, 24), (12, 0, 40, 31)),
+                   _ragged_batch(H, (31, 32, 33, 34), (0, 3, 40, 40)), _ragged_batch(H, (41, 42, 43, 44), (29, 40, 7, 0))]
+        refs = [[oracle_targets_for(oracle, anchors, g, H, 0.6) for g in b] for b in batches]
+        assert int((refs[0][0][1][:, 0] == 1).sum()) >= 20 and not refs[0][2][1].any()
+        for src in (cfg, anchors):
+            ta = TargetAssigner(src, canvas_height=H, device=gpu)
+            assert _soak_batches(ta, batches, refs, gpu, 200) >= 200
+
+
+def test_alternating_tail_kinds_on_one_context(gpu, oracle):
+    """The tails differ in the scratch they touch and re-arm (box-centric fast tail: registers and LDS only; more
+    than 256 pairs above the threshold or more than 64 boxes: the positives' hash table / per-anchor words in global
+    memory, column words in global memory beyond the LDS tail).  Alternate sets that take DIFFERENT tails on one
+    context: each call against its own oracle result."""
+    from pp_amd import boxes
+    from pp_amd.targets import TargetAssigner
+    from util import oracle_targets_for
+    rng = np.random.default_rng(11)
+    cfg, H = boxes.AnchorConfig(40, 40), 80
+    anchors = boxes.make_anchors(cfg)
+    sets = [_crowded_gt(rng, 30, H, 10, np.array([30.0, 40.0])), _crowded_gt(rng, 2100, H, 64, np.array([36.0, 48.0])),
+            _crowded_gt(rng, 12, H, 6, np.array([50.0, 20.0])), _crowded_gt(rng, 300, H, 200, np.array([20.0, 60.0])),
+            _crowded_gt(rng, 70, H, 30, np.array([44.0, 30.0]))]
+    refs = [oracle_targets_for(oracle, anchors, s, H, 0.45) for s in sets]
+    for src in (cfg, anchors):
+        ta = TargetAssigner(src, canvas_height=H, pos_thresh=0.45, device=gpu)
+        assert _soak_single(ta, sets, refs, gpu, 60) >= 60
 
 
 def test_feature_map_scale_not_a_power_of_two(gpu, oracle):
