@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -40,6 +41,31 @@ struct PinBuf {
   size_t bytes = 0;
   int ensure(size_t need);
   void release();
+};
+
+// A small persistent pool of host threads for the host drop-in entry points (pp_create_pillars_f64, pp_make_ious_f64):
+// the gathers from and the scatters into the caller's NumPy arrays are chains of cache misses in arrays no CPU cache
+// holds (an 86 MB tensor, a 40 MB matrix) -- disjoint rows, so they split across threads.  The reference's caller holds
+// the GIL for the whole call (pillars.cpp:429-435); the module releases it, so the threads are free to run.  Workers
+// spin briefly between the jobs of one call and sleep on a condition variable between calls.  Created lazily, per
+// context (a forked DataLoader worker creates its own context, hence its own pool); PP_HOST_THREADS sets the size
+// (default min(8, hardware threads); 1: everything on the calling thread).
+class HostPool {
+ public:
+  explicit HostPool(int threads);
+  ~HostPool();
+  int size() const { return n_; }  // parts per job, the calling thread included
+  // fn(part, parts) for part in [0, parts): part 0 on the calling thread; returns when every part is done
+  void run(const std::function<void(int, int)> &fn);
+  // the same on the workers only (parts = size() - 1, or inline at wait() when there is no worker): the caller goes on
+  // (HIP calls, a stream synchronize) and joins with wait()
+  void start(const std::function<void(int, int)> &fn);
+  void wait();
+
+ private:
+  struct Impl;
+  Impl *impl_;
+  int n_;
 };
 
 // Geometry of the implied cell grid, derived from the create_pillars scalars.
@@ -145,6 +171,10 @@ struct pp_ctx {
   // host drop-in staging
   pp::DevBuf stage_in, stage_out, stage_out2;
   pp::PinBuf pin_in, pin_out, pin_meta;
+  pp::HostPool *pool = nullptr;       // host threads of the drop-in entry points (lazily created)
+  hipEvent_t chunk_ev[12] = {};        // one per chunk of the features' device-to-host copy (lazily created)
+  int dropin_last_n = 0;               // pp_create_pillars_f64: the previous call's point count and how many points
+  int64_t dropin_last_end = 0;         // it emitted -- sizes the feature copy that is sent ahead of the descriptors
   // IoU / target scratch
   pp::DevBuf iou_ws;
   // the layout the target scratch was last armed for: {A, gcap, batch, units, form, splits, cand_per_wg, off_best,
@@ -159,3 +189,7 @@ struct pp_ctx {
   int ev_count = 0;
   int ev_columns = 7;    // bit k: column PP_KERNEL_k was recorded (k_step launches record the EMIT column only)
 };
+
+namespace pp {
+HostPool *host_pool(pp_ctx *ctx);  // the context's pool, created on first use
+}

@@ -22,6 +22,8 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 
 namespace pp {
 
@@ -65,6 +67,12 @@ struct TargetArgs {
   const double *g_corners, *g_centers_img, *g_centers, *g_wlh, *g_yaw;
   const int *g_class;
   double *ious;  // matrix mode: [A][G] f64, zeroed by the host; the pairs past the gate are written here
+  // matrix mode, sparse form (the host drop-in pp_make_ious_f64): instead of the dense matrix, the entries that are
+  // not zero as {anchor, box, IoU} records -- 0.16 % of the pairs at BASELINE config 3 -- appended through one counter;
+  // a record beyond triple_cap is counted and dropped (the host then takes the dense form)
+  struct IouTriple *triples;
+  unsigned *triple_count;
+  unsigned triple_cap;
   double pos_thresh, canvas_height;
   int num_classes;
   // scratch
@@ -97,6 +105,11 @@ struct TargetArgs {
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
 };
+struct IouTriple {
+  unsigned anchor, box;
+  double iou;
+};
+static_assert(sizeof(IouTriple) == 16, "triple layout");
 // A pair above the threshold is two records in two arrays, index for index: the 16-byte key the tail's threads read
 // side by side (lane e <-> key e: one wave-level load is 1024 consecutive bytes) and the 48-byte row.  (One 64-byte
 // record per pair, read field by field with the lanes 64 bytes apart, made every wave-level load of the tail touch
@@ -1155,8 +1168,18 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
       __syncthreads();
       IOU_STAMP(4);
       if constexpr (MATRIX) {
-        for (int q = tid; q < wn; q += kTgtThreads)
-          t.ious[(i0 + S.pair_lane[q]) * t.G + j0 + S.pair_gt[q]] = S.iou[q];
+        if (t.triples) {
+          for (int q = tid; q < wn; q += kTgtThreads) {
+            const double val = S.iou[q];
+            if (val != 0.0) {  // (a zero is what the host's fill already wrote)
+              const unsigned at = atomicAdd(t.triple_count, 1u);
+              if (at < t.triple_cap) t.triples[at] = IouTriple{(unsigned)(i0 + S.pair_lane[q]), (unsigned)(j0 + S.pair_gt[q]), val};
+            }
+          }
+        } else {
+          for (int q = tid; q < wn; q += kTgtThreads)
+            t.ious[(i0 + S.pair_lane[q]) * t.G + j0 + S.pair_gt[q]] = S.iou[q];
+        }
         __syncthreads();
         continue;
       }
@@ -2027,6 +2050,46 @@ struct DeviceGuard2 {
 
 using namespace pp;
 
+// make_ious' launch: the dense matrix (ious_dev), or -- triples != NULL -- the entries that are not zero as records
+// behind *triple_count (zeroed here)
+static int launch_make_ious(pp_ctx_t *ctx, hipStream_t stream, const double *a_corners_dev, const double *a_centers_dev,
+                            int64_t a_center_cols, int64_t A, const double *g_corners_dev, const double *g_centers_dev,
+                            int64_t g_center_cols, int64_t G, double *ious_dev, IouTriple *triples,
+                            unsigned *triple_count, unsigned triple_cap) {
+  DeviceGuard2 guard(ctx->device);
+  int rc = ctx->iou_ws.ensure(4096);
+  if (rc) return rc;
+  int *errflag = static_cast<int *>(ctx->iou_ws.ptr);
+  PP_HIP_TRY(hipMemsetAsync(errflag, 0, 4, stream));
+  if (triples) {
+    PP_HIP_TRY(hipMemsetAsync(triple_count, 0, 4, stream));
+  } else {
+    // every entry is written (pillars.cpp:421,424): zeros by this fill, the 0.16 % of the pairs that
+    // pass the centre gate by the kernel behind it on the same stream
+    PP_HIP_TRY(hipMemsetAsync(ious_dev, 0, (size_t)A * (size_t)G * 8, stream));
+  }
+  TargetArgs t{};
+  t.A = A;
+  t.G = (int)G;
+  t.a_corners = a_corners_dev;
+  t.a_centers = a_centers_dev;
+  t.a_center_cols = (int)a_center_cols;
+  t.g_center_cols = (int)g_center_cols;
+  t.g_corners = g_corners_dev;
+  t.g_centers_img = g_centers_dev;
+  t.ious = ious_dev;
+  t.triples = triples;
+  t.triple_count = triple_count;
+  t.triple_cap = triple_cap;
+  t.errflag = errflag;
+  const unsigned nwg = (unsigned)((A + kTgtThreads - 1) / kTgtThreads);
+  TargetBatch bt{};
+  bt.g_off[1] = (int)G;
+  hipLaunchKernelGGL(k_targets<true>, dim3(nwg), dim3(kTgtThreads), 0, stream, t, bt);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
 extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_corners_dev,
                                 const double *a_centers_dev, int64_t a_center_cols, int64_t A,
                                 const double *g_corners_dev, const double *g_centers_dev,
@@ -2045,32 +2108,8 @@ extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_co
     set_error("pp_make_ious_dev: NULL argument");
     return PP_ERR_VALUE;
   }
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DeviceGuard2 guard(ctx->device);
-  int rc = ctx->iou_ws.ensure(4096);
-  if (rc) return rc;
-  int *errflag = static_cast<int *>(ctx->iou_ws.ptr);
-  PP_HIP_TRY(hipMemsetAsync(errflag, 0, 4, stream));
-  // every entry is written (pillars.cpp:421,424): zeros by this fill, the 0.16 % of the pairs that
-  // pass the centre gate by the kernel behind it on the same stream
-  PP_HIP_TRY(hipMemsetAsync(ious_dev, 0, (size_t)A * (size_t)G * 8, stream));
-  TargetArgs t{};
-  t.A = A;
-  t.G = (int)G;
-  t.a_corners = a_corners_dev;
-  t.a_centers = a_centers_dev;
-  t.a_center_cols = (int)a_center_cols;
-  t.g_center_cols = (int)g_center_cols;
-  t.g_corners = g_corners_dev;
-  t.g_centers_img = g_centers_dev;
-  t.ious = ious_dev;
-  t.errflag = errflag;
-  const unsigned nwg = (unsigned)((A + kTgtThreads - 1) / kTgtThreads);
-  TargetBatch bt{};
-  bt.g_off[1] = (int)G;
-  hipLaunchKernelGGL(k_targets<true>, dim3(nwg), dim3(kTgtThreads), 0, stream, t, bt);
-  PP_HIP_TRY(hipGetLastError());
-  return PP_OK;
+  return launch_make_ious(ctx, static_cast<hipStream_t>(stream_), a_corners_dev, a_centers_dev, a_center_cols, A,
+                          g_corners_dev, g_centers_dev, g_center_cols, G, ious_dev, nullptr, nullptr, 0);
 }
 
 // error flag of the last IoU / target launch on this context (synchronises)
@@ -2117,16 +2156,30 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
   }
   DeviceGuard2 guard(ctx->device);
   hipStream_t stream = nullptr;
+  static const bool trace = getenv("PP_DROPIN_TRACE") != nullptr;  // development knob: where a call's time goes
+  auto t_prev = std::chrono::steady_clock::now();
+  double t_us[5] = {0, 0, 0, 0, 0};
+  auto lap = [&](int k) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    t_us[k] += std::chrono::duration<double, std::micro>(now - t_prev).count();
+    t_prev = now;
+  };
   // pinned staging: anchors [A][8] + [A][2], gts [G][8] + [G][2]
   const size_t in_bytes = ((size_t)A * 10 + (size_t)G * 10) * 8;
   int rc = ctx->pin_in.ensure(in_bytes);
   if (rc) return rc;
   rc = ctx->stage_in.ensure(in_bytes);
   if (rc) return rc;
-  rc = ctx->stage_out2.ensure((size_t)A * G * 8);
-  if (rc) return rc;
-  rc = ctx->pin_out.ensure((size_t)A * G * 8);
-  if (rc) return rc;
+  // The signature demands every entry of the caller's [A,G] matrix written (pillars.cpp:421,424) -- 40 MB at BASELINE
+  // config 3, of which ~8 000 entries are not zero.  Sparse form: the device returns those entries as 16-byte records
+  // (128 kB over PCIe instead of 40 MB), the pool's threads zero the caller's matrix WHILE the anchors travel and the
+  // kernel runs, then the records are written over the zeros.  More records than the list holds (every anchor near
+  // every box): the dense form below, as before.
+  const size_t cells = (size_t)A * (size_t)G;
+  const unsigned cap = (unsigned)std::min<size_t>(std::max<size_t>(cells / 16, 1u << 16), 8u << 20);  // <= 128 MB
+  const bool sparse = A < (1ll << 32) && cells >= 4096;
+  HostPool *pool = host_pool(ctx);
   double *h = static_cast<double *>(ctx->pin_in.ptr);
   double *h_ac = h, *h_an = h_ac + A * 8, *h_gc = h_an + A * 2, *h_gn = h_gc + G * 8;
   auto rd = [](const void *base, int64_t off) {
@@ -2134,35 +2187,100 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
     std::memcpy(&v, static_cast<const char *>(base) + off, 8);
     return v;
   };
-  for (int64_t i = 0; i < A; ++i) {
-    for (int k = 0; k < 4; ++k)
-      for (int c = 0; c < 2; ++c) h_ac[i * 8 + k * 2 + c] = rd(a_corners, i * ac[0] + k * ac[1] + c * ac[2]);
-    h_an[i * 2] = rd(a_centers, i * an[0]);
-    h_an[i * 2 + 1] = rd(a_centers, i * an[0] + an[1]);
-  }
+  const bool ac_dense = ac[2] == 8 && ac[1] == 16 && ac[0] == 64;
+  pool->run([&](int part, int parts) {  // the anchors' rows, split across the threads
+    const int64_t i0 = A * part / parts, i1 = A * (part + 1) / parts;
+    if (ac_dense && i1 > i0)
+      std::memcpy(h_ac + i0 * 8, static_cast<const char *>(a_corners) + i0 * 64, (size_t)(i1 - i0) * 64);
+    for (int64_t i = i0; i < i1; ++i) {
+      if (!ac_dense)
+        for (int k = 0; k < 4; ++k)
+          for (int c = 0; c < 2; ++c) h_ac[i * 8 + k * 2 + c] = rd(a_corners, i * ac[0] + k * ac[1] + c * ac[2]);
+      h_an[i * 2] = rd(a_centers, i * an[0]);
+      h_an[i * 2 + 1] = rd(a_centers, i * an[0] + an[1]);
+    }
+  });
   for (int64_t j = 0; j < G; ++j) {
     for (int k = 0; k < 4; ++k)
       for (int c = 0; c < 2; ++c) h_gc[j * 8 + k * 2 + c] = rd(g_corners, j * gc[0] + k * gc[1] + c * gc[2]);
     h_gn[j * 2] = rd(g_centers, j * gn[0]);
     h_gn[j * 2 + 1] = rd(g_centers, j * gn[0] + gn[1]);
   }
+  lap(0);
   double *d = static_cast<double *>(ctx->stage_in.ptr);
-  PP_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, stream));
+  char *dst = static_cast<char *>(ious);
+  const bool out_dense = io[1] == 8 && io[0] == G * 8;
+  if (sparse) {
+    rc = ctx->stage_out2.ensure(256 + (size_t)cap * 16);
+    if (rc) return rc;
+    rc = ctx->pin_meta.ensure(256);
+    if (rc) return rc;
+    char *so = static_cast<char *>(ctx->stage_out2.ptr);
+    unsigned *count_dev = reinterpret_cast<unsigned *>(so);
+    IouTriple *triples_dev = reinterpret_cast<IouTriple *>(so + 256);
+    unsigned *count_host = static_cast<unsigned *>(ctx->pin_meta.ptr);
+    PP_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, stream));
+    rc = launch_make_ious(ctx, stream, d, d + A * 8, 2, A, d + A * 10, d + A * 10 + G * 8, 2, G, nullptr, triples_dev,
+                          count_dev, cap);
+    if (rc) return rc;
+    PP_HIP_TRY(hipMemcpyAsync(count_host, count_dev, 4, hipMemcpyDeviceToHost, stream));
+    // ... meanwhile: zeros into the caller's matrix (rows split across the workers)
+    const std::function<void(int, int)> zero_rows = [&](int part, int parts) {
+      const int64_t i0 = A * part / parts, i1 = A * (part + 1) / parts;
+      if (out_dense) {
+        if (i1 > i0) std::memset(dst + i0 * G * 8, 0, (size_t)(i1 - i0) * G * 8);
+      } else {
+        const double zero = 0.0;
+        for (int64_t i = i0; i < i1; ++i)
+          for (int64_t j = 0; j < G; ++j) std::memcpy(dst + i * io[0] + j * io[1], &zero, 8);
+      }
+    };
+    pool->start(zero_rows);
+    const hipError_t e_sync = hipStreamSynchronize(stream);
+    pool->wait();
+    PP_HIP_TRY(e_sync);
+    lap(1);
+    const unsigned count = *count_host;
+    if (count <= cap) {
+      if (count) {
+        rc = ctx->pin_out.ensure((size_t)count * 16);
+        if (rc) return rc;
+        PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, triples_dev, (size_t)count * 16, hipMemcpyDeviceToHost, stream));
+        PP_HIP_TRY(hipStreamSynchronize(stream));
+        const IouTriple *tr = static_cast<const IouTriple *>(ctx->pin_out.ptr);
+        for (unsigned k = 0; k < count; ++k)
+          std::memcpy(dst + (int64_t)tr[k].anchor * io[0] + (int64_t)tr[k].box * io[1], &tr[k].iou, 8);
+      }
+      lap(2);
+      if (trace)
+        fprintf(stderr, "pp_make_ious_f64: gather %.0f us | H2D + kernel (host zero fill alongside, %d threads) %.0f | %u records back + written %.0f\n",
+                t_us[0], pool->size(), t_us[1], count, t_us[2]);
+      return pp_iou_check(ctx, stream);
+    }
+    // the list overflowed: the anchors are on the device already, take the dense form
+  } else {
+    PP_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, stream));
+  }
+  rc = ctx->stage_out2.ensure(cells * 8);
+  if (rc) return rc;
+  rc = ctx->pin_out.ensure(cells * 8);
+  if (rc) return rc;
   rc = pp_make_ious_dev(ctx, stream, d, d + A * 8, 2, A, d + A * 10, d + A * 10 + G * 8, 2, G,
                         static_cast<double *>(ctx->stage_out2.ptr));
   if (rc) return rc;
-  PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, ctx->stage_out2.ptr, (size_t)A * G * 8,
-                            hipMemcpyDeviceToHost, stream));
+  PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, ctx->stage_out2.ptr, cells * 8, hipMemcpyDeviceToHost, stream));
   PP_HIP_TRY(hipStreamSynchronize(stream));
   // every entry is written (pillars.cpp:421,424)
   const double *src = static_cast<const double *>(ctx->pin_out.ptr);
-  char *dst = static_cast<char *>(ious);
-  if (io[1] == 8 && io[0] == G * 8) {
-    std::memcpy(dst, src, (size_t)A * G * 8);
-  } else {
-    for (int64_t i = 0; i < A; ++i)
-      for (int64_t j = 0; j < G; ++j) std::memcpy(dst + i * io[0] + j * io[1], &src[i * G + j], 8);
-  }
+  pool->run([&](int part, int parts) {
+    const int64_t i0 = A * part / parts, i1 = A * (part + 1) / parts;
+    if (out_dense) {
+      if (i1 > i0) std::memcpy(dst + i0 * G * 8, src + i0 * G, (size_t)(i1 - i0) * G * 8);
+    } else {
+      for (int64_t i = i0; i < i1; ++i)
+        for (int64_t j = 0; j < G; ++j) std::memcpy(dst + i * io[0] + j * io[1], &src[i * G + j], 8);
+    }
+  });
   return pp_iou_check(ctx, stream);
 }
 

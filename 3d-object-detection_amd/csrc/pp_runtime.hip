@@ -4,8 +4,12 @@
 #include "pp_common.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace pp {
 
@@ -74,6 +78,102 @@ void PinBuf::release() {
   bytes = 0;
 }
 
+struct HostPool::Impl {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<unsigned long long> gen{0};   // bumped once per job
+  std::atomic<int> pending{0};              // worker parts of the current job still running
+  std::atomic<bool> stop{false};
+  const std::function<void(int, int)> *job = nullptr;
+  int first_part = 0, parts = 0;            // worker w runs part first_part + w of `parts`
+  const std::function<void(int, int)> *deferred = nullptr;  // start() without workers: run at wait()
+
+  void worker(int w) {
+    unsigned long long seen = 0;
+    for (;;) {
+      // between the jobs of one call: spin (a job follows the previous one within microseconds); then sleep
+      int spins = 0;
+      while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+        if (++spins < 4000) {
+          __builtin_ia32_pause();
+        } else {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || stop.load(); });
+        }
+      }
+      if (stop.load()) return;
+      seen = gen.load(std::memory_order_acquire);
+      (*job)(first_part + w, parts);
+      pending.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void post(const std::function<void(int, int)> &fn, int first, int total) {
+    job = &fn;
+    first_part = first;
+    parts = total;
+    pending.store((int)workers.size(), std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(m);
+      gen.fetch_add(1, std::memory_order_acq_rel);
+    }
+    cv.notify_all();
+  }
+  void join() {
+    while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+};
+
+HostPool::HostPool(int threads) : impl_(new Impl), n_(std::max(1, threads)) {
+  for (int w = 0; w + 1 < n_; ++w) impl_->workers.emplace_back([this, w] { impl_->worker(w); });
+}
+
+HostPool::~HostPool() {
+  {
+    std::lock_guard<std::mutex> lk(impl_->m);
+    impl_->stop.store(true);
+  }
+  impl_->cv.notify_all();
+  for (auto &t : impl_->workers) t.join();
+  delete impl_;
+}
+
+void HostPool::run(const std::function<void(int, int)> &fn) {
+  if (n_ == 1) {
+    fn(0, 1);
+    return;
+  }
+  impl_->post(fn, 1, n_);
+  fn(0, n_);
+  impl_->join();
+}
+
+void HostPool::start(const std::function<void(int, int)> &fn) {
+  if (n_ == 1) {
+    impl_->deferred = &fn;
+    return;
+  }
+  impl_->post(fn, 0, n_ - 1);
+}
+
+void HostPool::wait() {
+  if (n_ == 1) {
+    if (impl_->deferred) (*impl_->deferred)(0, 1);
+    impl_->deferred = nullptr;
+    return;
+  }
+  impl_->join();
+}
+
+HostPool *host_pool(pp_ctx *ctx) {
+  if (!ctx->pool) {
+    int n = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("PP_HOST_THREADS")) n = std::max(1, std::min(64, atoi(e)));
+    ctx->pool = new HostPool(n);
+  }
+  return ctx->pool;
+}
+
 }  // namespace pp
 
 using namespace pp;
@@ -135,6 +235,9 @@ extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
   ctx->pin_in.release();
   ctx->pin_out.release();
   ctx->pin_meta.release();
+  delete ctx->pool;
+  for (auto &e : ctx->chunk_ev)
+    if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < 3; ++k) {
     for (auto &e : ctx->ev_start[k]) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_stop[k]) (void)hipEventDestroy(e);

@@ -2855,16 +2855,46 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   if (rc) return rc;
   rc = ctx->stage_out.ensure((size_t)l.ncap * 72);
   if (rc) return rc;
+  HostPool *pool = host_pool(ctx);
+  // development knobs of the host path (defaults: what tools/lab/dropin_trace.py measured best -- profiles/r06/NOTES.md:
+  // 8 threads, one host-to-device copy, the features sent ahead in two chunks, polled waits: 0.36 -> 0.20 ms per call)
+  static const int k_h2d_parts = [] { const char *e = getenv("PP_DROPIN_H2D_PARTS"); return e ? std::max(1, std::min(8, atoi(e))) : 1; }();
+  static const int k_chunks = [] { const char *e = getenv("PP_DROPIN_CHUNKS"); return e ? std::max(1, std::min(8, atoi(e))) : 2; }();
+  static const bool k_spec = [] { const char *e = getenv("PP_DROPIN_SPEC"); return e ? atoi(e) != 0 : true; }();
+  static const bool k_spin = [] { const char *e = getenv("PP_DROPIN_SPIN"); return e ? atoi(e) != 0 : true; }();
+  // A call waits for the device two or three times, for tens of microseconds each: polled, not slept on (an interrupt-driven
+  // wake-up costs about as much as the wait itself).
+  auto wait_event = [&](hipEvent_t ev) -> hipError_t {
+    if (!k_spin) return hipEventSynchronize(ev);
+    for (;;) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e != hipErrorNotReady) return e;
+      __builtin_ia32_pause();
+    }
+  };
+  constexpr int kMaxEv = (int)(sizeof ctx->chunk_ev / sizeof ctx->chunk_ev[0]);
+  for (int c = 0; c < kMaxEv; ++c)
+    if (!ctx->chunk_ev[c]) PP_HIP_TRY(hipEventCreateWithFlags(&ctx->chunk_ev[c], hipEventDisableTiming));
   {
+    // the caller's points are a strided view (data/dataset.py:88 passes the transpose of a [4, n] array): rows split
+    // across the pool's threads; a part's host-to-device copy runs under the next part's gather
     double *dst = static_cast<double *>(ctx->pin_in.ptr);
     const char *src = static_cast<const char *>(points);
-    for (int64_t i = 0; i < n; ++i)
-      for (int c = 0; c < 4; ++c)
-        std::memcpy(&dst[i * 4 + c], src + i * ps0 + c * ps1, 8);
+    const int parts_h2d = n >= 8192 ? k_h2d_parts : 1;
+    for (int h = 0; h < parts_h2d; ++h) {
+      const int64_t r0 = (int64_t)n * h / parts_h2d, r1 = (int64_t)n * (h + 1) / parts_h2d;
+      pool->run([&](int part, int parts) {
+        const int64_t i0 = r0 + (r1 - r0) * part / parts, i1 = r0 + (r1 - r0) * (part + 1) / parts;
+        for (int64_t i = i0; i < i1; ++i)
+          for (int c = 0; c < 4; ++c)
+            std::memcpy(&dst[i * 4 + c], src + i * ps0 + c * ps1, 8);
+      });
+      if (r1 > r0)
+        PP_HIP_TRY(hipMemcpyAsync(static_cast<char *>(ctx->stage_in.ptr) + r0 * 32, dst + r0 * 4, (size_t)(r1 - r0) * 32,
+                                  hipMemcpyHostToDevice, stream));
+    }
   }
   lap(0);
-  PP_HIP_TRY(hipMemcpyAsync(ctx->stage_in.ptr, ctx->pin_in.ptr, (size_t)n * 32,
-                            hipMemcpyHostToDevice, stream));
   NPoints np;
   std::memset(&np, 0, sizeof np);
   np.n[0] = n;
@@ -2872,51 +2902,137 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
                                l.ncap, 4, 1, 1, np, 1, n, g, P, N, l, kModeCompact, nullptr,
                                nullptr, static_cast<double *>(ctx->stage_out.ptr), false);
   if (rc) return rc;
-  // descriptors back: totals, pillar_meta[P] (pillar order, written by k_emit in compact mode)
-  rc = ctx->pin_meta.ensure(256 + (size_t)P * 16);
+  // descriptors back in ONE copy: pillar_meta[P] (pillar order, written by k_emit in compact mode) and, behind it in the
+  // workspace, the totals
+  const size_t meta_bytes = (l.totals - l.meta) + 8;
+  rc = ctx->pin_meta.ensure(meta_bytes);
+  if (rc) return rc;
+  rc = ctx->pin_out.ensure((size_t)l.ncap * 72);
   if (rc) return rc;
   char *ws = static_cast<char *>(ctx->vox_ws[0].ptr);
   char *pm = static_cast<char *>(ctx->pin_meta.ptr);
-  PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.totals, 8, hipMemcpyDeviceToHost, stream));
-  PP_HIP_TRY(hipMemcpyAsync(pm + 256, ws + l.meta, (size_t)P * 16, hipMemcpyDeviceToHost, stream));
-  PP_HIP_TRY(hipStreamSynchronize(stream));
+  PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.meta, meta_bytes, hipMemcpyDeviceToHost, stream));
+  hipEvent_t ev_meta = ctx->chunk_ev[kMaxEv - 1];
+  PP_HIP_TRY(hipEventRecord(ev_meta, stream));
+  // The features follow WITHOUT waiting for the descriptors: how many points the call emits is only known from them, so
+  // the copy is sized by what the previous call of this shape emitted (consecutive sweeps are alike) plus an eighth,
+  // and topped up below when that was short.  In chunks: chunk k is scattered while chunk k + 1 is on its way.
+  int64_t cb[kMaxEv + 1];  // chunk c = compact points [cb[c], cb[c + 1])
+  int nch = 0;
+  cb[0] = 0;
+  auto issue_chunks = [&](int64_t upto, int pieces) -> int {
+    const int64_t from = cb[nch];
+    for (int c = 0; c < pieces && nch < kMaxEv - 2; ++c) {
+      const int64_t b1 = from + (upto - from) * (c + 1) / pieces;
+      if (b1 <= cb[nch]) continue;
+      PP_HIP_TRY(hipMemcpyAsync(static_cast<char *>(ctx->pin_out.ptr) + cb[nch] * 72,
+                                static_cast<const char *>(ctx->stage_out.ptr) + cb[nch] * 72, (size_t)(b1 - cb[nch]) * 72,
+                                hipMemcpyDeviceToHost, stream));
+      PP_HIP_TRY(hipEventRecord(ctx->chunk_ev[nch], stream));
+      cb[++nch] = b1;
+    }
+    return PP_OK;
+  };
+  if (k_spec && N > 0 && ctx->dropin_last_n == n && ctx->dropin_last_end > 0) {
+    const int64_t guess = std::min<int64_t>(n, ctx->dropin_last_end + ctx->dropin_last_end / 8);
+    rc = issue_chunks(guess, guess * 72 >= (256 << 10) ? k_chunks : 1);
+    if (rc) return rc;
+  }
+  PP_HIP_TRY(wait_event(ev_meta));
   lap(1);
   int tot[2];
-  std::memcpy(tot, pm, 8);
+  std::memcpy(tot, pm + (l.totals - l.meta), 8);
   if (num_cells) *num_cells = tot[0];
   const int npil = std::min(tot[0], std::min(P, max_pillars));
-  if (npil == 0) return PP_OK;
-  const int4 *meta = reinterpret_cast<const int4 *>(pm + 256);
-  const int64_t end = (int64_t)meta[npil - 1].y + meta[npil - 1].z;
-  rc = ctx->pin_out.ensure((size_t)end * 72);
-  if (rc) return rc;
-  if (N > 0) {
-    PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, ctx->stage_out.ptr, (size_t)end * 72,
-                              hipMemcpyDeviceToHost, stream));
-    PP_HIP_TRY(hipStreamSynchronize(stream));
+  if (npil == 0) {
+    if (nch) PP_HIP_TRY(hipStreamSynchronize(stream));  // the speculative copies still target the pinned buffer
+    return PP_OK;
   }
-  lap(2);
-  // scatter into the caller's arrays with pybind11 .mutable_at() bounds checks,
-  // pillar by pillar like pillars.cpp:335-396 (nothing else is touched)
+  const int4 *meta = reinterpret_cast<const int4 *>(pm);
+  const int64_t end = (int64_t)meta[npil - 1].y + meta[npil - 1].z;
+  ctx->dropin_last_n = n;
+  ctx->dropin_last_end = end;
   const double *feat = static_cast<const double *>(ctx->pin_out.ptr);
   char *tp = static_cast<char *>(tensor);
   char *ip = static_cast<char *>(indices);
+  auto write_index_row = [&](int p) {  // pillars.cpp:389-391
+    int cell = meta[p].x;
+    if (g.order != PP_ORDER_ROW_MAJOR)
+      cell = (int)(((unsigned long long)cell * g.mult_inv) % (unsigned long long)g.ncells);
+    const double canvas_x = (double)(cell % g.nx);
+    const double fy = (double)((g.ny - 1) - cell / g.nx);
+    const double canvas_y = (g.canvas_height - 1) - fy;
+    const double one = 1.0;
+    std::memcpy(ip + p * i_strides[0] + 0 * i_strides[1], &one, 8);
+    std::memcpy(ip + p * i_strides[0] + 1 * i_strides[1], &canvas_x, 8);
+    std::memcpy(ip + p * i_strides[0] + 2 * i_strides[1], &canvas_y, 8);
+  };
   // The usual caller hands in a C-contiguous [P,N,9] tensor (np.zeros, data/dataset.py:89): a pillar's live points are
   // then ONE contiguous run of live * 72 bytes -- but 7200 bytes from the next pillar's, in an 86 MB array that no CPU
-  // cache holds: the scatter was a chain of 12 000 cache misses, 195 of the call's 360 us.  The lines of the pillars a
-  // few iterations ahead are prefetched for writing while this one is copied.
+  // cache holds: the scatter is a chain of 12 000 cache misses (195 us of round 4's 360 us call on one thread; 150-178
+  // with the next pillars' lines prefetched for writing).  Nothing can go out of range in that layout once the shapes
+  // hold the call's pillars, so the rows -- disjoint -- are split across the pool's threads.
   const bool dense_t = tensor && t_strides[2] == 8 && t_strides[1] == 72 && t_shape[2] >= 9 && t_shape[1] >= N &&
                        t_shape[0] >= npil;
-  constexpr int kAhead = 12;
+  const bool dense_all = dense_t && indices && i_shape[0] >= npil && i_shape[1] >= 3;
+  if (N > 0 && cb[nch] < end) {  // nothing sent ahead, or the guess was short: the rest
+    rc = issue_chunks(end, (dense_all && (end - cb[nch]) * 72 >= (256 << 10)) ? k_chunks : 1);
+    if (rc) return rc;
+    if (cb[nch] < end) {  // (out of events: cannot happen with k_chunks <= 8 / 2)
+      set_error("create_pillars: internal: chunk events exhausted");
+      return PP_ERR_INTERNAL;
+    }
+  }
+  if (dense_all) {
+    int p_done = 0;
+    for (int c = 0; c < std::max(nch, 1); ++c) {
+      if (nch) PP_HIP_TRY(wait_event(ctx->chunk_ev[c]));
+      // the pillars whose points have all arrived: start + count <= cb[c + 1]
+      int p_hi = npil;
+      if (nch && cb[c + 1] < end) {
+        int lo = p_done, hi = npil;
+        while (lo < hi) {
+          const int mid = (lo + hi) / 2;
+          if ((int64_t)meta[mid].y + meta[mid].z <= cb[c + 1]) lo = mid + 1; else hi = mid;
+        }
+        p_hi = lo;
+      } else if (c + 1 < nch) {
+        continue;  // everything needed is here already; the later events are waited for at the end
+      }
+      const int p0 = p_done, p1 = p_hi;
+      p_done = p_hi;
+      if (p1 <= p0) continue;
+      pool->run([&](int part, int parts) {
+        const int q0 = p0 + (int)((int64_t)(p1 - p0) * part / parts), q1 = p0 + (int)((int64_t)(p1 - p0) * (part + 1) / parts);
+        constexpr int kAhead = 8;
+        for (int p = q0; p < q1; ++p) {
+          if (p + kAhead < q1) {
+            const char *nx = tp + (int64_t)(p + kAhead) * t_strides[0];
+            const int nl = std::min(meta[p + kAhead].z, N) * 72;
+            for (int o = 0; o < nl; o += 64) __builtin_prefetch(nx + o, 1, 0);
+            if (nl > 0) __builtin_prefetch(nx + nl - 1, 1, 0);
+          }
+          const int live = std::min(meta[p].z, N);
+          if (live > 0) std::memcpy(tp + (int64_t)p * t_strides[0], feat + (int64_t)meta[p].y * 9, (size_t)live * 72);
+          write_index_row(p);
+        }
+      });
+    }
+    if (nch) PP_HIP_TRY(wait_event(ctx->chunk_ev[nch - 1]));  // (a copy sent ahead may reach beyond `end`)
+    lap(2);
+    if (trace)
+      fprintf(stderr, "pp_create_pillars_f64: gather + H2D issue (%d parts) %.0f us | kernels + descriptors back %.0f | features back in %d chunks + scatter on %d threads %.0f\n",
+              n >= 8192 ? k_h2d_parts : 1, t_sec[0], t_sec[1], nch, pool->size(), t_sec[2]);
+    return PP_OK;
+  }
+  if (nch) PP_HIP_TRY(hipStreamSynchronize(stream));
+  lap(2);
+  // any other layout (strided views, undersized arrays): one thread, element by element with pybind11 .mutable_at()'s
+  // bounds checks, pillar by pillar like pillars.cpp:335-396 -- the writes made before an IndexError persist, nothing
+  // behind it is touched
   for (int p = 0; p < npil; ++p) {
     const int live = std::min(meta[p].z, N);
     if (dense_t) {
-      if (p + kAhead < npil) {
-        const char *nx = tp + (int64_t)(p + kAhead) * t_strides[0];
-        const int nl = std::min(meta[p + kAhead].z, N) * 72;
-        for (int o = 0; o < nl; o += 64) __builtin_prefetch(nx + o, 1, 0);
-        if (nl > 0) __builtin_prefetch(nx + nl - 1, 1, 0);
-      }
       if (live > 0) std::memcpy(tp + (int64_t)p * t_strides[0], feat + (int64_t)meta[p].y * 9, (size_t)live * 72);
     } else
     for (int k = 0; k < live; ++k) {
@@ -2933,16 +3049,7 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
       set_error("create_pillars: indices index (%d,2) out of range", p);
       return PP_ERR_INDEX;
     }
-    int cell = meta[p].x;
-    if (g.order != PP_ORDER_ROW_MAJOR)
-      cell = (int)(((unsigned long long)cell * g.mult_inv) % (unsigned long long)g.ncells);
-    const double canvas_x = (double)(cell % g.nx);
-    const double fy = (double)((g.ny - 1) - cell / g.nx);
-    const double canvas_y = (g.canvas_height - 1) - fy;
-    const double one = 1.0;
-    std::memcpy(ip + p * i_strides[0] + 0 * i_strides[1], &one, 8);
-    std::memcpy(ip + p * i_strides[0] + 1 * i_strides[1], &canvas_x, 8);
-    std::memcpy(ip + p * i_strides[0] + 2 * i_strides[1], &canvas_y, 8);
+    write_index_row(p);
   }
   lap(3);
   if (trace)

@@ -59,6 +59,47 @@ def build_pybind(force=False):
     return out
 
 
+def faithful_module_path():
+    import sysconfig
+    return os.path.join(_HERE, "pillars_faithful" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_faithful(force=False):
+    """Compile oracle/faithful_module.cpp -- the baseline-faithful CPU variant of BASELINE.md section 4 (bounds-checked
+    pybind11 accessors, one heap node per point, two std::unordered_map keyed on the cell's doubles) -- with the
+    reference's own build line (install_mods.sh:8: g++ -O3 -Wall -shared -std=c++11 -fPIC + the pybind11 includes;
+    c++14 because pybind11 3 needs it).  The polygon arithmetic is linked in from pp_oracle.c."""
+    import pybind11
+    import sysconfig
+    src = [os.path.join(_HERE, "faithful_module.cpp"), os.path.join(_HERE, "pp_oracle.c"), os.path.join(_HERE, "pp_oracle.h")]
+    out = faithful_module_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(p) for p in src):
+        return out
+    obj = os.path.join(_HERE, "pp_oracle.o")
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-Wall", "-std=c11", "-fPIC", "-ffp-contract=off", "-c",
+                           src[1], "-o", obj])
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-Wall", "-shared", "-std=c++14", "-fPIC",
+                           "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I" + _HERE,
+                           src[0], obj, "-o", out + ".tmp", "-lm"])
+    os.replace(out + ".tmp", out)
+    return out
+
+
+_faithful = None
+
+
+def faithful_module():
+    """The module `pillars_faithful`: create_pillars / make_ious with the reference's signatures AND its cost
+    structure (what bench.py times as cpu_baseline.faithful)."""
+    global _faithful
+    if _faithful is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pillars_faithful", build_faithful())
+        _faithful = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_faithful)
+    return _faithful
+
+
 _pymod = None
 
 

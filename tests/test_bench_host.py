@@ -59,3 +59,20 @@ def test_per_rank_and_min_max_single_process():
     mm = b.ranks_min_max(ctx, 40.0, 177_792_000)
     assert mm["k_step_us"] == [40.0, 40.0] and mm["per_rank_k_step_us"] == [40.0]
     assert abs(mm["frac"][0] - 177_792_000 / 40e-6 / 8e12) < 1e-12 and mm["frac"][0] == mm["frac"][1]
+
+
+def test_cpu_baseline_reports_both_variants():
+    """bench.py's cpu_baseline: the C port (top-level value: the faster, conservative one) AND the baseline-faithful
+    variant of BASELINE.md section 4, each on one core, as 4 worker processes and on all host cores (tiny budgets here)."""
+    b = _bench()
+    cb = b.cpu_baseline(seconds_budget=0.8, workers=4, worker_budget=0.6, c1_budget=0.8, all_budget=0.6)
+    assert cb["kind"] == "port" and cb["unit"] == "sweeps/s" and cb["cores"] == 1
+    assert cb["value"] == cb["port"]["one_core"]["value"] > 0
+    for variant in ("port", "faithful"):
+        rec = cb[variant]
+        assert rec["one_core"]["cores"] == 1 and rec["one_core"]["calls"] >= 5
+        assert rec["workers"]["processes"] == 4 and rec["workers"]["value"] > 0
+        assert rec["all_cores"]["processes"] >= 1 and rec["all_cores"]["value"] > 0
+    assert cb["c1"]["value"] > 0 and cb["c1"]["faithful"]["value"] > 0
+    r = b.dropin_record(0.2, 10.0, "x", faithful_ms=20.0)
+    assert r["meets_50x"] is True and abs(r["faithful_speedup"] - 100.0) < 1e-9 and r["faithful_meets_50x"] is True

@@ -103,6 +103,7 @@ def test_bench_contract_line(gpu):
         r = dh[leg]
         assert r["hip_ms"] > 0 and r["cpu_ms"] > 0 and abs(r["speedup"] - r["cpu_ms"] / r["hip_ms"]) < 1e-9
         assert r["meets_50x"] == (r["speedup"] >= 50.0)
+        assert r["faithful_cpu_ms"] > 0 and abs(r["faithful_speedup"] - r["faithful_cpu_ms"] / r["hip_ms"]) < 1e-9
 
 
 def test_fused_epilogue_equals_relu_batchnorm(gpu):

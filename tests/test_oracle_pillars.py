@@ -145,3 +145,81 @@ def test_pybind11_front_of_the_oracle_equals_the_ctypes_one(oracle):
     out = np.full((1, 2), -7.0)
     assert m.make_ious(a, g, np.array([[.5, .5, 0]]), np.array([[.5, .5, 0], [50.5, 50.5, 0]]), out) is None
     assert out[0, 0] == 1.0 and out[0, 1] == 0.0
+
+
+def _blocks_by_cell(T, I):
+    return {(I[p, 1], I[p, 2]): T[p] for p in np.nonzero(I[:, 0])[0]}
+
+
+def test_baseline_faithful_variant_equals_the_oracle_bit_for_bit(oracle):
+    """oracle/faithful_module.cpp: the CPU baseline BASELINE.md section 4 promises -- pybind11 .at() / .mutable_at() for
+    every element, one heap node per in-range point, two std::unordered_map keyed on the cell's doubles (the cost structure
+    of pillars.cpp:268-329, 335-396, 416-425) -- is what bench.py reports as cpu_baseline.faithful.  It must emit the
+    oracle's bits: per cell the same [N, 9] block and the same index row (the emission ORDER is its hash map's, arbitrary
+    like the reference's), the cap and the overflow rule included, and the reference's error behaviour (IndexError from
+    the bounds-checked store, pillars.cpp:48-56)."""
+    f = oracle.faithful_module()
+    assert sorted(n for n in dir(f) if not n.startswith("_")) == ["create_pillars", "make_ious"]
+    import pp_amd.synth as synth
+    pts = synth.lidar_like(20000, 12.0, 3).astype(np.float64)
+    agg = np.ascontiguousarray(pts.T)
+    view = agg.transpose([1, 0])                               # the strided view data/dataset.py:88 passes
+    for step, y_step, N in ((0.25, 0.25, 8), (0.5, 0.4, 40), (3.0, 3.0, 100)):   # the last: cells far beyond N points
+        args = (step, y_step, -12.0, -12.0, -3.0, 12.0, 12.0, 3.0, int(24 / y_step))
+        P = 20000
+        T, I = np.zeros((P, N, 9)), np.zeros((P, 3))
+        assert f.create_pillars(view, T, I, N, P, *args) is None
+        T2, I2 = np.zeros((P, N, 9)), np.zeros((P, 3))
+        m = oracle.create_pillars(pts, T2, I2, N, P, *args, order=oracle.ORDER_ROW_MAJOR)
+        got, want = _blocks_by_cell(T, I), _blocks_by_cell(T2, I2)
+        assert len(want) == m and got.keys() == want.keys()
+        assert all(np.array_equal(got[k], want[k]) for k in want)
+        assert int(I[:, 0].sum()) == m and not T[m:].any()
+        # overflow: exactly `cap` pillars, each the uncapped block of its cell; nothing beyond the cap is touched
+        cap = m // 3
+        Tc, Ic = np.zeros((P, N, 9)), np.zeros((P, 3))
+        f.create_pillars(view, Tc, Ic, N, cap, *args)
+        capped = _blocks_by_cell(Tc, Ic)
+        assert len(capped) == cap and not Tc[cap:].any() and not Ic[cap:].any()
+        assert all(np.array_equal(v, want[k]) for k, v in capped.items())
+    # strided outputs, never zeroed
+    big = np.full((50, 4, 18), 7.0)
+    Ts, Is = big[..., ::2], np.full((50, 3), 7.0)
+    f.create_pillars(v1_points(), Ts, Is, *V1_ARGS)
+    Tr, Ir = np.full((50, 4, 9), 7.0), np.full((50, 3), 7.0)
+    oracle.create_pillars(v1_points(), Tr, Ir, *V1_ARGS)
+    assert _blocks_by_cell(Ts, Is).keys() == _blocks_by_cell(Tr, Ir).keys() and (big[..., 1::2] == 7.0).all()
+    assert all(np.array_equal(v, _blocks_by_cell(Tr, Ir)[k]) for k, v in _blocks_by_cell(Ts, Is).items())
+    assert (Ts[2:] == 7.0).all() and (Ts[:2, 3] == 7.0).all()
+    # undersized outputs: the checked store raises, as in the reference
+    with pytest.raises(IndexError):
+        f.create_pillars(view, np.zeros((10, 4, 9)), np.zeros((10, 3)), 8, 2000, 0.25, 0.25, -12.0, -12.0, -3.0, 12.0, 12.0, 3.0, 96)
+    with pytest.raises(IndexError):
+        f.create_pillars(view, np.zeros((2000, 4, 9)), np.zeros((2000, 3)), 8, 2000, 0.25, 0.25, -12.0, -12.0, -3.0, 12.0, 12.0, 3.0, 96)
+
+
+def test_baseline_faithful_make_ious_equals_the_oracle(oracle):
+    """make_ious of the faithful variant (four checked reads per pair for the gate, a checked store, heap-backed rings for
+    a surviving pair; pillars.cpp:416-425, 149-160) against the oracle's: the dense matrix bit for bit, strided and
+    transposed outputs, every entry written, wrong winding raised."""
+    from pp_amd import boxes, synth
+    f = oracle.faithful_module()
+    anchors = boxes.make_anchors(boxes.AnchorConfig(60, 60))
+    gt = synth.gt_boxes(25, 120, 4, margin=10.0)
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 120)
+    A = anchors["corners"].shape[0]
+    want = np.full((A, 25), -3.0)
+    oracle.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, want)
+    got = np.full((A, 25), -5.0)
+    assert f.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, got) is None
+    assert np.array_equal(got, want) and (want > 0).sum() > 100
+    tr = np.full((25, A), -5.0)
+    f.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, tr.T)
+    assert np.array_equal(tr.T, want)
+    wide = np.full((A, 50), -5.0)
+    f.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, wide[:, ::2])
+    assert np.array_equal(wide[:, ::2], want) and (wide[:, 1::2] == -5.0).all()
+    with pytest.raises(ValueError):
+        f.make_ious(anchors["corners"][:, ::-1], k_img, anchors["centers"], c_img, got)
+    with pytest.raises(IndexError):
+        f.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, np.zeros((A, 24)))
