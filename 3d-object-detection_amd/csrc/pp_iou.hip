@@ -105,6 +105,10 @@ struct TargetArgs {
   float *cls_targets;  // [A][num_classes]
   float *reg_targets;  // [A][9]
 };
+// bits of the error word (pp_iou_check reports and clears them; both may be set by one launch)
+constexpr int kErrWinding = 1;      // IoU < 0: a box with the wrong corner winding (pillars.cpp:166-169)
+constexpr int kErrPosOverflow = 2;  // more pairs above the threshold than the positive list holds: entries dropped
+
 struct IouTriple {
   unsigned anchor, box;
   double iou;
@@ -1223,7 +1227,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets(TargetArgs t
     }
   }
   IOU_STAMP(5);
-  if (bad) atomicExch(t.errflag, 1);
+  if (bad) atomicOr(t.errflag, kErrWinding);
   if constexpr (MATRIX) return;
   // rows: positives of both targets, zero rows otherwise
   const int nc = t.num_classes;
@@ -1442,7 +1446,8 @@ __device__ void positives_tail(const TargetArgs &t, unsigned char *smem) {
   const unsigned n_raw = __hip_atomic_load(t.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned cap = (unsigned)t.G * t.pos_per_gt;
   const unsigned n = min(n_raw, cap);
-  if (n_raw > cap && tid == 0) atomicExch(t.errflag, 2);  // cannot happen: one entry per candidate at most
+  if (n_raw > cap && tid == 0) atomicOr(t.errflag, kErrPosOverflow);  // only with a box centre that is not finite on
+                                                                       // ONE axis (its window is a whole band of the map)
   if (n == 0) return;
   constexpr int kPer = kPosLds / kTgtThreads;
   const bool in_lds = n <= (unsigned)kPosLds;
@@ -1937,7 +1942,7 @@ __global__ __launch_bounds__(kTgtThreads) PP_TGT_OCC void k_targets_gt(TargetArg
         }
       }
     }
-    if (bad) atomicExch(t.errflag, 1);
+    if (bad) atomicOr(t.errflag, kErrWinding);
     if (wv == 0 && lane < 4) {
       // this workgroup's slot of the column list {box, anchor, IoU} and the pair's row, written whether or not a pair
       // overlapped (bits 0 = none): no counter, nothing stale, and the tail knows the list's length without a load.
@@ -2123,7 +2128,7 @@ extern "C" int pp_iou_check(pp_ctx_t *ctx, void *stream_) {
   if (flag) {
     // the flag is sticky across launches until it has been reported once
     PP_HIP_TRY(hipMemsetAsync(ctx->iou_ws.ptr, 0, 4, static_cast<hipStream_t>(stream_)));
-    if (flag == 2) {
+    if (flag & kErrPosOverflow) {  // (takes precedence: the scratch has to be re-armed whatever else happened)
       // the positive list overflowed (sized from the candidate count, so only reachable through boxes whose centre is
       // not finite): entries were dropped; re-arm every scratch word before the next call
       std::memset(ctx->tgt_key, 0, sizeof ctx->tgt_key);

@@ -2273,7 +2273,7 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
     set_error("pp_voxelize_step_dev: pipeline in flight on another stream (drain it, or pp_voxelize_step_reset)");
     return PP_ERR_VALUE;
   }
-  ctx->step_stream = stream;
+  // (ctx->step_stream is set where the call can no longer be refused: every PP_ERR_VALUE below leaves the context as it was)
   if (sb_emit.valid) {
     if (!(pfn ? (void *)pfn->canvas : (void *)pillars_dev) || !indices_dev) {
       set_error("pp_voxelize_step*_dev: a batch is due, its output buffers are NULL");
@@ -2455,6 +2455,7 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
   }
   const StepArgs whole = a;
   const int nt_t = sb_tile.valid ? whole.t.g.ntiles : 0, nt_o = sb_order.valid ? whole.o.g.ntiles : 0;
+  ctx->step_stream = stream;  // every argument check has passed: from here on a failure is not a refusal
   for (int k = 0; k < n_launch; ++k) {
     auto part = [&](bool valid, int B, int *lo, int *n) {  // role's share of launch k: sweeps [lo, lo + n)
       *lo = valid ? (int)((long long)B * k / n_launch) : 0;
@@ -2557,8 +2558,11 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
     }
     if (nblocks <= 0) continue;
     if (nblocks > INT_MAX) {
+      // (PP_ERR_VALUE means "refused, nothing launched, no state changed" to every caller -- voxelizer.py keeps its
+      // pipeline on it; an earlier launch of THIS call may be enqueued here, so this can't-happen case is an internal
+      // error: the caller resets the pipeline)
       set_error("pp_voxelize_step_dev: grid too large");
-      return PP_ERR_VALUE;
+      return PP_ERR_INTERNAL;
     }
     const void *fn = mode == kModePfn          ? reinterpret_cast<const void *>(&k_step<kModePfn, kAuxPlain>)
                      : mode == kModeDenseScalar ? reinterpret_cast<const void *>(&k_step<kModeDenseScalar, kAuxPlain>)

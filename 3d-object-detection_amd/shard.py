@@ -44,13 +44,16 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # The pool's operating notes: the host driver supports dmabuf IPC only, and RCCL needs this variable where the
+        # environment does not already carry it -- set if absent, never overridden.  HIP / HSA read their environment
+        # when they initialise, so this is done BEFORE anything below touches the device (torch.cuda.is_available()
+        # does); it only helps if nothing in the process has initialised HIP yet (bench.py sets it at import too).
+        if backend in (None, "nccl"):
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
-            # (the pool's operating notes: the host driver supports dmabuf IPC only, RCCL needs this where the
-            # environment does not already carry it -- set if absent, never overridden; must precede the first HIP call)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(local)
             # bind the communicator to this rank's GPU up front (no lazy device guess at the
             # first collective, no barrier-on-wrong-device warning)

@@ -46,6 +46,23 @@ class VoxelConfig:
         return VoxelConfig(max_points, max_pillars, step, step, -half, -half, z_min,
                            half, half, z_max, n, order)
 
+    @staticmethod
+    def rect(x_range, y_range, x_step, y_step, max_pillars, max_points, z_range=(-10.0, 10.0),
+             canvas_height=None, order=_lib.ORDER_SCRAMBLED):
+        """Any grid create_pillars accepts (pillars.cpp:236-249 takes nine independent scalars): different steps
+        and ranges per axis, a range that is not centred, and a ``canvas_height`` of the caller's choosing -- the
+        reference just computes ``(canvas_height - 1) - floor((y - y_min) / y_step)`` (pillars.cpp:278-280), rows
+        beyond the canvas or negative ones included.  Default ``canvas_height``: the grid's row count."""
+        if canvas_height is None:
+            canvas_height = int(round((y_range[1] - y_range[0]) / y_step))
+        return VoxelConfig(max_points, max_pillars, x_step, y_step, x_range[0], y_range[0], z_range[0],
+                           x_range[1], y_range[1], z_range[1], canvas_height, order)
+
+    def grid_args(self):
+        """The nine grid scalars in create_pillars' positional order (pillars.cpp:241-249)."""
+        return (self.x_step, self.y_step, self.x_min, self.y_min, self.z_min, self.x_max, self.y_max, self.z_max,
+                self.canvas_height)
+
     @property
     def canvas_width(self):
         # config.py:61

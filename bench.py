@@ -602,6 +602,9 @@ def main():
     ap.add_argument("--targets-only", action="store_true",
                     help="only the batched target assignment of configs[2] (--steps + --warmup launches, no output): "
                          "the child run `train_c3.targets.moved_bytes` is measured from under rocprofv3 --pmc")
+    ap.add_argument("--stress-only", action="store_true",
+                    help="only configs[4]'s voxelizer loop (k_step on 200k-point sweeps, rotating outputs; --steps + "
+                         "--warmup launches, no output): the child run `stress_c5.pipelined.traffic` is measured from")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the dropin_host record (the pybind11 module's "
                                                              "own speed on host arrays)")
@@ -662,6 +665,17 @@ def main():
         o_ = ta_.assign_batch_device(*g_)
         for _ in range(a.warmup + a.steps):
             ta_.assign_batch_device(*g_, out=o_)
+        torch.cuda.synchronize()
+        shard.shutdown(ctx)
+        return
+    if a.stress_only:
+        # the PMC child of stress_c5: the software-pipelined voxelizer at configs[4]'s shapes, outputs in turn
+        c5_ = VoxelConfig.square(C5["half"], C5["step"], C5["P"], C5["N"])
+        v5_ = PillarVoxelizer(c5_, device=dev)
+        p5_ = torch.from_numpy(np.stack([synth.lidar_like(C5["n"], C5["half"], s) for s in range(a.batch)])).to(dev)
+        o5_ = rotating_outputs(a.batch, C5["P"], C5["N"], dev)
+        for k_ in range(a.warmup + a.steps + PillarVoxelizer.LAG):
+            v5_.submit(p5_, out=o5_[k_ % len(o5_)])
         torch.cuda.synchronize()
         shard.shutdown(ctx)
         return
@@ -948,11 +962,22 @@ def main():
                        # what the box-centric kernel MOVES: it evaluates the anchors arithmetically and reads none of
                        # SURVEY's 40 B per anchor of input -- the two target arrays (72 B per anchor) and the boxes
                        "moved_bytes": 72 * tp.assigner.A * a.batch,
-                       "moved_bytes_source": "computed: 72 * A * batch (the two f32 target arrays; the boxes stay in L2); "
-                                             "profiles/r05/pmc_targets_c3_b4_*: 36.27 MB written + 0.21 MB fetched at B=4, "
-                                             "pmc_targets_c3_b1_*: 9.09 + 0.16 MB for one sample",
+                       "moved_bytes_source": "computed: 72 * A * batch (the two f32 target arrays; the boxes stay in L2)",
                        "frac_of_moved_bytes": 72 * tp.assigner.A * a.batch / (assign_call_us * 1e-6) / HBM_PEAK,
                        "one_sample_frac_of_moved_bytes": 72 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK}
+        if ctx.world_size == 1 and not a.no_live_traffic:
+            # ... and what the counters say it moves, measured in this run (two rocprofv3 --pmc child runs of the batched
+            # assignment alone; None where the profiler is missing or this run is itself being profiled)
+            torch.cuda.synchronize()
+            lt = live_traffic(a.batch, "k_targets_gt", child="--targets-only")
+            if lt is not None:
+                targets_rec["traffic"] = lt[0]
+                targets_rec["traffic_detail"] = lt[1]
+                targets_rec["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                                 "passes over `bench.py --targets-only`, median per launch, KiB * 1024")
+                targets_rec["frac_of_measured_bytes"] = lt[0] / (assign_call_us * 1e-6) / HBM_PEAK
+            else:
+                targets_rec["traffic"] = None
         del tg1, t_out
         e0.record()
         for _ in range(10):
@@ -1062,6 +1087,20 @@ def main():
                   "output_buffers": len(out5),
                   "one_sweep_per_launch": vox_both(v5, pts5[:1], rotating_outputs(1, C5["P"], C5["N"], dev),
                                                    b5 // a.batch, iters=100, ctx=ctx, dev=dev)}
+        stress["roofline"]["traffic_what"] = "the three-launch path's k_emit: " + str(stress["roofline"].get("traffic_source"))
+        if ctx.world_size == 1 and not a.no_live_traffic:
+            # HBM bytes per k_step launch at these shapes, measured in this run like the headline's (two rocprofv3 --pmc
+            # child runs of `bench.py --stress-only`)
+            torch.cuda.synchronize()
+            lt5 = live_traffic(a.batch, v5.step_kernel_name(a.batch), child="--stress-only", timeout_s=120)
+            if lt5 is not None:
+                stress["pipelined"].update(
+                    traffic=lt5[0], traffic_detail=lt5[1], traffic_over_algorithmic=lt5[0] / b5,
+                    traffic_fetch_x2=lt5[1]["FETCH_SIZE_bytes_x2"] + lt5[1]["WRITE_SIZE_bytes"],
+                    traffic_source="measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over "
+                                   "`bench.py --stress-only`, median per k_step launch, KiB * 1024")
+            else:
+                stress["pipelined"]["traffic"] = None
         if ctx.world_size > 1:
             stress["n_gpus"] = ctx.world_size
             stress["per_rank"] = r5["per_rank"]

@@ -255,3 +255,28 @@ def test_concurrent_worker_processes_share_one_device(gpu, tmp_path):
     r = subprocess.run([sys.executable, "-c", _WORKER, str(tmp_path), ROOT, "9", "1"], cwd=str(tmp_path),
                        env=env_nodev, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("canvas_height", [80, 200, 33])
+def test_rectangular_offset_grid_host_module(gpu, oracle, pillars, canvas_height, monkeypatch):
+    """The drop-in signature's nine independent grid scalars (pillars.cpp:236-249) through both host bindings:
+    x_step = 0.25, y_step = 0.4, x in [-30, 50), y in [-12, 20), canvas_height equal to / larger than / smaller than the
+    row count; f64 points that are NOT f32-representable, the strided view of data/dataset.py:88; overflow and no
+    overflow: tensor and indices bit for bit the oracle's (the module's default order: scrambled)."""
+    rng = np.random.default_rng(canvas_height)
+    n = 40000
+    agg = np.empty((4, n))
+    agg[0], agg[1] = rng.normal(8.0, 22.0, n), rng.normal(3.0, 9.0, n)
+    agg[2], agg[3] = rng.uniform(-3, 3, n), rng.uniform(0, 255, n)
+    agg[0, :4000], agg[1, :4000] = rng.uniform(11.0, 12.5, 4000), rng.uniform(-2.0, -0.4, 4000)
+    pts = agg.transpose([1, 0])
+    g = (0.25, 0.4, -30.0, -12.0, -2.5, 50.0, 20.0, 2.5, canvas_height)
+    for P, N in ((20000, 24), (2500, 24)):
+        T, I = np.full((P, N, 9), 0.5), np.full((P, 3), -1.0)
+        assert pillars.create_pillars(pts, T, I, N, P, *g) is None
+        Tr, Ir = np.full((P, N, 9), 0.5), np.full((P, 3), -1.0)
+        m = oracle.create_pillars(pts, Tr, Ir, N, P, *g, order=oracle.ORDER_SCRAMBLED)
+        assert (m > P) == (P == 2500)
+        assert np.array_equal(I, Ir) and np.array_equal(T, Tr)
+        if canvas_height == 33:
+            assert (I[:min(m, P), 2] < 0).any()

@@ -696,3 +696,46 @@ def test_box_centric_falls_back_beyond_its_grid_limit(gpu, oracle):
     # ... and the small sample alone afterwards (box-centric again: the scratch is re-armed for the other form)
     cls_1, reg_1 = ta.assign_batch(gts[1:], check=True)
     assert torch.equal(cls_1[0], cls_b[1]) and torch.equal(reg_1[0], reg_b[1])
+
+
+def test_positive_list_overflow_is_reported_and_the_next_call_is_right(gpu, oracle):
+    """The positive list of the box-centric kernel holds one entry per candidate anchor of a box's +-10 centre window
+    (pillars.cpp:418-419).  A box whose image-space centre is not finite on ONE axis passes that gate with a whole
+    band of the map (NaN compares false): with a box large enough and a threshold low enough, more pairs exceed the
+    threshold than the list holds.  The launch must say so (error bit 2 -> ValueError, not a winding error, entries
+    dropped rather than written out of bounds), and the NEXT call on the same context must be right again."""
+    import torch
+    from pp_amd import boxes, synth
+    from pp_amd.targets import TargetAssigner
+    from util import check_targets, oracle_targets_for
+    cfg, H = boxes.AnchorConfig(64, 64), 128
+    anchors = boxes.make_anchors(cfg)
+    ta = TargetAssigner(cfg, canvas_height=H, pos_thresh=0.001, device=gpu)
+    big = {"centers": np.array([[64.0, 64.0, 0.5]]), "wlh": np.array([[100.0, 100.0, 2.0]]),
+           "yaw": np.array([0.0]), "classes": np.array([3], np.int32)}
+    g = list(ta._gt_to_device(big["centers"], big["wlh"], big["yaw"], big["classes"]))
+    # finite centre: at most 13 x 13 x 2 candidates, the list holds them all
+    c0, r0 = ta.assign_device(*g, check=True)
+    check_targets(c0, r0, *oracle_targets_for(oracle, anchors, big, H, 0.001))
+    n_pos = int((r0[:, 0] == 1).sum())
+    assert 100 < n_pos <= 13 * 13 * 2
+    g[1] = g[1].clone()
+    g[1][0, 0] = float("nan")                       # the centre's x is not finite: every column passes the gate
+    with pytest.raises(ValueError, match="more pairs above the threshold"):
+        ta.assign_device(*g, check=True)
+    # the context is usable again, and right: the same box with its finite centre, then an ordinary sample
+    g2 = ta._gt_to_device(big["centers"], big["wlh"], big["yaw"], big["classes"])
+    c1, r1 = ta.assign_device(*g2, check=True)
+    assert torch.equal(c1, c0) and torch.equal(r1, r0)
+    gt = synth.gt_boxes(12, H, 3, margin=20.0)
+    tb = TargetAssigner(cfg, canvas_height=H, device=gpu)
+    c2, r2 = tb.assign(gt["centers"], gt["wlh"], gt["yaw"], gt["classes"], check=True)
+    check_targets(c2, r2, *oracle_targets_for(oracle, anchors, gt, H, 0.6))
+    # a wrong winding AND an overflow in one launch: the overflow is what is reported (the scratch must be re-armed),
+    # and the call after that is clean
+    g3 = [t.clone() for t in g]
+    g3[0] = g3[0].flip(1)                           # corners in the opposite order
+    with pytest.raises(ValueError):
+        ta.assign_device(*g3, check=True)
+    c3, r3 = ta.assign_device(*g2, check=True)
+    assert torch.equal(c3, c0) and torch.equal(r3, r0)

@@ -666,3 +666,83 @@ print("sub-batch launches ok")
     r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, PP_STEP_SUB_MB="8"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sub-batch launches ok" in r.stdout, r.stderr[-2000:]
+
+
+# --------------------------------------------------------------------------- grids that are not square
+def _rect_cloud(n, seed):
+    """Points around an off-centre sensor: most inside x in [-30, 50), y in [-12, 20), some outside on every side,
+    a dense patch (cells far beyond N points) and points exactly on cell and range boundaries."""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((n, 4), np.float32)
+    pts[:, 0] = rng.normal(8.0, 22.0, n)
+    pts[:, 1] = rng.normal(3.0, 9.0, n)
+    pts[:, 2] = rng.uniform(-3.0, 3.0, n)
+    pts[:, 3] = rng.uniform(0.0, 255.0, n)
+    k = n // 10
+    pts[:k, 0] = rng.uniform(11.0, 12.5, k)                      # the dense patch
+    pts[:k, 1] = rng.uniform(-2.0, -0.4, k)
+    edge = np.array([[-30.0, -12.0], [50.0, 20.0], [-30.0, 19.999998], [49.999996, -12.0], [0.25, 0.4], [10.0, 8.0],
+                     [-29.75, -11.6], [49.75, 19.6]], np.float32)
+    pts[k:k + len(edge), :2] = edge
+    return pts
+
+
+@pytest.mark.parametrize("canvas_height", [80, 200, 33])       # the grid's row count, a larger canvas, a smaller one
+@pytest.mark.parametrize("order", [0, 1])
+def test_rectangular_offset_grid_device_api(gpu, oracle, order, canvas_height):
+    """create_pillars takes nine independent grid scalars (pillars.cpp:236-249): x_step = 0.25, y_step = 0.4,
+    x in [-30, 50), y in [-12, 20) -- 320 x 80 cells, not centred -- and a canvas_height that is, is larger than, and is
+    smaller than the row count (the reference computes (canvas_height - 1) - floor((y - y_min) / y_step),
+    pillars.cpp:278-280: negative rows included).  Through the plain call AND the software-pipelined submit, with and
+    without overflow, both orders: indices exact, features bit for bit the oracle's."""
+    import torch
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    pts = _rect_cloud(50000, 4 + canvas_height)
+    dev = torch.from_numpy(pts).to(gpu)
+    for P, N in ((20000, 24), (2500, 24), (7000, 3)):            # no overflow / overflow / tiny N (every busy cell truncated)
+        cfg = VoxelConfig.rect((-30.0, 50.0), (-12.0, 20.0), 0.25, 0.4, P, N, z_range=(-2.5, 2.5),
+                               canvas_height=canvas_height, order=order)
+        assert cfg.canvas_width == 320
+        ref_p, ref_i, m = oracle.dataset_voxel_stage(pts.astype(np.float64), P, N, *cfg.grid_args(), order=order)
+        assert (m > P) == (P in (2500, 7000))
+        if canvas_height == 33:
+            assert (ref_i[:, 2] < 0).any()                       # rows above the canvas come out negative, as in the reference
+        vox = PillarVoxelizer(cfg, device=gpu)
+        pil, idx, cnt = vox(dev, return_counts=True)
+        torch.cuda.synchronize()
+        assert int(cnt[0, 0]) == m
+        assert np.array_equal(idx[0].cpu().numpy(), ref_i), (P, N, "indices")
+        assert np.array_equal(pil[0].cpu().numpy(), ref_p), (P, N, "features")
+        outs = list(vox.stream([dev, dev[:30000].contiguous(), dev]))
+        torch.cuda.synchronize()
+        assert len(outs) == 3
+        for k in (0, 2):
+            assert torch.equal(outs[k][0], pil) and torch.equal(outs[k][1], idx), (P, N, "pipelined", k)
+        ref_p2, ref_i2, _ = oracle.dataset_voxel_stage(pts[:30000].astype(np.float64), P, N, *cfg.grid_args(), order=order)
+        assert np.array_equal(outs[1][1][0].cpu().numpy(), ref_i2) and np.array_equal(outs[1][0][0].cpu().numpy(), ref_p2)
+
+
+def test_grid_beyond_32768_cells_per_axis_is_refused(gpu):
+    """The library packs a cell's column and row into 15 bits each: a grid beyond 32 768 cells on an axis is refused
+    with ValueError and a message that names the limit (a documented tightening: the reference has no limit, its hash
+    map is keyed on doubles) -- on the plain call, on submit (the pipeline stays usable) and on the host module."""
+    import torch
+    from pp_amd import pillars
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    pts = torch.zeros((64, 4), dtype=torch.float32, device=gpu)
+    wide = VoxelConfig.rect((0.0, 3300.0), (0.0, 10.0), 0.1, 0.1, 100, 4)        # 33 000 columns
+    vox = PillarVoxelizer(wide, device=gpu)
+    with pytest.raises(ValueError, match="limit 32768 per axis"):
+        vox(pts)
+    with pytest.raises(ValueError, match="limit 32768 per axis"):
+        vox.submit(pts)
+    tall = VoxelConfig.rect((0.0, 10.0), (0.0, 3300.0), 0.1, 0.1, 100, 4)
+    with pytest.raises(ValueError, match="limit 32768 per axis"):
+        PillarVoxelizer(tall, device=gpu)(pts)
+    with pytest.raises(ValueError, match="limit 32768 per axis"):
+        pillars.create_pillars(np.zeros((8, 4)), np.zeros((100, 4, 9)), np.zeros((100, 3)), 4, 100,
+                               *wide.grid_args())
+    ok = VoxelConfig.rect((0.0, 3276.0), (0.0, 10.0), 0.1, 0.1, 100, 4)          # 32 761 columns: accepted
+    p, i = PillarVoxelizer(ok, device=gpu)(pts)
+    torch.cuda.synchronize()
+    assert int(i[0, 0, 0]) == 1 and int(i[0, 1, 0]) == 0                         # 64 points at the origin: one pillar
