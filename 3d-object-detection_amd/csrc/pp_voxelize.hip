@@ -794,60 +794,218 @@ __device__ __forceinline__ void point_features(double x, double y, double z, dou
   f[8] = mean[2] - z;
 }
 
-// A pillar whose bucket does not fit the wave's LDS pool: its bucket is streamed
-// 64 points at a time, in input order (k_tile left it that way).
+// The running means (pillars.cpp:311-328) of the pillars in `mask` -- every occupied pillar of a wave whose buckets do
+// not fit the LDS pool together -- streamed through the pool in slices, in input order (k_tile left them that way), all
+// of them SIDE BY SIDE: the chain of pillar k and coordinate c runs in lane 3 k + c, like the pooled pillars' chains
+// in emit_group.  A chain step is a dependent f64 multiply and add whose operands come from LDS; the wave pays per
+// instruction, not per lane, so the pillars of a wave cost what the LONGEST of them costs (round 5 took them run by
+// run: in row-major order at BASELINE config 1's 100 x 100 grid a wave's four neighbours sum to 1127 points, the
+// longest single one is 381).  What the emit-wave stamps of config 1's shapes said about the first form of this pass
+// (fixed 32-point slices, operands fetched eight steps at a time from C++): 12-14 us for the wave that holds the
+// 381-point cell, of a launch of 23 -- 75 cycles per step, of which the two dependent f64 operations are ~20.  Hence:
+//   * every lane's chain runs the SAME number of steps per round: a slot behind a pillar's last point holds the
+//     identity operands (scale 1.0, value -0.0: m * 1.0 + -0.0 == m for every m, signed zeros and NaNs included), and
+//     the first point is an ordinary step too (scale 0 / 1 = 0.0, value x / 1 = x, from m = -0.0: -0.0 * 0.0 + x == x
+//     bit for bit, for x = +-0.0 as well) -- no per-lane trip counts, no special first step;
+//   * the uniform loop is inline assembly: four steps per group, two register sets in turn, the NEXT group's operands
+//     asked for before THIS group's four dependent steps -- the LDS round trip runs under the arithmetic.  (From C++
+//     the compiler cannot be made to do this: a fetch inside a branch is waited for at the join; fetched
+//     unconditionally the reads are moved down to their uses; with reads and waits as separate asm statements it
+//     copies a destination register before the wait that makes it valid.  Sixteen steps fetched together from C++ cost
+//     the dense kernels 30 VGPRs and k_step its first spills.)
+//   * the slice adapts: the pool is shared by the pillars that still have points, 128 / 64 / 32 slots each for 1 / 2 /
+//     3-4 of them (CAP = 128) -- fewer rounds, hence fewer rounds of the operands' four f64 divisions per point,
+//     once the short buckets are through.
+// Results: L.mean[k].
+#ifdef PP_STAMPS  // tools/lab builds: where streamed_means' time goes (shader clocks, maxima over the launch's waves)
+__device__ unsigned long long g_means_prof[8];  // 0 total, 1 chains (asm loops), 2 staging (operands), 3 steps, 4 rounds
+#define PP_MEANS_CLK() __builtin_readcyclecounter()
+#else
+#define PP_MEANS_CLK() 0ull
+#endif
+template <typename TIn, int CAP>
+__device__ void streamed_means(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, unsigned mask, int lane) {
+  using Rec = typename Rec4<TIn>::type;
+  constexpr int kPre = CAP / 64;
+  int cnt[KW];
+  const Rec *sp[KW];
+  int maxcnt = 0;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    cnt[k] = ((mask >> k) & 1u) ? L.cnt[k] : 0;  // (wave-uniform)
+    sp[k] = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + L.start[k];
+    maxcnt = max(maxcnt, cnt[k]);
+  }
+  // a round's plan, wave-uniform: the pillars with points left share the pool
+  struct Plan {
+    unsigned act;  // pillars with points at or behind `base`
+    int shift;     // log2 of the slice
+  };
+  auto plan_at = [&](int base) {
+    Plan p;
+    p.act = 0;
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+      if (cnt[k] > base) p.act |= 1u << k;
+    const int nb = __popc(p.act);
+    int cap_log = 0;
+    while ((2 << cap_log) <= CAP) ++cap_log;  // log2(CAP)
+    p.shift = cap_log - (nb <= 1 ? 0 : nb == 2 ? 1 : 2);
+    return p;
+  };
+  // entry j of a round = slot `off` of the slice of the q-th active pillar; its operands live at cq[j]
+  auto fetch = [&](const Plan &p, int base, Rec rec[kPre], int ek[kPre], int ei[kPre]) {
+#pragma unroll
+    for (int it = 0; it < kPre; ++it) {
+      const int j = lane + it * kWave;
+      const int q = j >> p.shift, off = j & ((1 << p.shift) - 1);
+      unsigned rest = p.act;
+      for (int u = 0; u < q; ++u) rest &= rest - 1;  // drop the q lowest set bits
+      ek[it] = rest ? __ffs((int)rest) - 1 : -1;
+      ei[it] = base + off;
+      rec[it].x = rec[it].y = rec[it].z = rec[it].w = 0;
+      if (ek[it] >= 0) {
+        int c = 0;
+        const Rec *s = sp[0];
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+          if (k == ek[it]) c = cnt[k], s = sp[k];
+        if (ei[it] < c) rec[it] = s[ei[it]];
+        else ek[it] = -2 - ek[it];  // a slot behind the pillar's last point: identity operands
+      }
+    }
+  };
+  const int kq = lane / 3, cq_ = lane - 3 * kq;
+  const bool chain = lane < 3 * KW && ((mask >> kq) & 1u);
+  [[maybe_unused]] unsigned long long pf_t0 = PP_MEANS_CLK(), pf_chain = 0, pf_stage = 0, pf_steps = 0, pf_rounds = 0, pf_fetch = 0;
+  double m = -0.0;
+  Rec rec[kPre];
+  int ek[kPre], ei[kPre];
+  Plan cur = plan_at(0);
+  fetch(cur, 0, rec, ek, ei);
+  for (int base = 0; base < maxcnt;) {
+    const int slice = 1 << cur.shift;
+    int left = 0;  // steps of this round: the longest remainder, at most a slice, in whole groups of four
+#pragma unroll
+    for (int k = 0; k < KW; ++k) left = max(left, cnt[k] - base);
+    const int steps = (min(left, slice) + 3) & ~3;
+    [[maybe_unused]] const unsigned long long pf_a = PP_MEANS_CLK();
+#pragma unroll
+    for (int it = 0; it < kPre; ++it) {
+      const int j = lane + it * kWave;
+      if (ek[it] >= 0) {
+        const double n = (double)ei[it], den = n + 1;
+        // pillars.cpp:322-326: n/(n+1) and v/(n+1), true f64 divisions, lane-parallel
+        L.u.cq[j] = make_double4(n / den, (double)rec[it].x / den, (double)rec[it].y / den, (double)rec[it].z / den);
+      } else if (ek[it] < -1 && (j & (slice - 1)) < steps) {
+        L.u.cq[j] = make_double4(1.0, -0.0, -0.0, -0.0);
+      }
+    }
+    wave_sync();
+    [[maybe_unused]] const unsigned long long pf_c = PP_MEANS_CLK();
+    // the next round's records travel while this round's chains run
+    const int base_next = base + slice;
+    const Plan nxt = plan_at(base_next);
+    if (base_next < maxcnt) fetch(nxt, base_next, rec, ek, ei);
+    [[maybe_unused]] const unsigned long long pf_b = PP_MEANS_CLK();
+    if (chain && ((cur.act >> kq) & 1u)) {
+      const int qpos = __popc(cur.act & ((1u << kq) - 1u)) << cur.shift;
+      // (the generic pointer's low 32 bits ARE the LDS byte address: aperture base in the high half + offset)
+      unsigned sa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double4 *)&L.u.cq[qpos];
+      unsigned va = sa + 8u * (unsigned)(1 + cq_);
+      int ng = __builtin_amdgcn_readfirstlane(steps >> 2);  // >= 1
+      // Register sets A = v[32:47], B = v[48:63] (named in the clobber list: the reads are ds_read2_b64 -- two steps'
+      // scales, or two steps' values, per instruction -- whose four-register destinations are used half by half, which
+      // an asm operand cannot express).  Per group of four steps: four LDS instructions, eight dependent f64 operations,
+      // the next group's operands in flight.  Measured (tools/lab/emit_stamps.py, profiles/r06/NOTES.md): 31 clocks per
+      // step; the bare dependent pair is 15-17 (tools/lab/f64_rate.cpp).  A wave that is alone on its SIMD issues one
+      // instruction every four clocks, whatever its kind, so every instruction of the loop counts: one ds_read_b64 per
+      // operand (eight reads per group) gave 33.5, a third register set (operands two groups ahead) 35 and the first
+      // spills -- the LDS round trip is covered, what is left is the loop's own instruction count.
+      asm volatile(
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "ds_read2_b64 v[32:35], %1 offset1:4\n\t"
+          "ds_read2_b64 v[40:43], %2 offset1:4\n\t"
+          "ds_read2_b64 v[36:39], %1 offset0:8 offset1:12\n\t"
+          "ds_read2_b64 v[44:47], %2 offset0:8 offset1:12\n"
+          "1:\n\t"
+          "ds_read2_b64 v[48:51], %1 offset0:16 offset1:20\n\t"
+          "ds_read2_b64 v[56:59], %2 offset0:16 offset1:20\n\t"
+          "ds_read2_b64 v[52:55], %1 offset0:24 offset1:28\n\t"
+          "ds_read2_b64 v[60:63], %2 offset0:24 offset1:28\n\t"
+          "s_waitcnt lgkmcnt(4)\n\t"
+          "v_mul_f64 %0, %0, v[32:33]\n\t"
+          "v_add_f64 %0, %0, v[40:41]\n\t"
+          "v_mul_f64 %0, %0, v[34:35]\n\t"
+          "v_add_f64 %0, %0, v[42:43]\n\t"
+          "v_mul_f64 %0, %0, v[36:37]\n\t"
+          "v_add_f64 %0, %0, v[44:45]\n\t"
+          "v_mul_f64 %0, %0, v[38:39]\n\t"
+          "v_add_f64 %0, %0, v[46:47]\n\t"
+          "s_add_i32 %3, %3, -1\n\t"
+          "s_cmp_eq_u32 %3, 0\n\t"
+          "s_cbranch_scc1 2f\n\t"
+          "ds_read2_b64 v[32:35], %1 offset0:32 offset1:36\n\t"
+          "ds_read2_b64 v[40:43], %2 offset0:32 offset1:36\n\t"
+          "ds_read2_b64 v[36:39], %1 offset0:40 offset1:44\n\t"
+          "ds_read2_b64 v[44:47], %2 offset0:40 offset1:44\n\t"
+          "v_add_u32 %1, 0x100, %1\n\t"
+          "v_add_u32 %2, 0x100, %2\n\t"
+          "s_waitcnt lgkmcnt(4)\n\t"
+          "v_mul_f64 %0, %0, v[48:49]\n\t"
+          "v_add_f64 %0, %0, v[56:57]\n\t"
+          "v_mul_f64 %0, %0, v[50:51]\n\t"
+          "v_add_f64 %0, %0, v[58:59]\n\t"
+          "v_mul_f64 %0, %0, v[52:53]\n\t"
+          "v_add_f64 %0, %0, v[60:61]\n\t"
+          "v_mul_f64 %0, %0, v[54:55]\n\t"
+          "v_add_f64 %0, %0, v[62:63]\n\t"
+          "s_add_i32 %3, %3, -1\n\t"
+          "s_cmp_lg_u32 %3, 0\n\t"
+          "s_cbranch_scc1 1b\n"
+          "2:\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "+v"(m), "+v"(sa), "+v"(va), "+s"(ng)
+          :
+          : "scc", "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44",
+            "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
+            "v61", "v62", "v63");
+    }
+    wave_sync();
+#ifdef PP_STAMPS
+    pf_stage += pf_c - pf_a;
+    pf_fetch += pf_b - pf_c;
+    pf_chain += PP_MEANS_CLK() - pf_b;
+    pf_steps += (unsigned long long)steps;
+    pf_rounds += 1;
+#endif
+    base = base_next;
+    cur = nxt;
+  }
+  if (chain) L.mean[kq][cq_] = m;
+  wave_sync();
+#ifdef PP_STAMPS
+  if (lane == 0) {
+    const unsigned long long tot = PP_MEANS_CLK() - pf_t0;
+    if (tot > atomicMax(&g_means_prof[0], tot)) {  // (the slowest wave's breakdown, more or less)
+      g_means_prof[1] = pf_chain;
+      g_means_prof[2] = pf_stage;
+      g_means_prof[3] = pf_steps;
+      g_means_prof[4] = pf_rounds;
+      g_means_prof[5] = pf_fetch;
+    }
+  }
+#endif
+}
+
+// The features of a big pillar's first min(count, N) points (its mean is in L.mean[k]: streamed_means).
 template <typename TIn, int MODE, int CAP>
 __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, int k, int p,
                                 int lane, PfnAcc *acc = nullptr, float *rmax = nullptr,
                                 float *rmin = nullptr) {
   using Rec = typename Rec4<TIn>::type;
-  const int cnt = L.cnt[k];
   const Rec *sp = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + L.start[k];
-  // the chain of coordinate c = lane % 3 in every lane (lanes 0, 1, 2 are read back): two f64 operations per
-  // step instead of six for the three chains in sequence -- the wave pays per operation, not per lane
-  const int cc = lane % 3;
-  double m = 0;
-  Rec nxt;
-  nxt.x = nxt.y = nxt.z = nxt.w = 0;
-  if (lane < cnt) nxt = sp[lane];
-  for (int base = 0; base < cnt; base += kWave) {
-    const int i = base + lane;
-    const Rec rec = nxt;
-    if (i + kWave < cnt) nxt = sp[i + kWave];  // the next 64 records travel while this chunk's chain runs
-    if (i < cnt) {
-      const double n = (double)i, den = n + 1;
-      L.px[lane] = rec.x;
-      L.py[lane] = rec.y;
-      L.pz[lane] = rec.z;
-      L.u.cq[lane] = make_double4(n / den, (double)rec.x / den, (double)rec.y / den,
-                                  (double)rec.z / den);
-    }
-    wave_sync();
-    const int c = min(kWave, cnt - base);
-    // The chain is serial in m, its operands are not: four points' operands are fetched ahead of the four
-    // dependent steps (one LDS round trip per point otherwise -- a 381-point cell of BASELINE config 1 is
-    // 381 of them).
-    const double *op = reinterpret_cast<const double *>(&L.u.cq[0]);
-    int t = 0;
-    if (base == 0) {
-      m = cc == 0 ? (double)L.px[0] : cc == 1 ? (double)L.py[0] : (double)L.pz[0];
-      t = 1;
-    }
-    for (; t + 3 < c; t += 4) {
-      const double s0 = op[4 * t], v0 = op[4 * t + 1 + cc], s1 = op[4 * t + 4], v1 = op[4 * t + 5 + cc];
-      const double s2 = op[4 * t + 8], v2 = op[4 * t + 9 + cc], s3 = op[4 * t + 12], v3 = op[4 * t + 13 + cc];
-      m = m * s0 + v0;
-      m = m * s1 + v1;
-      m = m * s2 + v2;
-      m = m * s3 + v3;
-    }
-    for (; t < c; ++t) m = m * op[4 * t] + op[4 * t + 1 + cc];
-    wave_sync();
-  }
-  const int mlo = __double2loint(m), mhi = __double2hiint(m);
-  const double m0 = __hiloint2double(__builtin_amdgcn_readlane(mhi, 0), __builtin_amdgcn_readlane(mlo, 0));
-  const double m1 = __hiloint2double(__builtin_amdgcn_readlane(mhi, 1), __builtin_amdgcn_readlane(mlo, 1));
-  const double m2 = __hiloint2double(__builtin_amdgcn_readlane(mhi, 2), __builtin_amdgcn_readlane(mlo, 2));
+  const double m0 = L.mean[k][0], m1 = L.mean[k][1], m2 = L.mean[k][2];
   const double mean[3] = {m0, m1, m2};
   const double cx = L.cx[k], cy = L.cy[k];
   const int N = a.N;
@@ -895,6 +1053,58 @@ __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, 
       o[((int64_t)d * a.P + p) * N + e] = 0.0f;
     }
   }
+}
+
+// One run of the streamed path: the LIVE points (the first min(count, N), input order) of the run's pillars, pillar k at
+// LDS positions [spg[k], spg[k] + lvg[k]) (4-aligned starts, gpad positions in all).  A lane owns a position: it loads
+// that point from the CSR array and turns it into its nine features (the means are in L.mean: streamed_means) -- into
+// L.u.feat for the slab store / the fold (dense vec4 and fused-net modes), or straight to memory (the other modes).
+template <typename TIn, int MODE, int CAP>
+__device__ __forceinline__ void emit_live_run(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, int p0, int lane,
+                                              const int spg[KW], const int lvg[KW], int gpad) {
+  using Rec = typename Rec4<TIn>::type;
+  constexpr int kPre = CAP / 64;
+  const int N = a.N;
+  const Rec *base = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap;
+  Rec rec[kPre];
+  int kq[kPre], rq[kPre];
+#pragma unroll
+  for (int it = 0; it < kPre; ++it) {
+    const int q = lane + it * kWave;
+    kq[it] = -1;
+    rq[it] = 0;
+    rec[it].x = rec[it].y = rec[it].z = rec[it].w = 0;
+    if (q < gpad) {
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk)
+        if (q >= spg[kk] && q < spg[kk] + lvg[kk]) {
+          kq[it] = kk;
+          rq[it] = q - spg[kk];
+        }
+    }
+    if (kq[it] >= 0) rec[it] = base[L.start[kq[it]] + rq[it]];
+  }
+  float *outb = a.out + (int64_t)b * 9 * a.P * N;
+#pragma unroll
+  for (int it = 0; it < kPre; ++it) {
+    const int k = kq[it], n = rq[it], q = lane + it * kWave;
+    if (k < 0) continue;
+    double f[9];
+    point_features((double)rec[it].x, (double)rec[it].y, (double)rec[it].z, (double)rec[it].w, L.cx[k], L.cy[k],
+                   L.mean[k], f);
+    if (MODE == kModeCompact) {
+      double *o = a.feat_out + ((int64_t)b * a.ncap + L.start[k] + n) * 9;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) o[d] = f[d];
+    } else if (MODE == kModeDenseScalar) {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) outb[((int64_t)d * a.P + (p0 + k)) * N + n] = (float)f[d];
+    } else {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) L.u.feat[d][q] = (float)f[d];
+    }
+  }
+  wave_sync();
 }
 
 // Pooled pillars [kbeg,kend) of this wave: entries j (pooled bucket position)
@@ -1294,8 +1504,8 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
         sg.nh[k] = (min(cnts[k], N) + 3) >> 2;
-        // pooled together, or alone in its own pass when the pool overflowed
-        if (cnts[k] > 0 && (pooled || cnts[k] <= CAPW)) sg.pooled |= 1u << k;
+        // pooled together; or, when the pool overflowed, its LIVE points staged in a run (emit_live_run)
+        if (cnts[k] > 0 && (pooled || ((min(cnts[k], N) + 3) & ~3) <= CAPW)) sg.pooled |= 1u << k;
       }
       // Everything fits the LDS pool (the normal case): ONE store pass after the point
       // phase writes every line whole.  (Measured: a separate zero pass before the
@@ -1415,8 +1625,21 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
       for (int k = 0; k < KW; ++k) pfn_fold(k, segpad[k], min(cnts[k], N));
     }
   } else {
-    // the pool overflowed: greedy runs of consecutive pillars that fit the pool,
-    // a pillar beyond the pool on its own through the ballot re-scan
+    // The pool overflowed: crowded cells (BASELINE config 1's 100 x 100 grid, row-major strips through the middle of
+    // the cloud).  Round 5 took greedy runs of whole buckets -- load, stage, chain, features, store, run after run, a
+    // bucket beyond the pool on its own -- and the emit-wave stamps of config 1's shapes showed EVERY such wave (one in
+    // twelve) at 13-23 us against a median of 6.5: the launch was those waves.  Two passes now:
+    //  (a) the running means of ALL the wave's occupied pillars side by side (streamed_means: slices of every bucket
+    //      through the pool, the 3 KW chains in as many lanes -- the wave pays for its LONGEST bucket, not their sum);
+    //  (b) the features.  Only the first min(count, N) points of a pillar are ever emitted, so the runs are formed
+    //      over the LIVE points: more pillars per run, no chain operands to stage (and their four f64 divisions per
+    //      point only in (a)), a lane loads its point straight from the CSR array and keeps it in registers.
+    unsigned occ = 0;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk)
+      if (cnts[kk] > 0) occ |= 1u << kk;
+    streamed_means<TIn, CAP>(L, a, b, occ, lane);
+    PP_STAMP_E(4);
     int k = 0;
 #pragma unroll 1
     while (k < KW) {
@@ -1424,7 +1647,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
         ++k;
         continue;
       }
-      if (cnts[k] > CAPW) {
+      if (((min(cnts[k], N) + 3) & ~3) > CAPW) {  // more LIVE points than the pool holds (N beyond the pool)
         if constexpr (MODE == kModePfn) {
           float mx = -INFINITY, mn = INFINITY;
           emit_big_pillar<TIn, MODE, CAP>(L, a, b, k, p0 + k, lane, &acc, &mx, &mn);
@@ -1441,41 +1664,33 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
         ++k;
         continue;
       }
-      const int kb = k;
-      int gpad = 0, graw = 0;
-      int sbg[KW], spg[KW], ckg[KW];
+      int gpad = 0;
+      int spg[KW], lvg[KW];
 #pragma unroll
       for (int kk = 0; kk < KW; ++kk) {
-        sbg[kk] = 0;
         spg[kk] = 0;
-        ckg[kk] = 0;
+        lvg[kk] = 0;
       }
-      while (k < KW && cnts[k] <= CAPW && gpad + ((cnts[k] + 3) & ~3) <= CAPW) {
+      while (k < KW && gpad + ((min(cnts[k], N) + 3) & ~3) <= CAPW) {  // (an empty row joins any run)
+        const int lv = min(cnts[k], N);
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk)
           if (kk == k) {
-            sbg[kk] = graw;
             spg[kk] = gpad;
-            ckg[kk] = cnts[kk];
+            lvg[kk] = lv;
           }
-        graw += cnts[k];
-        gpad += (cnts[k] + 3) & ~3;
+        gpad += (lv + 3) & ~3;
         ++k;
       }
       unsigned gmask = 0;
 #pragma unroll
       for (int kk = 0; kk < KW; ++kk)
-        if (ckg[kk] > 0) gmask |= 1u << kk;
-      const int st = __builtin_amdgcn_readfirstlane(L.start[kb]);  // kb is occupied
-      const Rec *srec = reinterpret_cast<const Rec *>(a.sorted_pts) + (int64_t)b * a.ncap + st;
-#pragma unroll
-      for (int it = 0; it < kPre; ++it)
-        if (lane + it * kWave < graw) rec_r[it] = srec[lane + it * kWave];
-      emit_group<TIn, MODE, CAP>(L, a, b, p0, kb, k, lane, rec_r, sbg, spg, ckg, graw);
+        if (lvg[kk] > 0) gmask |= 1u << kk;
+      emit_live_run<TIn, MODE, CAP>(L, a, b, p0, lane, spg, lvg, gpad);
       if constexpr (MODE == kModePfn) {
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk)
-          if (ckg[kk] > 0) pfn_fold(kk, spg[kk], min(ckg[kk], N));
+          if (lvg[kk] > 0) pfn_fold(kk, spg[kk], lvg[kk]);
         wave_sync();
       }
       if (MODE == kModeDenseVec4) {
@@ -2074,6 +2289,15 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
 using namespace pp;
 
 #ifdef PP_STAMPS
+// development builds only (tools/lab): streamed_means' slowest wave {total, chains, staging (shader clocks), steps, rounds}
+extern "C" int pp_debug_means_prof(unsigned long long *host, int reset) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pp::g_means_prof), sizeof pp::g_means_prof) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pp::g_means_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
 // development builds only (tools/lab): k_tile's phase stamps of sweep 0, 8 per wave
 extern "C" int pp_debug_stamps(pp_ctx_t *ctx, unsigned long long *host, int cap) {
   const size_t n = std::min((size_t)cap * 8, ctx->dbg_stamps_bytes);

@@ -51,3 +51,21 @@ for a_, b_ in ((0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (0, 6)):
     if m.any():
         d = (st[m, b_] - st[m, a_]) / 100.0
         print(f"  {names[a_]:>14s} -> {names[b_]:14s} n={m.sum():6d} median {np.median(d):5.2f}  p90 {np.percentile(d,90):5.2f}  max {d.max():5.2f}")
+
+# the slowest waves, stamp by stamp (non-pooled waves: stamp 4 = running means of all pillars done)
+order = np.argsort(-(st[:, 6] - st[:, 0]))[:12]
+print("  slowest waves (us from the wave's own start): descriptors, indices/zeros, stamp 4, stored, end")
+for i in order:
+    r = st[i]
+    rel = lambda k: (r[k] - r[0]) / 100.0 if r[k] >= r[0] else float("nan")
+    print("    start %6.2f | %5.2f %5.2f %5.2f %5.2f %5.2f" % (us(r[0]), rel(2), rel(3), rel(4), rel(5), rel(6)))
+
+try:
+    g = _lib.lib().pp_debug_means_prof
+    g.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    prof = np.zeros(8, np.uint64)
+    if g(prof.ctypes.data, 1) == 0 and prof[0]:
+        print("  streamed_means, slowest wave (shader clocks): total %d, chains %d (%d steps in %d rounds: %.1f clocks per step), "
+              "operand staging %d, next round's plan + fetch issue %d" % (prof[0], prof[1], prof[3], prof[4], prof[1] / max(1, prof[3]), prof[2], prof[5]))
+except AttributeError:
+    pass
