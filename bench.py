@@ -1261,6 +1261,10 @@ def main():
             out["dropin_host"] = dropin_host()
         if not a.no_cpu_baseline and ctx.world_size == 1:
             out["cpu_baseline"] = cpu_baseline()
+        elif ctx.world_size > 1:
+            # the CPU legs are timed by rank 0 at N = 1 only (while N rank processes hold the host's cores the figure would
+            # be a different one): the line to read them from
+            out["cpu_baseline_from"] = "the N = 1 line of the same run series (`python bench.py`): cpu_baseline.port / .faithful"
         print(json.dumps(out))
     shard.barrier(ctx)
     shard.shutdown(ctx)

@@ -107,3 +107,40 @@ def test_two_ranks_gloo_shared_device(gpu, mode, tmp_path):
     # every rank used its own MIOpen directories under TMPDIR
     roots = [d for d in os.listdir(tmp_path) if d.startswith("pp_miopen_")]
     assert roots and sorted(os.listdir(os.path.join(tmp_path, roots[0]))) == ["rank0", "rank1"]
+
+
+@pytest.mark.gpu
+def test_four_ranks_gloo_shared_device_forward(gpu, tmp_path):
+    """The widest multi-rank rehearsal this pool's one-GPU box allows: its process guard admits six processes on the
+    card, this test process is one of them, so FOUR ranks share device 0 over gloo (the eight-rank arithmetic of
+    BASELINE configs[3] is rehearsed on the CPU: tests/test_shard_gloo.py::test_eight_ranks_on_cpu_rehearse_configs3;
+    the eight-GPU curve is the driver's).  `python bench.py --gpus 4`, no launcher: the contract line for N = 4, the
+    process group's size, four private MIOpen directories, per-rank kernel times of length 4, inside the driver's
+    per-N time budget.  (/root/reference train.py:88-89,120-121.)"""
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "2",
+           "--backend", "gloo", "--no-cpu-baseline", "--no-stress", "--no-train-leg"]
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["n_gpus"] == 4 and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["collectives"]["world_size"] == 4 and out["collectives"]["backend"] == "gloo"
+    assert out["config"]["global_batch"] == 4 * out["config"]["sweeps_per_gpu_per_step"]
+    assert out["value"] > 0 and abs(out["value"] - 3 * out["config"]["global_batch"] /
+                                    (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    mm = out["roofline"]["ranks_min_max"]
+    assert len(mm["per_rank_avg_launch_us"]) == 4 and mm["avg_launch_us"][0] <= mm["avg_launch_us"][1]
+    assert "train_c3" not in out and "stress_c5" not in out and "cpu_baseline" not in out
+    assert out["cpu_baseline_from"].startswith("the N = 1 line")
+    roots = [d for d in os.listdir(tmp_path) if d.startswith("pp_miopen_")]
+    assert roots and sorted(os.listdir(os.path.join(tmp_path, roots[0]))) == ["rank0", "rank1", "rank2", "rank3"]
+    assert wall < 600, f"{wall:.0f} s for the N = 4 line"

@@ -191,3 +191,55 @@ def test_bench_per_rank_records_over_two_ranks():
         assert rows == [[10.0, 100.0], [11.0, 200.0]]
         assert mm["k_step_us"] == [30.0, 40.0] and mm["per_rank_k_step_us"] == [30.0, 40.0]
         assert abs(mm["frac"][0] - 0.375) < 1e-12 and abs(mm["frac"][1] - 0.5) < 1e-12
+
+
+def _eight_worker(rank, world, port, q):
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from pp_amd import shard
+    spec = importlib.util.spec_from_file_location("pp_bench_ranks8", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = b
+    spec.loader.exec_module(b)
+    ctx = shard.init_from_env("gloo")
+    mine = shard.sweeps_for_rank(8, ctx.rank, ctx.world_size)               # configs[3]: batch = 8, one sweep per GPU
+    red = shard.reduce_loss_scalars(ctx, float(rank), 2.0 * rank, 0.0, 3.0 * rank, n_local=len(mine))
+    tmax = shard.max_over_ranks(ctx, 1.0 + 0.25 * rank)
+    mm = b.ranks_min_max(ctx, 13.0 + rank, 44_448_000)
+    torch.manual_seed(0)
+    net = torch.nn.Linear(4, 3)
+    net(torch.full((2, 4), float(rank))).sum().backward()
+    shard.allreduce_gradients(ctx, net.parameters(), bucket_bytes=32)
+    shard.barrier(ctx)
+    q.put((rank, mine, red.tolist(), tmax, mm, net.weight.grad.tolist()))
+    shard.shutdown(ctx)
+
+
+def test_eight_ranks_on_cpu_rehearse_configs3():
+    """BASELINE configs[3] is 8 ranks, one sweep each (/root/reference train.py:88-89,120-121 as one process per
+    GPU).  Eight GPU processes cannot share this pool's one-GPU box (its process guard allows six), so the eight-rank
+    code path is rehearsed here over gloo on the CPU: one sweep id per rank, the loss-scalar all-reduce weighted by
+    sweeps, the max-over-ranks clock, bench.py's per-rank roofline record of length 8, bucketed gradient averaging."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[k] for k in range(8)]                    # rank k owns sweep k
+    mean_rank = sum(range(8)) / 8.0
+    for rank, _, red, tmax, mm, grad in res:
+        assert torch.allclose(torch.tensor(red), torch.tensor([mean_rank, 2 * mean_rank, 0.0, 3 * mean_rank]), atol=1e-6)
+        assert tmax == 1.0 + 0.25 * 7
+        assert mm["per_rank_k_step_us"] == [13.0 + k for k in range(8)] and mm["k_step_us"] == [13.0, 20.0]
+        assert len(mm["frac"]) == 2 and mm["frac"][0] < mm["frac"][1]
+        assert torch.allclose(torch.tensor(grad), torch.full((3, 4), 2.0 * mean_rank), atol=1e-6)   # mean over ranks of 2 * rank
