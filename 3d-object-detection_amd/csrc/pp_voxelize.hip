@@ -684,6 +684,21 @@ __device__ __forceinline__ void unscatter_body(const UnscatterArgs &u, int blk, 
   }
 }
 
+// Which tile a tile workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one
+// and its L2 -- observed, not promised: MI355X_MICROARCH.md); neighbouring tiles gather neighbouring runs of every
+// chunk of the split arrays (a 128-byte line of kpts holds the runs of ~4 tiles at BASELINE config 5's 800k points),
+// so with tile = block every line was fetched by several XCDs -- k_tile's FETCH_SIZE was 1.4-1.8x what it gathers.
+// Blocks t, t + 8, t + 16, ... take CONSECUTIVE tiles instead: an eighth of the tile range per XCD.  (A permutation of
+// the tiles whatever the dispatch order is: placement changes the traffic, never the result.)
+__device__ __forceinline__ int tile_of_block(int t, int nt) {
+#ifdef PP_TILE_NO_XCD_MAP  // tools/lab: A/B
+  return t;
+#else
+  const int k = t & 7, q = t >> 3;
+  return k * (nt >> 3) + min(k, nt & 7) + q;
+#endif
+}
+
 template <typename T, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     NPoints np, GridGeom g, int ncap, int nchunks_cap, const int *__restrict__ kslot,
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_tile(
     return;
   }
   tile_body<T, WAVES>(np, g, ncap, nchunks_cap, kslot, kpts, mat, sorted_pts, tile_meta, tile_agg, stamps,
-                      tile_smem, (int)blockIdx.x, (int)blockIdx.y);
+                      tile_smem, tile_of_block((int)blockIdx.x, g.ntiles), (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1823,6 +1838,7 @@ struct StepArgs {
   OrderRole o;
   PrefetchRole pf;
   int n_tile_blocks, n_split_blocks, emit_nbx;
+  int tile_xcd_map;  // development knob PP_STEP_TILE_XCD=1: the tile role takes its tiles XCD by XCD (tile_of_block)
   int tile_b0, split_b0, emit_b0;  // first sweep of each role's batch in this launch (a call whose dense output is
                                    // beyond the Infinity Cache goes out as several launches, a few sweeps each)
   int mix, mix_groups;  // block order: mix_groups groups of {1 binning block, mix-1 emit blocks}, then the rest
@@ -1902,7 +1918,11 @@ __global__ __launch_bounds__(kStepThreads, step_minwaves(MODE)) void k_step(Step
   }
   if (id < a.n_tile_blocks) {
     const int nt = a.t.g.ntiles;
-    const int b = a.tile_b0 + id / nt, tile = id - (id / nt) * nt;
+    // (tile = block here: with tile_of_block k_step's FETCH_SIZE at BASELINE config 5 halves, 56.9 -> 29.0 MiB per launch,
+    // and the launch gets 3 us SLOWER, 107.2 -> 110.1 us, twice in alternation -- the binning reads were never what the
+    // launch waits for; profiles/r06/NOTES.md.  The three-launch k_tile, whose own time they are, keeps the map.)
+    const int t_blk = id - (id / nt) * nt;
+    const int b = a.tile_b0 + id / nt, tile = a.tile_xcd_map ? tile_of_block(t_blk, nt) : t_blk;
     tile_body<float, kStepWaves>(a.t.np, a.t.g, a.t.ncap, a.t.nchunks_cap, a.t.kslot,
                                  reinterpret_cast<const float4 *>(a.t.kpts), a.t.mat,
                                  reinterpret_cast<float4 *>(a.t.sorted_pts), a.t.tile_meta, a.t.tile_agg,
@@ -2652,6 +2672,11 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
     a.n_unscatter_blocks = a.un.nblocks * pfn->clear_batch;
   }
   if (a.emit_nbx == 0) a.emit_nbx = 1;
+  static const int tile_xcd = [] {
+    const char *e = getenv("PP_STEP_TILE_XCD");
+    return e ? atoi(e) : 0;
+  }();
+  a.tile_xcd_map = tile_xcd;
   static const int pref_blocks = [] {  // development knob: PP_STEP_PREFETCH=<workgroups> (0 = off)
     const char *e = getenv("PP_STEP_PREFETCH");
     return e ? std::max(0, atoi(e)) : 128;

@@ -80,10 +80,19 @@ class TargetAssigner:
         g = self._gt_to_device(gt_centers, gt_wlh, gt_yaw, gt_classes)
         return self.assign_device(*g, check=check)
 
-    def assign_device(self, g_corners, g_centers_img, g_centers, g_wlh, g_yaw, g_class, check=False):
+    def assign_device(self, g_corners, g_centers_img, g_centers, g_wlh, g_yaw, g_class, check=False, out=None):
+        """``out``: an optional ``(cls[A,C], reg[A,9])`` pair of contiguous f32 tensors to fill (a loop that re-uses its
+        outputs saves two allocator calls per sample -- a third of a call's host time at one sample per launch)."""
         G = int(g_corners.shape[0])
-        cls_t = torch.empty((self.A, self.num_classes), dtype=torch.float32, device=self.device)
-        reg_t = torch.empty((self.A, 9), dtype=torch.float32, device=self.device)
+        if out is None:
+            cls_t = torch.empty((self.A, self.num_classes), dtype=torch.float32, device=self.device)
+            reg_t = torch.empty((self.A, 9), dtype=torch.float32, device=self.device)
+        else:
+            cls_t, reg_t = out
+            if cls_t.shape != (self.A, self.num_classes) or reg_t.shape != (self.A, 9) or \
+                    cls_t.dtype != torch.float32 or reg_t.dtype != torch.float32 or \
+                    not (cls_t.is_contiguous() and reg_t.is_contiguous()) or cls_t.device != self.device:
+                raise ValueError("out: contiguous f32 (cls[A,C], reg[A,9]) on " + str(self.device))
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self.grid is not None:
             c = self.grid

@@ -939,13 +939,21 @@ def main():
         assign_call_us = e0.elapsed_time(e1) * 1e3 / 100
         assign_us = assign_call_us / a.batch
         tg1 = [tp.upload_ground_truth(g) for g in gts_host]     # ... and one launch per sample (rounds 1-3)
+        # (outputs re-used: with two allocator calls per sample the loop is bound by the HOST's issue rate on this pool's
+        # slower boxes -- 12.3 us per call issued against an 11.5 us kernel where measured, 16-19 us read on some boxes in
+        # round 5 while the kernel trace showed 13; profiles/r06/NOTES.md)
+        o1 = (torch.empty((tp.assigner.A, tp.assigner.num_classes), dtype=torch.float32, device=dev),
+              torch.empty((tp.assigner.A, 9), dtype=torch.float32, device=dev))
         for g in tg1:
-            tp.assigner.assign_device(*g)
+            tp.assigner.assign_device(*g, out=o1)
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
         e0.record()
         for _ in range(20):
             for g in tg1:
-                tp.assigner.assign_device(*g)
+                tp.assigner.assign_device(*g, out=o1)
         e1.record()
+        assign1_issue_us = (time.perf_counter() - t_h) * 1e6 / (20 * len(tg1))
         torch.cuda.synchronize()
         assign1_us = e0.elapsed_time(e1) * 1e3 / (20 * len(tg1))
         t_bytes = 112 * tp.assigner.A * a.batch
@@ -957,7 +965,7 @@ def main():
                        "bytes_per_launch": t_bytes, "bytes_what": "112 * A per sample (SURVEY 8d) x the batch",
                        "us_per_call": assign_call_us, "achieved": t_bytes / (assign_call_us * 1e-6) / 1e9,
                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": t_bytes / (assign_call_us * 1e-6) / HBM_PEAK,
-                       "one_sample_per_launch_us": assign1_us,
+                       "one_sample_per_launch_us": assign1_us, "one_sample_host_issue_us": assign1_issue_us,
                        "one_sample_per_launch_frac": 112 * tp.assigner.A / (assign1_us * 1e-6) / HBM_PEAK,
                        # what the box-centric kernel MOVES: it evaluates the anchors arithmetically and reads none of
                        # SURVEY's 40 B per anchor of input -- the two target arrays (72 B per anchor) and the boxes
@@ -1162,12 +1170,14 @@ def main():
         ta = TargetAssigner(boxes.AnchorConfig.reference_default(), canvas_height=600, device=dev)
         gr = synth.gt_boxes(40, 600, 0)
         g_ = ta._gt_to_device(gr["centers"], gr["wlh"], gr["yaw"], gr["classes"])
+        or_ = (torch.empty((ta.A, ta.num_classes), dtype=torch.float32, device=dev),
+               torch.empty((ta.A, 9), dtype=torch.float32, device=dev))
         for _ in range(10):
-            ta.assign_device(*g_)
+            ta.assign_device(*g_, out=or_)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(100):
-            ta.assign_device(*g_)
+            ta.assign_device(*g_, out=or_)
         e1.record()
         torch.cuda.synchronize()
         t_us = e0.elapsed_time(e1) * 1e3 / 100

@@ -29,10 +29,28 @@ for name, src in (("arrays", boxes.make_anchors(cfg)), ("grid", cfg)):
         t0 = time.perf_counter()
         for k in range(it):
             ta.assign_device(*g[k % B])
+        t_issue = (time.perf_counter() - t0) / it       # the host's side alone: two allocations + the C call + the launch
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / it
         print(f"A={A} G={G} anchors={name}: one sample per launch {dt*1e6:.1f} us per sample; algorithmic 112*A = "
               f"{112*A/1e6:.1f} MB -> {112*A/dt/1e9:.0f} GB/s")
+        # the same loop three more times, apart: wall, the host's issue time, and the device's own span (event pair);
+        # then with the outputs re-used (no allocator calls).  A loop whose wall time equals its issue time is bound by
+        # the HOST (boxes of this pool differ 4x in single-thread speed), whatever the kernel takes.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for reuse in (False, False, False, True):
+            out = (torch.empty((A, 9), dtype=torch.float32, device="cuda"), torch.empty((A, 9), dtype=torch.float32, device="cuda")) if reuse else None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            for k in range(it):
+                ta.assign_device(*g[k % B], out=out)
+            e1.record()
+            ti = (time.perf_counter() - t0) / it
+            torch.cuda.synchronize()
+            tw = (time.perf_counter() - t0) / it
+            print(f"    loop of {it}{' (outputs re-used)' if reuse else ''}: wall {tw*1e6:.1f} us per call, host issue {ti*1e6:.1f}, "
+                  f"device span (event pair) {e0.elapsed_time(e1)*1e3/it:.1f}")
     if what in ("all", "batch", "grid"):
         counts, packed = ta.upload_batch(gts)
         out = None
