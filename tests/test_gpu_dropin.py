@@ -280,3 +280,37 @@ def test_rectangular_offset_grid_host_module(gpu, oracle, pillars, canvas_height
         assert np.array_equal(I, Ir) and np.array_equal(T, Tr)
         if canvas_height == 33:
             assert (I[:min(m, P), 2] < 0).any()
+
+
+def test_f32_representable_points_take_the_f32_kernels_same_bits(gpu, oracle, pillars):
+    """The host entry point sends a cloud whose every value survives double -> float -> double through the f32-input
+    kernels (half the bytes over PCIe; what data/dataset.py:51-88 hands over IS f32 values widened by np.hstack) and
+    any other cloud through the f64-input kernels.  Both must give the oracle's bits on the SAME f64 input -- also
+    when exactly one value of 40 000 points is not an f32 value (the whole call then takes the f64 kernels), and with
+    a NaN row and a -0.0 in the cloud (NaN points are dropped, the library's documented deviation)."""
+    from pp_amd import synth
+    pts = synth.lidar_like(40000, 20.0, 9).astype(np.float64)           # f32 values, widened: dataset.py:82
+    pts[7] = [-0.0, 0.0, -0.0, 3.0]
+    P, N = 9000, 20
+    g = (0.2, 0.2, -20.0, -20.0, -10.0, 20.0, 20.0, 10.0, 200)
+    variants = {"f32 values": pts.copy()}
+    one = pts.copy()
+    one[12345, 1] += 1e-12                                               # one value between two f32 values
+    variants["one f64 value"] = one
+    nan = pts.copy()
+    nan[100, 0] = np.nan
+    variants["a NaN"] = nan
+    outs = {}
+    for name, p in variants.items():
+        agg = np.ascontiguousarray(p.T)
+        T, I = np.zeros((P, N, 9)), np.zeros((P, 3))
+        pillars.create_pillars(agg.transpose([1, 0]), T, I, N, P, *g)
+        Tr, Ir = np.zeros((P, N, 9)), np.zeros((P, 3))
+        q = p if name != "a NaN" else np.delete(p, 100, axis=0)        # the oracle's NaN row would poison a cell
+        oracle.create_pillars(q, Tr, Ir, N, P, *g, order=oracle.ORDER_SCRAMBLED)
+        assert np.array_equal(I, Ir), name
+        assert np.array_equal(T.view(np.uint64), Tr.view(np.uint64)), name     # bits, signed zeros included
+        outs[name] = (T, I)
+    # the two kernel families agree wherever the perturbed point does not live
+    same = np.all(outs["f32 values"][1] == outs["one f64 value"][1])
+    assert same and (outs["f32 values"][0] != outs["one f64 value"][0]).sum() <= 9 * N
