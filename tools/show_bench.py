@@ -14,7 +14,7 @@ print('fused e2e', round(ff['value'], 1), 'three-launch call us', round(ff['roof
 t = j['train_c3']; tt = t['targets']
 print('train_c3', round(t['value'], 1), 'ms', round(t['ms_per_step'], 2), '| targets B us', round(tt['us_per_call'], 2), 'frac', round(tt['frac'], 3), 'moved frac', round(tt['frac_of_moved_bytes'], 3), '| one sample us', round(tt['one_sample_per_launch_us'], 2), 'frac', round(tt['one_sample_per_launch_frac'], 3))
 s = j['stress_c5']
-print('stress B', {k: round(x, 3) if x < 10 else round(x, 1) for k, x in s['pipelined'].items()}, 'three', round(s['three_launch_us_per_step'], 1), '| one sweep kernel', round(s['one_sweep_per_launch']['k_step_us'], 1), round(s['one_sweep_per_launch']['kernel_frac'], 3))
+print('stress B', {k: round(x, 3) if x < 10 else round(x, 1) for k, x in s['pipelined'].items() if isinstance(x, (int, float))}, 'three', round(s['three_launch_us_per_step'], 1), '| one sweep kernel', round(s['one_sweep_per_launch']['k_step_us'], 1), round(s['one_sweep_per_launch']['kernel_frac'], 3))
 if 'end_to_end' in s: e = s['end_to_end']; print('stress e2e', round(e['value'], 1), 'sweeps/s', round(e['ms_per_step'], 2), 'ms/step k_step', round(e['k_step_us'], 1), round(e['k_step_frac'], 3))
 d = j['reference_default']
 print('refdef B', round(d['voxelizer']['k_step_us'], 1), round(d['voxelizer']['kernel_frac'], 3), 'one', round(d['one_sweep_per_launch']['k_step_us'], 1), round(d['one_sweep_per_launch']['kernel_frac'], 3), 'targets one', round(d['target_assign_us'], 1), 'batch', round(d['target_assign_batch']['us_per_call'], 1), round(d['target_assign_batch']['frac'], 3))
