@@ -27,7 +27,7 @@ EXPORTS = [
     "pp_last_error", "pp_version", "pp_device_count", "pp_ctx_create", "pp_ctx_destroy",
     "pp_voxelize_reserve", "pp_voxelize_dev", "pp_voxelize_step_dev", "pp_voxelize_step_pfn_canvas_dev", "pp_voxelize_step_kernel_name", "pp_voxelize_step_reset", "pp_subtract_mean_dev", "pp_voxelize_pfn_dev", "pp_voxelize_pfn_canvas_dev", "pp_voxelize_pfn_canvas_reuse_dev", "pp_pfn_dense_dev", "pp_scatter_canvas_dev", "pp_pfn_train_stats_dev", "pp_pfn_train_backward_dev", "pp_create_pillars_f64", "pp_make_ious_f64",
     "pp_iou_check", "pp_make_ious_dev", "pp_assign_targets_dev", "pp_assign_targets_grid_dev", "pp_assign_targets_batch_dev", "pp_assign_targets_grid_batch_dev", "pp_ingest_dev", "pp_ingest_sweeps_dev", "pp_decode_dev", "pp_decode_strided_dev", "pp_decode_batch_dev", "pp_bias_relu_bn_dev", "pp_bias_relu_bn_nhwc_dev", "pp_relu_bn_train_fwd_dev", "pp_relu_bn_train_bwd_dev", "pp_ctx_set_timing",
-    "pp_ctx_read_emit_ms", "pp_ctx_read_kernel_ms", "pp_voxelize_check",
+    "pp_ctx_read_emit_ms", "pp_ctx_read_kernel_ms", "pp_voxelize_check", "pp_host_pool_selftest",
 ]
 
 
@@ -239,6 +239,7 @@ def _load(path):
     L.pp_ctx_read_kernel_ms.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_float), c_int,
                                         ctypes.POINTER(c_int)]
     L.pp_voxelize_check.argtypes = [vp, vp]
+    L.pp_host_pool_selftest.argtypes = [c_int, c_int, c_int]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("pp_last_error", "pp_version", "pp_ctx_destroy"):

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -244,6 +245,45 @@ extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
   }
   if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
   delete ctx;
+}
+
+extern "C" int pp_host_pool_selftest(int threads, int jobs, int n) {
+  if (threads < 1 || threads > 64 || jobs < 0 || n < 0) {
+    set_error("pp_host_pool_selftest: bad argument");
+    return PP_ERR_VALUE;
+  }
+  HostPool pool(threads);
+  std::vector<long long> slot(64);
+  std::vector<int> seen(64);
+  for (int j = 0; j < jobs; ++j) {
+    // every 256th job finds the workers ASLEEP (a pause beyond their spin): the condition-variable wake-up path
+    if ((j & 255) == 255) std::this_thread::sleep_for(std::chrono::microseconds(400));
+    std::fill(slot.begin(), slot.end(), 0ll);
+    std::fill(seen.begin(), seen.end(), 0);
+    int expect_parts = 0;
+    const std::function<void(int, int)> fn = [&](int part, int parts) {
+      const long long i0 = (long long)n * part / parts, i1 = (long long)n * (part + 1) / parts;
+      long long acc = 0;
+      for (long long i = i0; i < i1; ++i) acc += i + 1;
+      slot[part] += acc;          // disjoint slots: no two parts share one
+      seen[part] += parts;        // (the parts count every part was told)
+    };
+    if (j & 1) {                  // workers only, the caller free meanwhile
+      expect_parts = threads == 1 ? 1 : threads - 1;
+      pool.start(fn);
+      pool.wait();
+    } else {
+      expect_parts = threads;
+      pool.run(fn);
+    }
+    long long total = 0;
+    for (int p = 0; p < 64; ++p) {
+      total += slot[p];
+      if (seen[p] != (p < expect_parts ? expect_parts : 0)) return j + 1;
+    }
+    if (total != (long long)n * (n + 1) / 2) return j + 1;
+  }
+  return 0;
 }
 
 extern "C" int pp_ctx_set_timing(pp_ctx_t *ctx, int slots) {

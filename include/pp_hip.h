@@ -549,6 +549,14 @@ int pp_ctx_set_timing(pp_ctx_t *ctx, int slots);
 int pp_ctx_read_kernel_ms(pp_ctx_t *ctx, int which, float *ms, int cap, int *count);
 int pp_ctx_read_emit_ms(pp_ctx_t *ctx, float *ms, int cap, int *count);
 
+/* Self-test of the host thread pool behind the two host entry points (pp_create_pillars_f64's gather and scatter,
+ * pp_make_ious_f64's zero fill): needs no device.  Runs `jobs` jobs on a pool of `threads` threads, alternating the
+ * blocking form and the start / wait form, every part adding its own range of 1..n into a per-part slot; returns 0
+ * when every part of every job ran exactly once with the right (part, parts) pair, else the index of the first job
+ * that went wrong + 1.  (The reference has no counterpart: its module is single-threaded and holds the GIL,
+ * data/pillars.cpp:429-435.) */
+int pp_host_pool_selftest(int threads, int jobs, int n);
+
 #ifdef __cplusplus
 }
 #endif

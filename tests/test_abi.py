@@ -164,3 +164,20 @@ def test_device_entry_points_reject_null_and_bad_sizes_without_touching_a_device
         rc = call()
         assert rc == V, (name, rc)
         assert L.pp_last_error(), name
+
+
+def test_host_thread_pool_selftest_without_a_device():
+    """The pool of host threads behind pp_create_pillars_f64 / pp_make_ious_f64 (gather, scatter, zero fill) needs no
+    device to be exercised: thousands of back-to-back jobs in both forms (blocking; start / wait with the caller free),
+    every part of every job exactly once with the right (part, parts) pair, for 1..16 threads -- including the
+    sleep / wake path (a pause between jobs longer than the workers' spin)."""
+    import time
+    import pp_amd
+    L = pp_amd._lib.lib()
+    for threads in (1, 2, 3, 8, 16):
+        assert L.pp_host_pool_selftest(threads, 3000, 10007) == 0, threads
+    assert L.pp_host_pool_selftest(4, 0, 5) == 0 and L.pp_host_pool_selftest(4, 7, 0) == 0
+    assert L.pp_host_pool_selftest(0, 1, 1) == pp_amd._lib.PP_ERR_VALUE
+    for _ in range(5):                      # a fresh pool each time, used after its workers have gone to sleep
+        assert L.pp_host_pool_selftest(8, 20, 1000) == 0
+        time.sleep(0.002)
