@@ -21,6 +21,7 @@
 #include <unistd.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 #include "pp_hip.h"
@@ -31,21 +32,27 @@ namespace {
 
 pp_ctx_t *g_ctx = nullptr;
 pid_t g_pid = 0;
+// The context (staging buffers, one stream) serves one call at a time; the GIL is released around the calls below, so
+// Python threads are serialised here.  (The reference holds the GIL for its whole call: its callers never overlap.)
+std::mutex g_call_mutex;
 
-pp_ctx_t *context() {
+// (called with g_call_mutex held and the GIL released: reports through *err instead of throwing)
+pp_ctx_t *context_nothrow(std::string *err) {
   if (!g_ctx || g_pid != getpid()) {  // a forked child must not reuse the parent's context
     const char *dev = std::getenv("PP_HIP_DEVICE");
     pp_ctx_t *c = nullptr;
-    if (pp_ctx_create(dev ? std::atoi(dev) : 0, &c) != PP_OK)
-      throw std::runtime_error(std::string("pillars: ") + pp_last_error());
+    if (pp_ctx_create(dev ? std::atoi(dev) : 0, &c) != PP_OK) {
+      *err = pp_last_error();
+      return nullptr;
+    }
     g_ctx = c;
     g_pid = getpid();
   }
   return g_ctx;
 }
 
-[[noreturn]] void raise_for(int rc, const char *what) {
-  const std::string msg = std::string(what) + ": " + pp_last_error();
+[[noreturn]] void raise_for(int rc, const char *what, const std::string &detail) {
+  const std::string msg = std::string(what) + ": " + detail;
   switch (rc) {
     case PP_ERR_INDEX:
       throw py::index_error(msg);  // what pybind11's bounds-checked .at() raises
@@ -108,14 +115,17 @@ void create_pillars(in_array points, py::object tensor_o, py::object indices_o,
   const int64_t ist[2] = {indices.strides(0), indices.strides(1)};
   int64_t ncell = 0;
   int rc;
+  std::string err;
   {
-    pp_ctx_t *c = context();
     py::gil_scoped_release nogil;  // the reference holds the GIL for the whole call; no need to
-    rc = pp_create_pillars_f64(c, points.data(), points.shape(0), points.strides(0), points.strides(1),
-                               tensor.mutable_data(), ts, tst, indices.mutable_data(), is, ist, &prm,
-                               &ncell);
+    std::lock_guard<std::mutex> one_call(g_call_mutex);
+    pp_ctx_t *c = context_nothrow(&err);
+    rc = c ? pp_create_pillars_f64(c, points.data(), points.shape(0), points.strides(0), points.strides(1),
+                                   tensor.mutable_data(), ts, tst, indices.mutable_data(), is, ist, &prm, &ncell)
+           : PP_ERR_HIP;
+    if (rc != PP_OK && err.empty()) err = pp_last_error();
   }
-  if (rc != PP_OK) raise_for(rc, "create_pillars");
+  if (rc != PP_OK) raise_for(rc, "create_pillars", err);
 }
 
 void make_ious(in_array a_corners, in_array g_corners, in_array a_centers, in_array g_centers,
@@ -137,13 +147,17 @@ void make_ious(in_array a_corners, in_array g_corners, in_array a_centers, in_ar
   const int64_t gn[2] = {g_centers.strides(0), g_centers.strides(1)};
   const int64_t io[2] = {ious.strides(0), ious.strides(1)};
   int rc;
+  std::string err;
   {
-    pp_ctx_t *c = context();
     py::gil_scoped_release nogil;
-    rc = pp_make_ious_f64(c, a_corners.data(), A, ac, g_corners.data(), G, gc, a_centers.data(), an,
-                          g_centers.data(), gn, ious.mutable_data(), io);
+    std::lock_guard<std::mutex> one_call(g_call_mutex);
+    pp_ctx_t *c = context_nothrow(&err);
+    rc = c ? pp_make_ious_f64(c, a_corners.data(), A, ac, g_corners.data(), G, gc, a_centers.data(), an,
+                              g_centers.data(), gn, ious.mutable_data(), io)
+           : PP_ERR_HIP;
+    if (rc != PP_OK && err.empty()) err = pp_last_error();
   }
-  if (rc != PP_OK) raise_for(rc, "make_ious");
+  if (rc != PP_OK) raise_for(rc, "make_ious", err);
 }
 
 }  // namespace

@@ -21,6 +21,7 @@ the module survives ``DataLoader`` worker start-up (train.py:120-121); use the
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -36,6 +37,10 @@ DEVICE = int(os.environ.get("PP_HIP_DEVICE", "0"))
 
 _ctx = None
 _ctx_pid = None
+# The module's context (staging buffers, one stream) serves ONE call at a time; ctypes releases the GIL around a foreign
+# call, so two Python threads could otherwise be inside it at once.  (The reference's module holds the GIL for the whole
+# call, pillars.cpp:429-435: its callers never overlap either.)
+_call_lock = threading.Lock()
 
 
 def _context():
@@ -91,12 +96,13 @@ def create_pillars(points, tensor, indices, max_points_per_pillar, max_pillars,
     prm = _lib.make_voxel_params(max_points_per_pillar, max_pillars, x_step, y_step, x_min, y_min,
                                  z_min, x_max, y_max, z_max, canvas_height, ORDER)
     ncell = ctypes.c_int64()
-    rc = _lib.lib().pp_create_pillars_f64(
-        _context().handle, points.ctypes.data, points.shape[0], points.strides[0],
-        points.strides[1], tensor.ctypes.data, _i64(tensor.shape), _i64(tensor.strides),
-        indices.ctypes.data, _i64(indices.shape), _i64(indices.strides),
-        ctypes.byref(prm), ctypes.byref(ncell))
-    _lib.check(rc, "create_pillars")
+    with _call_lock:
+        rc = _lib.lib().pp_create_pillars_f64(
+            _context().handle, points.ctypes.data, points.shape[0], points.strides[0],
+            points.strides[1], tensor.ctypes.data, _i64(tensor.shape), _i64(tensor.strides),
+            indices.ctypes.data, _i64(indices.shape), _i64(indices.strides),
+            ctypes.byref(prm), ctypes.byref(ncell))
+        _lib.check(rc, "create_pillars")
     return None
 
 
@@ -123,11 +129,12 @@ def make_ious(a_corners, g_corners, a_centers, g_centers, ious):
             or g_centers.shape[0] < G or g_centers.shape[1] < 2
             or ious.shape[0] < A or ious.shape[1] < G):
         raise IndexError("make_ious: index out of bounds for the given array shapes")
-    rc = _lib.lib().pp_make_ious_f64(
-        _context().handle, a_corners.ctypes.data, A, _i64(a_corners.strides),
-        g_corners.ctypes.data, G, _i64(g_corners.strides),
-        a_centers.ctypes.data, _i64(a_centers.strides),
-        g_centers.ctypes.data, _i64(g_centers.strides),
-        ious.ctypes.data, _i64(ious.strides))
-    _lib.check(rc, "make_ious")
+    with _call_lock:
+        rc = _lib.lib().pp_make_ious_f64(
+            _context().handle, a_corners.ctypes.data, A, _i64(a_corners.strides),
+            g_corners.ctypes.data, G, _i64(g_corners.strides),
+            a_centers.ctypes.data, _i64(a_centers.strides),
+            g_centers.ctypes.data, _i64(g_centers.strides),
+            ious.ctypes.data, _i64(ious.strides))
+        _lib.check(rc, "make_ious")
     return None

@@ -314,3 +314,36 @@ def test_f32_representable_points_take_the_f32_kernels_same_bits(gpu, oracle, pi
     # the two kernel families agree wherever the perturbed point does not live
     same = np.all(outs["f32 values"][1] == outs["one f64 value"][1])
     assert same and (outs["f32 values"][0] != outs["one f64 value"][0]).sum() <= 9 * N
+
+
+def test_python_threads_calling_at_once_are_serialised(gpu, oracle, pillars):
+    """Both bindings release the GIL around the C call (ctypes always does; the pybind11 module does so that its pool
+    of host threads can run), and the module's one context serves one call at a time: calls from several Python threads
+    must queue up, each getting its own cloud's result.  (The reference holds the GIL for the whole call,
+    pillars.cpp:429-435: its callers never overlap.)"""
+    import threading
+    from pp_amd import synth
+    P, N = 6000, 16
+    g = (0.25, 0.25, -16.0, -16.0, -5.0, 16.0, 16.0, 5.0, 128)
+    clouds = [synth.lidar_like(25000, 16.0, 50 + k).astype(np.float64) for k in range(4)]
+    outs = [(np.zeros((P, N, 9)), np.zeros((P, 3))) for _ in clouds]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(6):
+                outs[k][0][:] = 0
+                outs[k][1][:] = 0
+                pillars.create_pillars(clouds[k], outs[k][0], outs[k][1], N, P, *g)
+        except Exception as e:          # pragma: no cover
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for k, c in enumerate(clouds):
+        Tr, Ir = np.zeros((P, N, 9)), np.zeros((P, 3))
+        oracle.create_pillars(c, Tr, Ir, N, P, *g, order=oracle.ORDER_SCRAMBLED)
+        assert np.array_equal(outs[k][1], Ir) and np.array_equal(outs[k][0], Tr), k
