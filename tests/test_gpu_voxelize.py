@@ -746,3 +746,64 @@ def test_grid_beyond_32768_cells_per_axis_is_refused(gpu):
     p, i = PillarVoxelizer(ok, device=gpu)(pts)
     torch.cuda.synchronize()
     assert int(i[0, 0, 0]) == 1 and int(i[0, 1, 0]) == 0                         # 64 points at the origin: one pillar
+
+
+@pytest.mark.parametrize("N", [4, 100, 200])
+@pytest.mark.parametrize("order", [0, 1])
+def test_crowded_cells_at_every_slice_boundary(gpu, oracle, order, N):
+    """The streamed path of a wave whose buckets overflow its LDS pool (streamed_means + emit_live_run): cells with
+    exactly 1, 3, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 130, 255, 256, 257, 381 and 700 points, laid out so that
+    the four pillars of a wave mix every combination of short, pool-sized and streamed buckets (in row-major order
+    the counts follow each other cell by cell; the scrambled order mixes them differently), N below, at and above the
+    pool (4 / 100 / 200: live points in one run, several runs, more than the pool holds), points shuffled: the plain
+    call, the software-pipelined call and -- through PPFeatureNet's fused form -- the pooled-maximum path all bit
+    for bit against the oracle (the running mean is a sequential f64 chain: pillars.cpp:311-328)."""
+    import torch
+    from pp_amd.voxelizer import PillarVoxelizer, VoxelConfig
+    rng = np.random.default_rng(1000 * N + order)
+    counts = [1, 3, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 130, 255, 256, 257, 381, 700]
+    W = H = 12
+    cell_counts = [counts[(i * 7 + (i // W)) % len(counts)] if (i % 5) else 0 for i in range(W * H)]   # some cells empty
+    pts = []
+    for i, c in enumerate(cell_counts):
+        cx, cy = i % W, i // W
+        p = np.empty((c, 4), np.float32)
+        p[:, 0] = cx + rng.uniform(0.01, 0.99, c)
+        p[:, 1] = cy + rng.uniform(0.01, 0.99, c)
+        p[:, 2] = rng.uniform(-1.0, 1.0, c)
+        p[:, 3] = rng.uniform(0, 255, c)
+        pts.append(p)
+    pts = np.concatenate(pts)
+    rng.shuffle(pts)
+    P = 160
+    cfg = VoxelConfig.rect((0.0, float(W)), (0.0, float(H)), 1.0, 1.0, P, N, z_range=(-2.0, 2.0), order=order)
+    ref_p, ref_i, m = oracle.dataset_voxel_stage(pts.astype(np.float64), P, N, *cfg.grid_args(), order=order)
+    assert m == sum(1 for c in cell_counts if c) and m <= P
+    dev = torch.from_numpy(pts).to(gpu)
+    vox = PillarVoxelizer(cfg, device=gpu)
+    pil, idx = vox(dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx[0].cpu().numpy(), ref_i)
+    assert np.array_equal(pil[0].cpu().numpy(), ref_p)
+    outs = list(vox.stream([dev, dev]))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[0], pil) and torch.equal(o[1], idx) for o in outs)
+    # two sweeps per launch, the second with a different shuffle: same pillars, rows in the other input order
+    pts2 = pts.copy()
+    rng.shuffle(pts2)
+    ref_p2, ref_i2, _ = oracle.dataset_voxel_stage(pts2.astype(np.float64), P, N, *cfg.grid_args(), order=order)
+    both = torch.from_numpy(np.stack([pts, pts2])).to(gpu)
+    pb, ib = vox(both)
+    torch.cuda.synchronize()
+    assert np.array_equal(pb[0].cpu().numpy(), ref_p) and np.array_equal(pb[1].cpu().numpy(), ref_p2)
+    assert np.array_equal(ib[1].cpu().numpy(), ref_i2)
+    # the fused feature net takes the same path with a 64-point pool (slices of 64 / 32 / 16): its features must be the
+    # bits of the feature-net kernel run on the dense tensor above (same arithmetic: tests/test_gpu_pfn.py)
+    from test_gpu_pfn import _net
+    fn = _net(gpu)
+    with torch.no_grad():
+        fn.hip_eval = True
+        want = fn(pb)
+    feats, idx_f = vox.pfn(both, fn.fused_params())
+    torch.cuda.synchronize()
+    assert torch.equal(idx_f, ib) and torch.equal(feats, want)
