@@ -172,6 +172,12 @@ struct pp_ctx {
   pp::DevBuf stage_in, stage_out, stage_out2;
   pp::PinBuf pin_in, pin_out, pin_meta;
   pp::HostPool *pool = nullptr;       // host threads of the drop-in entry points (lazily created)
+  // pp_make_ious_f64: the anchors of the previous call stay on the device (and, bit for bit, in a pinned mirror): the
+  // reference hands the SAME anchor arrays in with every sample (utils/box_utils.py:181-183), and 11 MB of them per call
+  // was two thirds of the call.  The gather compares while it copies; only a changed set is uploaded again.
+  pp::PinBuf anchors_pin;
+  pp::DevBuf anchors_dev;
+  int64_t anchors_A = -1;              // rows the mirror holds (-1: nothing)
   hipEvent_t chunk_ev[12] = {};        // one per chunk of the features' device-to-host copy (lazily created)
   int dropin_last_n = 0;               // pp_create_pillars_f64: the previous call's point count and how many points
   int64_t dropin_last_end = 0;         // it emitted -- sizes the feature copy that is sent ahead of the descriptors

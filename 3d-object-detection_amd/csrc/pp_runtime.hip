@@ -236,6 +236,8 @@ extern "C" void pp_ctx_destroy(pp_ctx_t *ctx) {
   ctx->pin_in.release();
   ctx->pin_out.release();
   ctx->pin_meta.release();
+  ctx->anchors_pin.release();
+  ctx->anchors_dev.release();
   delete ctx->pool;
   for (auto &e : ctx->chunk_ev)
     if (e) (void)hipEventDestroy(e);

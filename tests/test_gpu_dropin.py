@@ -142,6 +142,58 @@ def test_make_ious_host_dropin(gpu, oracle, pillars):
                           np.zeros((A, G)))
 
 
+def test_make_ious_anchors_stay_resident_and_follow_in_place_edits(gpu, oracle, pillars):
+    """pp_make_ious_f64 keeps the previous call's anchors on the device and uploads them again only when the
+    gather finds a changed bit.  The reference reads its arguments afresh on every call (pillars.cpp:385-420), so
+    every kind of change between two calls must show in the result: one corner edited in place, one centre edited in
+    place, another anchor count, strided (non-dense) anchor arrays, a -0.0 for a 0.0, and the same set again."""
+    from pp_amd import boxes, synth
+    anchors = boxes.make_anchors(boxes.AnchorConfig(40, 40))
+    ac, an = anchors["corners"].copy(), anchors["centers"].copy()
+    gt = synth.gt_boxes(9, 80, seed=11, margin=10.0)
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 80)
+    A, G = len(ac), 9
+
+    def both(ac_, an_, k_=k_img, c_=c_img):
+        out, ref = np.full((len(ac_), len(k_)), -2.0), np.full((len(ac_), len(k_)), -2.0)
+        pillars.make_ious(ac_, k_, an_, c_, out)
+        oracle.make_ious(ac_, k_, an_, c_, ref)
+        assert np.array_equal(out, ref)
+        return out
+
+    first = both(ac, an)
+    assert np.array_equal(both(ac, an), first)                 # resident: nothing uploaded, same bits
+    hit = int(np.argmax(first.max(axis=1)))                    # an anchor that overlaps a box
+    ac[hit] += 0.25                                            # one anchor's corners, in place
+    moved = both(ac, an)
+    assert not np.array_equal(moved[hit], first[hit])
+    an[hit] += 500.0                                           # its centre far away: the distance gate drops it
+    gated = both(ac, an)
+    assert not gated[hit].any() and moved[hit].any()
+    an[hit] -= 500.0
+    ac[hit] -= 0.25
+    assert np.array_equal(both(ac, an), first)                 # and back
+    # fewer anchors, then the full set again; then strided views of wider arrays (the element-wise gather)
+    both(ac[: A // 3], an[: A // 3])
+    assert np.array_equal(both(ac, an), first)
+    wide_c, wide_n = np.zeros((A, 4, 4)), np.zeros((A, 6))
+    wide_c[:, :, ::2], wide_n[:, ::3] = ac, an[:, :2]
+    assert np.array_equal(both(wide_c[:, :, ::2], wide_n[:, ::3]), first)
+    wide_c[hit, :, ::2] += 0.125
+    assert not np.array_equal(both(wide_c[:, :, ::2], wide_n[:, ::3])[hit], first[hit])
+    # a sign bit alone is a change (compared as bits, not as numbers)
+    z = ac.copy()
+    z[0, 0, 0] = 0.0
+    a0 = both(z, an)
+    z[0, 0, 0] = -0.0
+    assert np.array_equal(both(z, an), a0)
+    # other ground truths against resident anchors
+    gt2 = synth.gt_boxes(5, 80, seed=12, margin=10.0)
+    c2, k2 = boxes.boxes_to_image_space(gt2["centers"], gt2["wlh"], gt2["yaw"], 80)
+    both(z, an, k2, c2)
+    both(ac, an, k2, c2)
+
+
 _DATA_PILLARS_CHILD = r"""
 import sys
 import numpy as np
