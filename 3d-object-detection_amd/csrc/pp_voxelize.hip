@@ -764,6 +764,8 @@ struct EmitArgs {
 enum { kModeDenseVec4 = 0, kModeDenseScalar = 1, kModeCompact = 2, kModePfn = 3 };
 constexpr int kAuxPlain = 0, kAuxSc1 = 16;           // buffer-store cache policy bits (gfx950: sc1 = 16)
 constexpr size_t kSc1MaxBytes = 128u << 20;          // write-through stores pay off up to about half the Infinity Cache
+constexpr size_t kTileXcdMapBytes = 8u << 20;        // k_step: split records (16 + 4 B per point) of the tile role's batch
+                                                     // beyond which it takes its tiles XCD by XCD (two L2s' worth)
 constexpr size_t kStepLaunchBytes = 0;               // dense output per k_step launch; 0 = one launch per call (see
                                                      // pp_voxelize_step_dev: splitting was measured and gains nothing)
 
@@ -1838,7 +1840,7 @@ struct StepArgs {
   OrderRole o;
   PrefetchRole pf;
   int n_tile_blocks, n_split_blocks, emit_nbx;
-  int tile_xcd_map;  // development knob PP_STEP_TILE_XCD=1: the tile role takes its tiles XCD by XCD (tile_of_block)
+  int tile_xcd_map;  // the tile role takes its tiles XCD by XCD (tile_of_block): step_impl, by the size of its gathers
   int tile_b0, split_b0, emit_b0;  // first sweep of each role's batch in this launch (a call whose dense output is
                                    // beyond the Infinity Cache goes out as several launches, a few sweeps each)
   int mix, mix_groups;  // block order: mix_groups groups of {1 binning block, mix-1 emit blocks}, then the rest
@@ -1918,9 +1920,9 @@ __global__ __launch_bounds__(kStepThreads, step_minwaves(MODE)) void k_step(Step
   }
   if (id < a.n_tile_blocks) {
     const int nt = a.t.g.ntiles;
-    // (tile = block here: with tile_of_block k_step's FETCH_SIZE at BASELINE config 5 halves, 56.9 -> 29.0 MiB per launch,
-    // and the launch gets 3 us SLOWER, 107.2 -> 110.1 us, twice in alternation -- the binning reads were never what the
-    // launch waits for; profiles/r06/NOTES.md.  The three-launch k_tile, whose own time they are, keeps the map.)
+    // (tile_xcd_map: set by step_impl once the tile role's gathers exceed what the L2s hold; the logical id is what is
+    // mapped -- under the mixed block order binning block g sits at hardware block g * mix, so blocks with equal g % 8
+    // still share an XCD, whichever one it is)
     const int t_blk = id - (id / nt) * nt;
     const int b = a.tile_b0 + id / nt, tile = a.tile_xcd_map ? tile_of_block(t_blk, nt) : t_blk;
     tile_body<float, kStepWaves>(a.t.np, a.t.g, a.t.ncap, a.t.nchunks_cap, a.t.kslot,
@@ -2672,11 +2674,16 @@ static int step_impl(pp_ctx_t *ctx, void *stream_, const float *points_dev, int6
     a.n_unscatter_blocks = a.un.nblocks * pfn->clear_batch;
   }
   if (a.emit_nbx == 0) a.emit_nbx = 1;
-  static const int tile_xcd = [] {
+  // The tile role takes its tiles XCD by XCD (tile_of_block) once its gathers are beyond what the L2s keep anyway: at
+  // BASELINE config 5 (800k points per launch: 16 MB of split records) k_step's FETCH_SIZE halves, 56.9 -> 29.0 MiB, and the
+  // launch is 1.5-4 us shorter (five alternations on two boxes, tools/lab/knobs_c5.sh / knobs_shapes.sh); at configs[1]'s
+  // 240k points (4.8 MB, which every XCD's 4 MB L2 nearly holds) it measures the same to 0.2-0.4 us worse: tile = block.
+  static const int tile_xcd = [] {  // development knob: PP_STEP_TILE_XCD=0/1 (unset: by size)
     const char *e = getenv("PP_STEP_TILE_XCD");
-    return e ? atoi(e) : 0;
+    return e ? (atoi(e) ? 1 : 0) : -1;
   }();
-  a.tile_xcd_map = tile_xcd;
+  a.tile_xcd_map = tile_xcd >= 0 ? tile_xcd
+                                 : (sb_tile.valid && (size_t)sb_tile.batch * (size_t)sb_tile.maxn * 20u > kTileXcdMapBytes);
   static const int pref_blocks = [] {  // development knob: PP_STEP_PREFETCH=<workgroups> (0 = off)
     const char *e = getenv("PP_STEP_PREFETCH");
     return e ? std::max(0, atoi(e)) : 128;
