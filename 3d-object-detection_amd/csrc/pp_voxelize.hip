@@ -751,7 +751,10 @@ struct EmitArgs {
   float *out;          // [B][9][P][N]
   long long *idx_out;  // [B][P][3]
   // compact mode
-  double *feat_out;  // [B][ncap][9]
+  int4 *pillar_meta_host;   // compact mode, optional: the same descriptors and totals ALSO into device-visible host memory
+  int2 *totals_host;        // (pp_create_pillars_f64: they are on the host when the kernel is done, no copy engine)
+  double *feat_out;  // [B][ncap][9]; or, feat_pack = 1 (f32-valued clouds), [B][ncap] records of kPackedFeat bytes
+  int feat_pack;
   // fused feature-net mode
   const float *pfn_w;  // [64][12]: w[0..8], bias, bn scale, bn shift per output channel
   float *pfn_out;      // [B][64][P], or NULL when only the canvas is wanted
@@ -1016,6 +1019,24 @@ __device__ void streamed_means(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, u
 }
 
 // The features of a big pillar's first min(count, N) points (its mean is in L.mean[k]: streamed_means).
+// Compact mode's store of one point's nine features (the host drop-in's transport, pp_create_pillars_f64).  When the
+// cloud is f32-valued the first four -- x, y, z, intensity, which ARE the input's floats -- travel as floats: 56 bytes a
+// point instead of 72 over PCIe, widened again by the host's scatter; the five differences keep their doubles.
+constexpr int kPackedFeat = 16 + 5 * 8;
+__device__ __forceinline__ void store_compact_features(const EmitArgs &a, int64_t idx, const double (&f)[9]) {
+  if (a.feat_pack) {
+    char *o = reinterpret_cast<char *>(a.feat_out) + idx * kPackedFeat;  // 8-byte aligned
+    *reinterpret_cast<float2 *>(o) = make_float2((float)f[0], (float)f[1]);
+    *reinterpret_cast<float2 *>(o + 8) = make_float2((float)f[2], (float)f[3]);
+#pragma unroll
+    for (int d = 4; d < 9; ++d) *reinterpret_cast<double *>(o + 16 + (d - 4) * 8) = f[d];
+  } else {
+    double *o = a.feat_out + idx * 9;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) o[d] = f[d];
+  }
+}
+
 template <typename TIn, int MODE, int CAP>
 __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, int k, int p,
                                 int lane, PfnAcc *acc = nullptr, float *rmax = nullptr,
@@ -1034,9 +1055,7 @@ __device__ void emit_big_pillar(WaveLds<TIn, CAP> &L, const EmitArgs &a, int b, 
       double f[9];
       point_features((double)rec.x, (double)rec.y, (double)rec.z, (double)rec.w, cx, cy, mean, f);
       if (MODE == kModeCompact) {
-        double *o = a.feat_out + ((int64_t)b * a.ncap + L.start[k] + n) * 9;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) o[d] = f[d];
+        store_compact_features(a, (int64_t)b * a.ncap + L.start[k] + n, f);
       } else if (MODE == kModePfn) {
 #pragma unroll
         for (int d = 0; d < 9; ++d) L.u.feat[d][lane] = (float)f[d];
@@ -1110,9 +1129,7 @@ __device__ __forceinline__ void emit_live_run(WaveLds<TIn, CAP> &L, const EmitAr
     point_features((double)rec[it].x, (double)rec[it].y, (double)rec[it].z, (double)rec[it].w, L.cx[k], L.cy[k],
                    L.mean[k], f);
     if (MODE == kModeCompact) {
-      double *o = a.feat_out + ((int64_t)b * a.ncap + L.start[k] + n) * 9;
-#pragma unroll
-      for (int d = 0; d < 9; ++d) o[d] = f[d];
+      store_compact_features(a, (int64_t)b * a.ncap + L.start[k] + n, f);
     } else if (MODE == kModeDenseScalar) {
 #pragma unroll
       for (int d = 0; d < 9; ++d) outb[((int64_t)d * a.P + (p0 + k)) * N + n] = (float)f[d];
@@ -1220,9 +1237,7 @@ __device__ __forceinline__ void emit_group(WaveLds<TIn, CAP> &L, const EmitArgs 
       point_features((double)L.px[q], (double)L.py[q], (double)L.pz[q], (double)L.pr[q],
                      L.cx[k], L.cy[k], L.mean[k], f);
       if (MODE == kModeCompact) {
-        double *o = a.feat_out + ((int64_t)b * a.ncap + start0 + j) * 9;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) o[d] = f[d];
+        store_compact_features(a, (int64_t)b * a.ncap + start0 + j, f);
       } else if (MODE == kModeDenseScalar) {
 #pragma unroll
         for (int d = 0; d < 9; ++d)
@@ -1394,8 +1409,10 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
   const u64 tot = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(inc >> 32), kWave - 1) << 32) |
                   (unsigned)__builtin_amdgcn_readlane((int)(inc & 0xFFFFFFFFull), kWave - 1);
   const unsigned lane_excl = (unsigned)((inc - mine) & 0xFFFFFFFFull);  // occupied cells before my tiles
-  if (bx == 0 && w == 0 && lane == 0)
+  if (bx == 0 && w == 0 && lane == 0) {
     a.totals[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
+    if (MODE == kModeCompact && a.totals_host) a.totals_host[b] = make_int2((int)(tot & 0xFFFFFFFFull), (int)(tot >> 32));
+  }
   const int npil = min((int)(tot & 0xFFFFFFFFull), P);
   PP_STAMP_E(1);
 #pragma unroll
@@ -1432,7 +1449,10 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, WaveLds<TIn, CAP> *
     before_k = (unsigned)__builtin_amdgcn_readlane((int)before_k, owner_s);
     if (lane == k) {
       m = a.tile_meta[((int64_t)b * ntiles + tile_k) * (1 << a.g.tile_shift) + (p - before_k)];
-      if (MODE == kModeCompact) a.pillar_meta[(int64_t)b * P + p] = m;
+      if (MODE == kModeCompact) {
+        a.pillar_meta[(int64_t)b * P + p] = m;
+        if (a.pillar_meta_host) a.pillar_meta_host[(int64_t)b * P + p] = m;
+      }
     }
   }
   }  // tile-prefix path
@@ -2148,7 +2168,8 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
                     int mode, float *out, long long *idx_out, double *feat_out,
                     bool timed, const float *pfn_w = nullptr, float *pfn_out = nullptr,
                     float *canvas = nullptr, int canvas_h = 0, int canvas_w = 0,
-                    int canvas_nhwc = 0, const long long *prev_idx = nullptr) {
+                    int canvas_nhwc = 0, const long long *prev_idx = nullptr, int feat_pack = 0,
+                    int4 *meta_direct = nullptr, int2 *totals_direct = nullptr) {
   constexpr int slot = 0;  // the plain calls' workspace (k_step's batches rotate through the others)
   using Rec = typename Rec4<TIn>::type;
   char *ws = static_cast<char *>(ctx->vox_ws[slot].ptr);
@@ -2252,6 +2273,9 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
   a.out = out;
   a.idx_out = idx_out;
   a.feat_out = feat_out;
+  a.feat_pack = feat_pack;
+  a.pillar_meta_host = meta_direct;
+  a.totals_host = totals_direct;
   a.pfn_w = pfn_w;
   a.pfn_out = pfn_out;
   a.canvas = canvas;
@@ -2303,6 +2327,35 @@ int launch_pipeline(pp_ctx *ctx, hipStream_t stream, const TIn *pts, int64_t swe
     }
   }
   return PP_OK;
+}
+
+// The host drop-in's way back for the features (pp_create_pillars_f64): piece `part` of `parts` of the compact records
+// [0, end) from the device staging into device-visible host memory, 16 bytes a lane.  `end` -- how many points the call
+// emitted -- is read from the descriptors k_emit has just left on the DEVICE (same stream), so the pieces are enqueued
+// behind the kernels without the host having seen a single number: the round trip "descriptors back, then size and start
+// the copy" (a wait, a copy engine's start-up) is gone, and what crosses the link is exactly the emitted records.
+// The host cuts [0, end) at the same places (piece_begin).
+constexpr int kCopyThreads = 256;
+__host__ __device__ inline long long piece_begin(long long end, int part, int parts) { return end * part / parts; }
+__global__ __launch_bounds__(kCopyThreads) void k_records_to_host(const int2 *totals, const int4 *meta, int P, int max_pillars,
+                                                                   int rec, const char *src, char *dst, int part, int parts) {
+  const int npil = min(totals[0].x, min(P, max_pillars));
+  if (npil <= 0) return;
+  const int4 last = meta[npil - 1];
+  const long long end = (long long)last.y + last.z;
+  const long long b0 = piece_begin(end, part, parts) * rec, b1 = piece_begin(end, part + 1, parts) * rec;  // multiples of 8
+  // 16-byte units from the first 16-aligned byte; the (at most one) 8-byte piece at either end by one lane each
+  const long long a0 = (b0 + 15) & ~15ll, a1 = b1 & ~15ll;
+  const long long tid = (long long)blockIdx.x * kCopyThreads + threadIdx.x, nthr = (long long)gridDim.x * kCopyThreads;
+  if (a0 >= a1) {  // (a piece shorter than a unit)
+    for (long long o = b0 + tid * 8; o < b1; o += nthr * 8)
+      *reinterpret_cast<uint2 *>(dst + o) = *reinterpret_cast<const uint2 *>(src + o);
+    return;
+  }
+  if (tid == 0 && b0 < a0) *reinterpret_cast<uint2 *>(dst + b0) = *reinterpret_cast<const uint2 *>(src + b0);
+  if (tid == 1 && a1 < b1) *reinterpret_cast<uint2 *>(dst + a1) = *reinterpret_cast<const uint2 *>(src + a1);
+  for (long long o = a0 + tid * 16; o < a1; o += nthr * 16)
+    *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
 }
 
 }  // namespace
@@ -3137,6 +3190,9 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   // the f64-input kernels as before.  (NaN compares unequal to itself and counts as surviving: both kernel families
   // drop the point.)
   static const bool k_try_f32 = [] { const char *e = getenv("PP_DROPIN_F32"); return e ? atoi(e) != 0 : true; }();
+  // ... and on the way back such a cloud's x, y, z, intensity columns travel as the floats they are (56 bytes a point
+  // instead of 72; the scatter widens them): store_compact_features.  PP_DROPIN_PACK=0: nine doubles as before.
+  static const bool k_pack = [] { const char *e = getenv("PP_DROPIN_PACK"); return e ? atoi(e) != 0 : true; }();
   const char *src_pts = static_cast<const char *>(points);
   bool as_f32 = k_try_f32;
   if (as_f32) {
@@ -3164,14 +3220,36 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   if (rc) return rc;
   rc = ctx->stage_out.ensure((size_t)l.ncap * 72);
   if (rc) return rc;
+  // Two small transfers need no copy engine at all (PP_DROPIN_DIRECT, bit mask; f32-valued clouds): 1 -- k_split reads
+  // the gathered points straight from the pinned staging (each point is read once, coalesced: the kernel runs at the
+  // link's rate and the copy's start-up and completion hand-over fall away); 2 -- k_emit writes the descriptors and the
+  // totals, which nothing on the device reads back, straight into pinned memory: they are there when the kernel is.
+  // 4 -- the features' way back is k_records_to_host, enqueued behind the kernels and sized on the device.
+  static const int k_direct = [] { const char *e = getenv("PP_DROPIN_DIRECT"); return e ? atoi(e) : 7; }();
+  const size_t meta_bytes = (l.totals - l.meta) + 8;
+  rc = ctx->pin_meta.ensure(meta_bytes);
+  if (rc) return rc;
+  char *pm = static_cast<char *>(ctx->pin_meta.ptr);
+  void *pm_dev = nullptr;
+  const bool meta_direct = (k_direct & 2) && hipHostGetDevicePointer(&pm_dev, pm, 0) == hipSuccess && pm_dev;
+  (void)hipGetLastError();  // (a refused mapping is not an error of this call: the copies are used)
+  int4 *meta_host = meta_direct ? reinterpret_cast<int4 *>(pm_dev) : nullptr;
+  int2 *totals_host = meta_direct ? reinterpret_cast<int2 *>(static_cast<char *>(pm_dev) + (l.totals - l.meta)) : nullptr;
   NPoints np;
   std::memset(&np, 0, sizeof np);
   np.n[0] = n;
   if (as_f32) {
     lap(0);
-    PP_HIP_TRY(hipMemcpyAsync(ctx->stage_in.ptr, ctx->pin_in.ptr, (size_t)n * 16, hipMemcpyHostToDevice, stream));
-    rc = launch_pipeline<float>(ctx, stream, static_cast<const float *>(ctx->stage_in.ptr), l.ncap, 4, 1, 1, np, 1, n, g, P,
-                                N, l, kModeCompact, nullptr, nullptr, static_cast<double *>(ctx->stage_out.ptr), false);
+    const float *pts_dev = static_cast<const float *>(ctx->stage_in.ptr);
+    void *mapped = nullptr;
+    if ((k_direct & 1) && hipHostGetDevicePointer(&mapped, ctx->pin_in.ptr, 0) == hipSuccess && mapped)
+      pts_dev = static_cast<const float *>(mapped);
+    else
+      PP_HIP_TRY(hipMemcpyAsync(ctx->stage_in.ptr, ctx->pin_in.ptr, (size_t)n * 16, hipMemcpyHostToDevice, stream));
+    (void)hipGetLastError();
+    rc = launch_pipeline<float>(ctx, stream, pts_dev, l.ncap, 4, 1, 1, np, 1, n, g, P,
+                                N, l, kModeCompact, nullptr, nullptr, static_cast<double *>(ctx->stage_out.ptr), false,
+                                nullptr, nullptr, nullptr, 0, 0, 0, nullptr, k_pack ? 1 : 0, meta_host, totals_host);
     if (rc) return rc;
   } else {
     // the caller's points are a strided view (data/dataset.py:88 passes the transpose of a [4, n] array): rows split
@@ -3193,43 +3271,61 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
     lap(0);
     rc = launch_pipeline<double>(ctx, stream, static_cast<const double *>(ctx->stage_in.ptr),
                                  l.ncap, 4, 1, 1, np, 1, n, g, P, N, l, kModeCompact, nullptr,
-                                 nullptr, static_cast<double *>(ctx->stage_out.ptr), false);
+                                 nullptr, static_cast<double *>(ctx->stage_out.ptr), false,
+                                 nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, meta_host, totals_host);
     if (rc) return rc;
   }
   // descriptors back in ONE copy: pillar_meta[P] (pillar order, written by k_emit in compact mode) and, behind it in the
   // workspace, the totals
-  const size_t meta_bytes = (l.totals - l.meta) + 8;
-  rc = ctx->pin_meta.ensure(meta_bytes);
-  if (rc) return rc;
   rc = ctx->pin_out.ensure((size_t)l.ncap * 72);
   if (rc) return rc;
   char *ws = static_cast<char *>(ctx->vox_ws[0].ptr);
-  char *pm = static_cast<char *>(ctx->pin_meta.ptr);
-  PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.meta, meta_bytes, hipMemcpyDeviceToHost, stream));
+  if (!meta_direct) PP_HIP_TRY(hipMemcpyAsync(pm, ws + l.meta, meta_bytes, hipMemcpyDeviceToHost, stream));
   hipEvent_t ev_meta = ctx->chunk_ev[kMaxEv - 1];
   PP_HIP_TRY(hipEventRecord(ev_meta, stream));
   // The features follow WITHOUT waiting for the descriptors: how many points the call emits is only known from them, so
   // the copy is sized by what the previous call of this shape emitted (consecutive sweeps are alike) plus an eighth,
   // and topped up below when that was short.  In chunks: chunk k is scattered while chunk k + 1 is on its way.
+  const bool packed = as_f32 && k_pack;
+  const int64_t rec = packed ? kPackedFeat : 72;  // bytes of a point's features on the way back
   int64_t cb[kMaxEv + 1];  // chunk c = compact points [cb[c], cb[c + 1])
   int nch = 0;
   cb[0] = 0;
+  // (PP_DROPIN_DIRECT & 4) the pieces go out right here, behind the kernels, sized on the device by k_records_to_host
+  int direct_pieces = 0;
+  {
+    void *out_dev = nullptr;
+    if ((k_direct & 4) && N > 0 && hipHostGetDevicePointer(&out_dev, ctx->pin_out.ptr, 0) == hipSuccess && out_dev) {
+      direct_pieces = (int64_t)n * rec >= (256 << 10) ? k_chunks : 1;
+      const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)n * rec / direct_pieces + 16 * kCopyThreads - 1) /
+                                                                               (16 * kCopyThreads)));
+      for (int c = 0; c < direct_pieces; ++c) {
+        hipLaunchKernelGGL(k_records_to_host, dim3((unsigned)blocks), dim3(kCopyThreads), 0, stream,
+                           reinterpret_cast<const int2 *>(ws + l.totals), reinterpret_cast<const int4 *>(ws + l.meta), P,
+                           max_pillars, (int)rec, static_cast<const char *>(ctx->stage_out.ptr), static_cast<char *>(out_dev),
+                           c, direct_pieces);
+        PP_HIP_TRY(hipGetLastError());
+        PP_HIP_TRY(hipEventRecord(ctx->chunk_ev[c], stream));
+      }
+    }
+    (void)hipGetLastError();
+  }
   auto issue_chunks = [&](int64_t upto, int pieces) -> int {
     const int64_t from = cb[nch];
     for (int c = 0; c < pieces && nch < kMaxEv - 2; ++c) {
       const int64_t b1 = from + (upto - from) * (c + 1) / pieces;
       if (b1 <= cb[nch]) continue;
-      PP_HIP_TRY(hipMemcpyAsync(static_cast<char *>(ctx->pin_out.ptr) + cb[nch] * 72,
-                                static_cast<const char *>(ctx->stage_out.ptr) + cb[nch] * 72, (size_t)(b1 - cb[nch]) * 72,
+      PP_HIP_TRY(hipMemcpyAsync(static_cast<char *>(ctx->pin_out.ptr) + cb[nch] * rec,
+                                static_cast<const char *>(ctx->stage_out.ptr) + cb[nch] * rec, (size_t)(b1 - cb[nch]) * rec,
                                 hipMemcpyDeviceToHost, stream));
       PP_HIP_TRY(hipEventRecord(ctx->chunk_ev[nch], stream));
       cb[++nch] = b1;
     }
     return PP_OK;
   };
-  if (k_spec && N > 0 && ctx->dropin_last_n == n && ctx->dropin_last_end > 0) {
+  if (!direct_pieces && k_spec && N > 0 && ctx->dropin_last_n == n && ctx->dropin_last_end > 0) {
     const int64_t guess = std::min<int64_t>(n, ctx->dropin_last_end + ctx->dropin_last_end / 8);
-    rc = issue_chunks(guess, guess * 72 >= (256 << 10) ? k_chunks : 1);
+    rc = issue_chunks(guess, guess * rec >= (256 << 10) ? k_chunks : 1);
     if (rc) return rc;
   }
   PP_HIP_TRY(wait_event(ev_meta));
@@ -3239,14 +3335,29 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   if (num_cells) *num_cells = tot[0];
   const int npil = std::min(tot[0], std::min(P, max_pillars));
   if (npil == 0) {
-    if (nch) PP_HIP_TRY(hipStreamSynchronize(stream));  // the speculative copies still target the pinned buffer
+    if (nch || direct_pieces) PP_HIP_TRY(hipStreamSynchronize(stream));  // copies sent ahead still target the pinned buffer
     return PP_OK;
   }
   const int4 *meta = reinterpret_cast<const int4 *>(pm);
   const int64_t end = (int64_t)meta[npil - 1].y + meta[npil - 1].z;
   ctx->dropin_last_n = n;
   ctx->dropin_last_end = end;
-  const double *feat = static_cast<const double *>(ctx->pin_out.ptr);
+  const char *feat = static_cast<const char *>(ctx->pin_out.ptr);
+  // `live` points' features from compact position `at` into a dense [live][9] run of doubles
+  auto copy_rows = [&](char *dst, int64_t at, int live) {
+    if (!packed) {
+      std::memcpy(dst, feat + at * 72, (size_t)live * 72);
+      return;
+    }
+    const char *src = feat + at * kPackedFeat;
+    for (int k = 0; k < live; ++k, src += kPackedFeat, dst += 72) {
+      float head[4];
+      std::memcpy(head, src, 16);
+      const double wide[4] = {(double)head[0], (double)head[1], (double)head[2], (double)head[3]};
+      std::memcpy(dst, wide, 32);
+      std::memcpy(dst + 32, src + 16, 40);
+    }
+  };
   char *tp = static_cast<char *>(tensor);
   char *ip = static_cast<char *>(indices);
   auto write_index_row = [&](int p) {  // pillars.cpp:389-391
@@ -3269,8 +3380,11 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   const bool dense_t = tensor && t_strides[2] == 8 && t_strides[1] == 72 && t_shape[2] >= 9 && t_shape[1] >= N &&
                        t_shape[0] >= npil;
   const bool dense_all = dense_t && indices && i_shape[0] >= npil && i_shape[1] >= 3;
-  if (N > 0 && cb[nch] < end) {  // nothing sent ahead, or the guess was short: the rest
-    rc = issue_chunks(end, (dense_all && (end - cb[nch]) * 72 >= (256 << 10)) ? k_chunks : 1);
+  if (direct_pieces) {  // the device cut [0, end) at the same places
+    nch = direct_pieces;
+    for (int c = 0; c <= nch; ++c) cb[c] = piece_begin(end, c, nch);
+  } else if (N > 0 && cb[nch] < end) {  // nothing sent ahead, or the guess was short: the rest
+    rc = issue_chunks(end, (dense_all && (end - cb[nch]) * rec >= (256 << 10)) ? k_chunks : 1);
     if (rc) return rc;
     if (cb[nch] < end) {  // (out of events: cannot happen with k_chunks <= 8 / 2)
       set_error("create_pillars: internal: chunk events exhausted");
@@ -3307,7 +3421,7 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
             if (nl > 0) __builtin_prefetch(nx + nl - 1, 1, 0);
           }
           const int live = std::min(meta[p].z, N);
-          if (live > 0) std::memcpy(tp + (int64_t)p * t_strides[0], feat + (int64_t)meta[p].y * 9, (size_t)live * 72);
+          if (live > 0) copy_rows(tp + (int64_t)p * t_strides[0], meta[p].y, live);
           write_index_row(p);
         }
       });
@@ -3327,10 +3441,11 @@ extern "C" int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t 
   for (int p = 0; p < npil; ++p) {
     const int live = std::min(meta[p].z, N);
     if (dense_t) {
-      if (live > 0) std::memcpy(tp + (int64_t)p * t_strides[0], feat + (int64_t)meta[p].y * 9, (size_t)live * 72);
+      if (live > 0) copy_rows(tp + (int64_t)p * t_strides[0], meta[p].y, live);
     } else
     for (int k = 0; k < live; ++k) {
-      const double *f = feat + ((int64_t)meta[p].y + k) * 9;
+      double f[9];
+      copy_rows(reinterpret_cast<char *>(f), (int64_t)meta[p].y + k, 1);
       for (int d = 0; d < 9; ++d) {
         if (!tensor || p >= t_shape[0] || k >= t_shape[1] || d >= t_shape[2]) {
           set_error("create_pillars: tensor index (%d,%d,%d) out of range", p, k, d);
