@@ -2118,6 +2118,20 @@ extern "C" int pp_make_ious_dev(pp_ctx_t *ctx, void *stream_, const double *a_co
                           g_corners_dev, g_centers_dev, g_center_cols, G, ious_dev, nullptr, nullptr, 0);
 }
 
+// make_ious' host drop-in: the record count and the error word into device-visible host memory behind the kernel (one
+// wait instead of three copies with a wait each); the error word is cleared once it has been handed over, like
+// pp_iou_check does
+__global__ void k_iou_tail(const unsigned *count, int *flag, unsigned *host_out) {
+  if (threadIdx.x == 0) {
+    const int f = *flag;
+    host_out[0] = *count;
+    host_out[1] = (unsigned)f;
+    if (f) *flag = 0;
+  }
+}
+
+static int iou_flag_result(pp_ctx_t *ctx, int flag);
+
 // error flag of the last IoU / target launch on this context (synchronises)
 extern "C" int pp_iou_check(pp_ctx_t *ctx, void *stream_) {
   if (!ctx || !ctx->iou_ws.ptr) return PP_OK;
@@ -2129,6 +2143,12 @@ extern "C" int pp_iou_check(pp_ctx_t *ctx, void *stream_) {
   if (flag) {
     // the flag is sticky across launches until it has been reported once
     PP_HIP_TRY(hipMemsetAsync(ctx->iou_ws.ptr, 0, 4, static_cast<hipStream_t>(stream_)));
+  }
+  return iou_flag_result(ctx, flag);
+}
+
+static int iou_flag_result(pp_ctx_t *ctx, int flag) {
+  if (flag) {
     if (flag & kErrPosOverflow) {  // (takes precedence: the scratch has to be re-armed whatever else happened)
       // the positive list overflowed (sized from the candidate count, so only reachable through boxes whose centre is
       // not finite): entries were dropped; re-arm every scratch word before the next call
@@ -2250,9 +2270,26 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
     unsigned *count_dev = reinterpret_cast<unsigned *>(so);
     IouTriple *triples_dev = reinterpret_cast<IouTriple *>(so + 256);
     unsigned *count_host = static_cast<unsigned *>(ctx->pin_meta.ptr);
-    rc = launch_make_ious(ctx, stream, d_a, d_a + A * 8, 2, A, d_g, d_g + G * 8, 2, G, nullptr, triples_dev, count_dev, cap);
+    // PP_DROPIN_DIRECT (any bit; pp_create_pillars_f64 shares the knob): the kernel appends its records straight into
+    // device-visible pinned memory -- each is one 16-byte store of one lane, ~8 000 of them -- and a one-thread kernel
+    // behind it leaves the count and the error word there too: the call waits for the device ONCE (before: the count's
+    // copy, the records' copy and pp_iou_check's copy, a wait each).  Lists beyond 16 MB keep the copies.
+    static const bool k_direct = [] { const char *e = getenv("PP_DROPIN_DIRECT"); return e ? atoi(e) != 0 : true; }();
+    void *tr_map = nullptr, *cnt_map = nullptr;
+    bool direct = k_direct && (size_t)cap * 16 <= (16u << 20) && ctx->pin_out.ensure((size_t)cap * 16) == PP_OK &&
+                  hipHostGetDevicePointer(&tr_map, ctx->pin_out.ptr, 0) == hipSuccess && tr_map &&
+                  hipHostGetDevicePointer(&cnt_map, count_host, 0) == hipSuccess && cnt_map;
+    (void)hipGetLastError();  // (a refused mapping is not an error of this call: the copies are used)
+    rc = launch_make_ious(ctx, stream, d_a, d_a + A * 8, 2, A, d_g, d_g + G * 8, 2, G, nullptr,
+                          direct ? static_cast<IouTriple *>(tr_map) : triples_dev, count_dev, cap);
     if (rc) return rc;
-    PP_HIP_TRY(hipMemcpyAsync(count_host, count_dev, 4, hipMemcpyDeviceToHost, stream));
+    if (direct) {
+      hipLaunchKernelGGL(k_iou_tail, dim3(1), dim3(64), 0, stream, count_dev, static_cast<int *>(ctx->iou_ws.ptr),
+                         static_cast<unsigned *>(cnt_map));
+      PP_HIP_TRY(hipGetLastError());
+    } else {
+      PP_HIP_TRY(hipMemcpyAsync(count_host, count_dev, 4, hipMemcpyDeviceToHost, stream));
+    }
     // ... meanwhile: zeros into the caller's matrix (rows split across the workers)
     const std::function<void(int, int)> zero_rows = [&](int part, int parts) {
       const int64_t i0 = A * part / parts, i1 = A * (part + 1) / parts;
@@ -2269,13 +2306,16 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
     pool->wait();
     PP_HIP_TRY(e_sync);
     lap(1);
-    const unsigned count = *count_host;
+    const unsigned count = count_host[0];
+    if (direct && count_host[1]) return iou_flag_result(ctx, (int)count_host[1]);  // (a wrong winding: the matrix is zeros)
     if (count <= cap) {
       if (count) {
-        rc = ctx->pin_out.ensure((size_t)count * 16);
-        if (rc) return rc;
-        PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, triples_dev, (size_t)count * 16, hipMemcpyDeviceToHost, stream));
-        PP_HIP_TRY(hipStreamSynchronize(stream));
+        if (!direct) {
+          rc = ctx->pin_out.ensure((size_t)count * 16);
+          if (rc) return rc;
+          PP_HIP_TRY(hipMemcpyAsync(ctx->pin_out.ptr, triples_dev, (size_t)count * 16, hipMemcpyDeviceToHost, stream));
+          PP_HIP_TRY(hipStreamSynchronize(stream));
+        }
         const IouTriple *tr = static_cast<const IouTriple *>(ctx->pin_out.ptr);
         for (unsigned k = 0; k < count; ++k)
           std::memcpy(dst + (int64_t)tr[k].anchor * io[0] + (int64_t)tr[k].box * io[1], &tr[k].iou, 8);
@@ -2284,7 +2324,7 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
       if (trace)
         fprintf(stderr, "pp_make_ious_f64: gather + compare %.0f us (anchors %s) | H2D + kernel (host zero fill alongside, %d threads) %.0f | %u records back + written %.0f\n",
                 t_us[0], changed.load() ? "uploaded" : "resident", pool->size(), t_us[1], count, t_us[2]);
-      return pp_iou_check(ctx, stream);
+      return direct ? PP_OK : pp_iou_check(ctx, stream);
     }
     // the list overflowed: the anchors are on the device already, take the dense form
   }

@@ -1,6 +1,8 @@
 """GPU tests of the host drop-in module (the reference's pybind11 surface,
 data/pillars.cpp:429-435) through pp_create_pillars_f64 / pp_make_ious_f64."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -399,3 +401,65 @@ def test_python_threads_calling_at_once_are_serialised(gpu, oracle, pillars):
         Tr, Ir = np.zeros((P, N, 9)), np.zeros((P, 3))
         oracle.create_pillars(c, Tr, Ir, N, P, *g, order=oracle.ORDER_SCRAMBLED)
         assert np.array_equal(outs[k][1], Ir) and np.array_equal(outs[k][0], Tr), k
+
+
+_TRANSPORT_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import pp_amd
+from pp_amd import pillars, synth
+from oracle import oracle
+P, N = 9000, 20
+g = (0.2, 0.2, -20.0, -20.0, -10.0, 20.0, 20.0, 10.0, 200)
+f32_valued = synth.lidar_like(40000, 20.0, 9).astype(np.float64)
+f64_valued = f32_valued + 1e-9
+for name, p in (("f32", f32_valued), ("f64", f64_valued), ("tiny", f32_valued[:37]), ("N0", f32_valued)):
+    n_ = 0 if name == "N0" else N
+    for rep in range(3):                                    # the staging buffers are re-used call after call
+        T, I = np.full((P, max(n_, 1), 9), 0.25), np.full((P, 3), -4.0)
+        pillars.create_pillars(np.ascontiguousarray(p.T).transpose([1, 0]), T, I, n_, P, *g)
+        Tr, Ir = np.full((P, max(n_, 1), 9), 0.25), np.full((P, 3), -4.0)
+        oracle.create_pillars(p, Tr, Ir, n_, P, *g, order=oracle.ORDER_SCRAMBLED)
+        assert np.array_equal(I, Ir), (name, rep)
+        assert np.array_equal(T.view(np.uint64), Tr.view(np.uint64)), (name, rep)
+    # a strided tensor: the element-wise scatter reads the same records
+    big = np.zeros((P, N, 18))
+    pillars.create_pillars(p, big[:, :, ::2], I, N, P, *g)
+    Tr2 = np.zeros((P, N, 9))
+    oracle.create_pillars(p, Tr2, Ir, N, P, *g, order=oracle.ORDER_SCRAMBLED)
+    assert np.array_equal(big[:, :, ::2], Tr2) and not big[:, :, 1::2].any(), name
+# make_ious: the records straight into pinned memory (any PP_DROPIN_DIRECT bit) or by copies (0)
+from pp_amd import boxes
+anchors = boxes.make_anchors(boxes.AnchorConfig(50, 50))
+for seed, G in ((3, 11), (4, 1), (5, 30)):
+    gt = synth.gt_boxes(G, 100, seed=seed, margin=12.0)
+    c_img, k_img = boxes.boxes_to_image_space(gt["centers"], gt["wlh"], gt["yaw"], 100)
+    out, ref = np.full((len(anchors["corners"]), G), -1.0), np.full((len(anchors["corners"]), G), -1.0)
+    pillars.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, out)
+    oracle.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, ref)
+    assert np.array_equal(out, ref) and (out > 0).any(), seed
+try:
+    pillars.make_ious(anchors["corners"], k_img[:, ::-1].copy(), anchors["centers"], c_img, out)
+    raise SystemExit("wrong winding accepted")
+except ValueError:
+    pass
+pillars.make_ious(anchors["corners"], k_img, anchors["centers"], c_img, out)       # the error word was cleared
+assert np.array_equal(out, ref)
+print("transport ok")
+"""
+
+
+@pytest.mark.parametrize("direct,pack", [(0, 0), (0, 1), (3, 1), (4, 0), (7, 1)])
+def test_host_transport_variants_give_the_same_bits(gpu, direct, pack, tmp_path):
+    """pp_create_pillars_f64's ways over the link (read once per process from the environment, hence a child each):
+    PP_DROPIN_DIRECT bit 1 -- k_split reads the gathered points from mapped pinned memory, no host-to-device copy; bit 2
+    -- k_emit leaves descriptors and totals in mapped pinned memory as well; bit 4 -- the feature records come back
+    through k_records_to_host, sized on the device; PP_DROPIN_PACK -- an f32-valued cloud's x, y, z, intensity travel as
+    floats (56-byte records).  Every combination, for f32-valued and other clouds, a 37-point cloud, max_points 0 and
+    a strided tensor: the oracle's bits (pillars.cpp:335-396).  pp_make_ious_f64 with its records appended straight into
+    pinned memory (any bit) or copied (0): the oracle's matrix, a wrong winding raised and cleared (pillars.cpp:166-169)."""
+    env = dict(os.environ, PP_DROPIN_DIRECT=str(direct), PP_DROPIN_PACK=str(pack))
+    r = subprocess.run([sys.executable, "-c", _TRANSPORT_CHILD, ROOT], cwd=str(tmp_path), env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "transport ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
