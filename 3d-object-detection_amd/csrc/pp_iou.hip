@@ -2255,6 +2255,8 @@ extern "C" int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
   lap(0);
   double *d_a = static_cast<double *>(ctx->anchors_dev.ptr), *d_g = static_cast<double *>(ctx->stage_in.ptr);
   if (changed.load()) {
+    ctx->anchors_A = -1;  // (the mirror is ahead of the device until the copy is enqueued: a failure here must not leave
+                          // the next call comparing against a mirror the device never received)
     PP_HIP_TRY(hipMemcpyAsync(d_a, h_ac, a_bytes, hipMemcpyHostToDevice, stream));
     ctx->anchors_A = A;  // (the copy is ordered before every launch below on this stream, and the call ends synchronised)
   }
