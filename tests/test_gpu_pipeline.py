@@ -104,6 +104,10 @@ def test_bench_contract_line(gpu):
         assert r["hip_ms"] > 0 and r["cpu_ms"] > 0 and abs(r["speedup"] - r["cpu_ms"] / r["hip_ms"]) < 1e-9
         assert r["meets_50x"] == (r["speedup"] >= 50.0)
         assert r["faithful_cpu_ms"] > 0 and abs(r["faithful_speedup"] - r["faithful_cpu_ms"] / r["hip_ms"]) < 1e-9
+    # make_ious with the anchors resident (the reference's call pattern) and with one anchor edited before every call
+    mi = dh["make_ious_call"]
+    assert mi["anchors_changed_every_call_ms"] >= mi["hip_ms"] * 0.9
+    assert abs(mi["anchors_changed_every_call_speedup"] - mi["cpu_ms"] / mi["anchors_changed_every_call_ms"]) < 0.02
 
 
 def test_fused_epilogue_equals_relu_batchnorm(gpu):
