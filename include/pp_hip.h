@@ -273,6 +273,12 @@ int pp_voxelize_pfn_canvas_reuse_dev(pp_ctx_t *ctx, void *stream, const float *p
  * zeroes); out-of-range writes return PP_ERR_INDEX after the in-range part was
  * written (pybind11 .mutable_at semantics).  num_cells (may be NULL) receives
  * the number of non-empty cells.
+ * Host side (one call at a time per context; the call returns with every
+ * device operation finished): a pool of host threads gathers the points and
+ * scatters the rows (PP_HOST_THREADS); a cloud whose every value is an f32
+ * value crosses the link as f32, both ways where it applies; the context's
+ * pinned staging buffers are read and written by the kernels themselves
+ * (device-visible host memory; PP_DROPIN_DIRECT=0: copy engines instead).
  */
 int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,
                           int64_t p_stride0, int64_t p_stride1, void *tensor,
@@ -286,6 +292,12 @@ int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,
  * all-pairs rotated IoU; every ious[i][j] is written.  f64 host arrays, BYTE
  * strides.  a_corners [A,4,2], g_corners [G,4,2], a_centers [A,>=2],
  * g_centers [G,>=2], ious [A,G].
+ * The anchors of the previous call stay on the device (80 bytes each, freed
+ * with the context): every call compares the caller's anchor arrays bit for
+ * bit with a pinned mirror and uploads them again only when something changed
+ * (utils/box_utils.py:181-183 passes the same arrays for every sample).
+ * Returns PP_ERR_WINDING for a box with the wrong corner order (the
+ * reference: std::exit(1), pillars.cpp:166-169); ious is then all zeros.
  */
 int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
                      const int64_t ac_strides[3], const void *g_corners,
