@@ -297,7 +297,8 @@ int pp_create_pillars_f64(pp_ctx_t *ctx, const void *points, int64_t n_points,
  * bit with a pinned mirror and uploads them again only when something changed
  * (utils/box_utils.py:181-183 passes the same arrays for every sample).
  * Returns PP_ERR_WINDING for a box with the wrong corner order (the
- * reference: std::exit(1), pillars.cpp:166-169); ious is then all zeros.
+ * reference: std::exit(1), pillars.cpp:166-169); the contents of ious are then
+ * unspecified.
  */
 int pp_make_ious_f64(pp_ctx_t *ctx, const void *a_corners, int64_t A,
                      const int64_t ac_strides[3], const void *g_corners,
