@@ -414,7 +414,12 @@ P, N = 9000, 20
 g = (0.2, 0.2, -20.0, -20.0, -10.0, 20.0, 20.0, 10.0, 200)
 f32_valued = synth.lidar_like(40000, 20.0, 9).astype(np.float64)
 f64_valued = f32_valued + 1e-9
-for name, p in (("f32", f32_valued), ("f64", f64_valued), ("tiny", f32_valued[:37]), ("N0", f32_valued)):
+far = f32_valued[:6000].copy()
+far[:, 0] += 1000.0                                         # 6 000 points, every one outside the grid ...
+few = far.copy()
+few[[5, 4000, 5999]] = f32_valued[[5, 4000, 5999]]          # ... but three (two copy pieces, one of them empty)
+for name, p in (("f32", f32_valued), ("f64", f64_valued), ("tiny", f32_valued[:37]), ("N0", f32_valued),
+                ("none in range", far), ("three in range", few), ("three in range, f64", few + 1e-9)):
     n_ = 0 if name == "N0" else N
     for rep in range(3):                                    # the staging buffers are re-used call after call
         T, I = np.full((P, max(n_, 1), 9), 0.25), np.full((P, 3), -4.0)
