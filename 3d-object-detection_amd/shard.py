@@ -14,12 +14,16 @@ import torch.distributed as dist
 
 
 class ShardContext:
-    def __init__(self, rank=0, world_size=1, local_rank=0, backend=None):
+    def __init__(self, rank=0, world_size=1, local_rank=0, backend=None, force_group=False):
         self.rank, self.world_size, self.local_rank, self.backend = rank, world_size, local_rank, backend
+        self.force_group = force_group
 
     @property
     def distributed(self):
-        return self.world_size > 1
+        """True when the collectives are issued: more than one rank -- or a process group of ONE rank that was asked
+        for explicitly (PP_FORCE_PROCESS_GROUP=1: the N > 1 code path, every all-reduce and barrier of it, on a box
+        with one GPU; the rehearsal of RCCL itself that two ranks on one device cannot give)."""
+        return self.world_size > 1 or self.force_group
 
 
 def private_miopen_cache(local_rank, root=None):
@@ -39,11 +43,13 @@ def private_miopen_cache(local_rank, root=None):
 
 def init_from_env(backend=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract); a
-    single process without those variables is world_size 1, no process group."""
+    single process without those variables is world_size 1, no process group
+    (unless PP_FORCE_PROCESS_GROUP=1 asks for a group of one rank: ShardContext.distributed)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = world == 1 and os.environ.get("PP_FORCE_PROCESS_GROUP") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         # The pool's operating notes: the host driver supports dmabuf IPC only, and RCCL needs this variable where the
         # environment does not already carry it -- set if absent, never overridden.  HIP / HSA read their environment
         # when they initialise, so this is done BEFORE anything below touches the device (torch.cuda.is_available()
@@ -59,8 +65,10 @@ def init_from_env(backend=None):
             # first collective, no barrier-on-wrong-device warning)
             kw["device_id"] = torch.device("cuda", local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force:
+            os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    return ShardContext(rank, world, local, backend)
+    return ShardContext(rank, world, local, backend, force_group=force and dist.is_initialized())
 
 
 def sweeps_for_rank(num_sweeps, rank, world_size):

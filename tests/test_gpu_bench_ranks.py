@@ -144,3 +144,34 @@ def test_four_ranks_gloo_shared_device_forward(gpu, tmp_path):
     roots = [d for d in os.listdir(tmp_path) if d.startswith("pp_miopen_")]
     assert roots and sorted(os.listdir(os.path.join(tmp_path, roots[0]))) == ["rank0", "rank1", "rank2", "rank3"]
     assert wall < 600, f"{wall:.0f} s for the N = 4 line"
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_runs_the_multi_rank_code_path(gpu, tmp_path):
+    """RCCL under bench.py: `PP_FORCE_PROCESS_GROUP=1 python bench.py --gpus 1 --backend nccl` makes a process group of ONE
+    rank on the `nccl` backend and takes the N > 1 code path through it -- barriers around the timed loops, the
+    max-over-ranks reduction, the per-rank all-reduces behind `ranks_min_max`, and the train leg's positive-count,
+    gradient and loss-scalar all-reduces -- on the one GPU of a box (two ranks on one device are refused by RCCL; the
+    gloo rehearsals above cover world sizes 2 and 4).  The line must be the N = 1 line with a `collectives` record that
+    names RCCL.  (/root/reference train.py:88-89,120-121.)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--train-steps", "2",
+           "--backend", "nccl", "--no-cpu-baseline", "--no-stress", "--no-dropin", "--no-next-rows", "--no-live-traffic",
+           "--no-fused"]
+    env = dict(os.environ, TMPDIR=str(tmp_path), PP_FORCE_PROCESS_GROUP="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["collectives"]["backend"] == "nccl" and out["collectives"]["world_size"] == 1
+    tr = out["train_c3"]
+    assert tr["collectives"]["backend"] == "nccl" and tr["collectives"]["world_size"] == 1
+    assert tr["allreduce_ms"] > 0                         # the gradient buckets went through ncclAllReduce
+    assert len(out["roofline"]["ranks_min_max"]["per_rank_avg_launch_us"]) == 1
