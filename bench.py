@@ -246,6 +246,17 @@ def dropin_host(reps=15):
     hip_call, _ = _median_ms(call_hip, 2 * reps, warm=4)
     cpu_call, _ = _median_ms(call_cpu, max(5, reps // 2))
     fth_call, _ = _median_ms(call_fth, max(5, reps // 2))
+
+    def fresh(create):     # the call on arrays FRESH from np.zeros (data/dataset.py:89-90): their first touch -- a page fault
+        ts = []            # per 4 KB of every row written -- falls inside the call, whoever makes it
+        for _ in range(2 + max(7, reps // 2)):
+            pillar, indices = np.zeros((P, N, 9)), np.zeros((P, 3))
+            t0_ = time.perf_counter()
+            create(agg.transpose([1, 0]), pillar, indices, *cp_args)
+            ts.append(time.perf_counter() - t0_)
+            del pillar, indices
+        return float(np.median(ts[2:])) * 1e3
+    hip_fresh, cpu_fresh = fresh(mod.create_pillars), fresh(cpu_mod.create_pillars)
     # the caller's own statements are page-fault bound (np.zeros of 86 MB per run): the three variants take turns, so that
     # whatever the allocator and the page cache do drifts over all of them alike
     glues = [glue(mod.create_pillars), glue(cpu_mod.create_pillars), glue(fth_mod.create_pillars)]
@@ -276,11 +287,15 @@ def dropin_host(reps=15):
     return {
         "module": "native/" + os.path.basename(_lib.pybind_module_path()) + " (pybind11, csrc/pillars_module.cpp -> "
                   "pp_create_pillars_f64 / pp_make_ious_f64)",
-        "create_pillars_call": dropin_record(
+        "create_pillars_call": dict(dropin_record(
             hip_call, cpu_call, "pillars.create_pillars(points f64 [n,4] strided view, tensor f64 [P,N,9], indices f64 "
             "[P,3], ...) at configs[1]'s shapes on pre-zeroed arrays, the call alone; median of "
             f"{2 * reps}; cpu = the oracle's reference-style create_pillars (hash map of heap nodes) on one core; the module "
             "gathers, scatters and (make_ious) zero-fills on a pool of host threads (PP_HOST_THREADS, default 8)", fth_call),
+            fresh_arrays={"hip_ms": round(hip_fresh, 4), "cpu_ms": round(cpu_fresh, 4),
+                          "speedup": round(cpu_fresh / hip_fresh, 2),
+                          "what": "the same call on arrays fresh from np.zeros, as data/dataset.py:89-90 hands them over: "
+                                  "the first-touch page faults of the rows written are inside the call on either side"}),
         "create_pillars_in_dataset_glue": dropin_record(
             hip_glue, cpu_glue, "the same call inside the reference caller's own statements (data/dataset.py:88-106: two "
             "np.zeros incl. the 86 MB f64 tensor, the call, transpose to [9,P,N], .float(), .long()): the glue is "

@@ -104,6 +104,8 @@ def test_bench_contract_line(gpu):
         assert r["hip_ms"] > 0 and r["cpu_ms"] > 0 and abs(r["speedup"] - r["cpu_ms"] / r["hip_ms"]) < 1e-9
         assert r["meets_50x"] == (r["speedup"] >= 50.0)
         assert r["faithful_cpu_ms"] > 0 and abs(r["faithful_speedup"] - r["faithful_cpu_ms"] / r["hip_ms"]) < 1e-9
+    fa = dh["create_pillars_call"]["fresh_arrays"]
+    assert fa["hip_ms"] > 0 and fa["cpu_ms"] > fa["hip_ms"] and abs(fa["speedup"] - fa["cpu_ms"] / fa["hip_ms"]) < 0.02
     # make_ious with the anchors resident (the reference's call pattern) and with one anchor edited before every call
     mi = dh["make_ious_call"]
     assert mi["anchors_changed_every_call_ms"] >= mi["hip_ms"] * 0.9
